@@ -1,0 +1,223 @@
+/*
+ * include/popsift_hip.h -- C-ABI of the MI355X-native SIFT extraction hot path.
+ *
+ * This is the drop-in boundary: the C++14 host library (popsift_amd/csrc/host, classes
+ * PopSift / SiftJob / popsift::Config / popsift::FeaturesHost with the reference's
+ * signatures) sits above it, the hand-written HIP kernels for gfx950 sit below it.
+ * Plain pointers and sizes only; no HIP, torch or C++ types; every function returns an
+ * int status (PSX_OK == 0) and never throws.  psx_last_error() gives the message the C++
+ * layer turns into std::runtime_error, the reference's error convention
+ * (common/debug_macros.h:122-127 POP_FATAL).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/src/popsift).
+ */
+#ifndef POPSIFT_HIP_H
+#define POPSIFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSX_OK                 0
+#define PSX_ERR_INVALID       -1   /* bad argument / unsupported mode          */
+#define PSX_ERR_HIP           -2   /* a HIP runtime call failed                */
+#define PSX_ERR_NOMEM         -3   /* host or device allocation failed         */
+#define PSX_ERR_STATE         -4   /* call sequence error (e.g. no image set)  */
+
+#define PSX_MAX_OCTAVES       20   /* sift_conf.h:12  MAX_OCTAVES              */
+#define PSX_GAUSS_ALIGN       32   /* sift_constants.h:37 GAUSS_ALIGN          */
+#define PSX_GAUSS_LEVELS      12   /* sift_constants.h:38 GAUSS_LEVELS         */
+#define PSX_ORI_MAX            4   /* sift_constants.h:55 ORIENTATION_MAX_COUNT*/
+
+/* popsift::Config::GaussMode, sift_conf.h:38-46 */
+enum { PSX_GAUSS_VLFEAT_COMPUTE = 0, PSX_GAUSS_VLFEAT_RELATIVE = 1, PSX_GAUSS_VLFEAT_RELATIVE_ALL = 2,
+       PSX_GAUSS_OPENCV_COMPUTE = 3, PSX_GAUSS_FIXED9 = 4, PSX_GAUSS_FIXED15 = 5 };
+/* popsift::Config::SiftMode, sift_conf.h:51-61 */
+enum { PSX_MODE_POPSIFT = 0, PSX_MODE_OPENCV = 1, PSX_MODE_VLFEAT = 2 };
+/* popsift::Config::ScalingMode, sift_conf.h:75-80 */
+enum { PSX_SCALE_DIRECT = 0, PSX_SCALE_DEFAULT = 1 };
+/* popsift::Config::DescMode, sift_conf.h:85-97 */
+enum { PSX_DESC_LOOP = 0, PSX_DESC_ILOOP = 1, PSX_DESC_GRID = 2, PSX_DESC_IGRID = 3, PSX_DESC_NOTILE = 4 };
+/* popsift::Config::NormMode, sift_conf.h:102-108 */
+enum { PSX_NORM_ROOTSIFT = 0, PSX_NORM_CLASSIC = 1 };
+/* popsift::Config::GridFilterMode, sift_conf.h:118-125 */
+enum { PSX_FILTER_RANDOM = 0, PSX_FILTER_LARGEST_FIRST = 1, PSX_FILTER_SMALLEST_FIRST = 2 };
+
+/* POD image of popsift::Config (sift_conf.h:29-409; defaults sift_conf.cu:18-41). */
+typedef struct psx_config {
+    int   octaves;             /* -1: auto = max(floor(log2(min(w,h))) - 3 + 2^up, 1), popsift.cpp:118-122 */
+    int   levels;              /* 3 */
+    float sigma;               /* 1.6 */
+    float edge_limit;          /* 10 */
+    float threshold;           /* 0.04 */
+    float upscale_factor;      /* 1.0 (Config::setDownsampling stores -v) */
+    int   gauss_mode;          /* PSX_GAUSS_VLFEAT_COMPUTE */
+    int   sift_mode;           /* PSX_MODE_POPSIFT */
+    int   scaling_mode;        /* PSX_SCALE_DEFAULT */
+    int   desc_mode;           /* PSX_DESC_LOOP */
+    int   norm_mode;           /* PSX_NORM_ROOTSIFT */
+    int   norm_multi;          /* 0 */
+    int   max_extrema;         /* 100000 per octave */
+    int   assume_initial_blur; /* 1 */
+    float initial_blur;        /* 0.5 */
+    int   filter_max_extrema;  /* -1 (grid filter off) */
+    int   filter_grid_size;    /* 2 */
+    int   grid_filter_mode;    /* PSX_FILTER_RANDOM */
+} psx_config;
+
+/* One keypoint as handed back to the host: popsift::Feature (features.h:23-37) with the
+ * four Descriptor* replaced by indices into the descriptor array (-1 == nullptr); the C++
+ * layer turns them into pointers into its own FeaturesHost storage, which removes the
+ * reference's device-side host-pointer arithmetic (sift_pyramid.cu:242-280). */
+typedef struct psx_feature {
+    int   debug_octave;
+    float xpos;
+    float ypos;
+    float sigma;
+    int   num_ori;
+    float orientation[PSX_ORI_MAX];
+    int   desc_idx[PSX_ORI_MAX];
+} psx_feature;
+
+/* popsift::InitialExtremum (sift_extremum.h:25-39) as stored by the extrema kernel. */
+typedef struct psx_iext {
+    float xpos;
+    float ypos;
+    int   lpos;
+    float sigma;
+    int   cell;
+    int   ignore;
+} psx_iext;
+
+/* popsift::Extremum (sift_extremum.h:47-63). */
+typedef struct psx_extremum {
+    float xpos;
+    float ypos;
+    int   lpos;
+    float sigma;
+    int   octave;
+    int   num_ori;
+    int   idx_ori;
+    float orientation[PSX_ORI_MAX];
+} psx_extremum;
+
+typedef struct psx_ctx psx_ctx;   /* one Pyramid + its buffers + one HIP stream */
+
+/* ---- configuration -------------------------------------------------------------------- */
+
+/* Config::Config() defaults, sift_conf.cu:18-41 (without its cudaGetDevice side effect). */
+int psx_config_default(psx_config* cfg);
+
+/* Config::getPeakThreshold(), sift_conf.cu:276-279. */
+float psx_peak_threshold(const psx_config* cfg);
+
+/* init_filter() host part (gauss_filter.cu:127-237): fills the "inc" and "dd" tables.
+ * inc_filter: PSX_GAUSS_LEVELS*PSX_GAUSS_ALIGN floats, dd_filter: PSX_MAX_OCTAVES*PSX_GAUSS_ALIGN.
+ * Error cases of gauss_filter.cu:131-144 (sigma > 2, too many levels) return PSX_ERR_INVALID. */
+int psx_gauss_tables(const psx_config* cfg, float* inc_filter, int* inc_span, float* inc_sigma,
+                     float* dd_filter, int* dd_span, float* dd_sigma);
+
+/* ---- context -------------------------------------------------------------------------- */
+
+/* Replaces PopSift::PopSift + applyConfiguration (popsift.cpp:25-48, 91-107): selects the
+ * device, uploads Gauss tables / constants into the context (no global symbols), creates the
+ * stream.  Modes outside the default branch of build_pyramid (s_pyramid_build.cu:547-575) and
+ * DescMode != Loop return PSX_ERR_INVALID ("not yet", sift_desc.cu:80-82). */
+int psx_create(int device, const psx_config* cfg, psx_ctx** out);
+int psx_destroy(psx_ctx* ctx);
+const char* psx_last_error(const psx_ctx* ctx);   /* ctx may be NULL: last create() error */
+
+/* Replaces PopSift::private_init / Pyramid::Pyramid / Pyramid::resetDimensions
+ * (popsift.cpp:128-144, sift_pyramid.cu:108-177): (re)allocates pyramid planes for an input of
+ * w x h pixels.  Buffers only ever grow. */
+int psx_resize(psx_ctx* ctx, int w, int h);
+
+/* Octave geometry after psx_resize: popsift.cpp:124-125 and sift_pyramid.cu:129-134. */
+int psx_num_octaves(const psx_ctx* ctx);
+int psx_num_levels(const psx_ctx* ctx);           /* levels + 3 */
+int psx_octave_dims(const psx_ctx* ctx, int octave, int* w, int* h);
+
+/* ---- input ---------------------------------------------------------------------------- */
+
+/* Replaces Image::load / ImageFloat::load (s_image.cu:69-77, 193-201): host -> device copy of
+ * a tightly packed w*h plane, stream ordered.  Calls psx_resize when dimensions change. */
+int psx_upload_u8(psx_ctx* ctx, const uint8_t* host, int w, int h);
+int psx_upload_f32(psx_ctx* ctx, const float* host, int w, int h);
+
+/* Input already resident in HBM (tight w*h plane).  The pointer must stay valid until the
+ * extraction that uses it has finished.  No copy is made. */
+int psx_set_input_dev(psx_ctx* ctx, const void* dev_ptr, int w, int h, int is_float);
+
+/* ---- stages (all asynchronous on the context's stream) ---------------------------------- */
+
+/* Pyramid::step1 -> build_pyramid (s_pyramid_build.cu:459-594, default branch). */
+int psx_build_pyramid(psx_ctx* ctx);
+/* Pyramid::find_extrema (s_extrema.cu:560-640). */
+int psx_find_extrema(psx_ctx* ctx);
+/* Pyramid::orientation incl. ori_prefix_sum (s_orientation.cu:364-441) and the optional
+ * extrema_filter_grid (s_filtergrid.cu:113-325). */
+int psx_orientation(psx_ctx* ctx);
+/* Pyramid::descriptors incl. normalize_histogram (sift_desc.cu:55-110) and prep_features
+ * (sift_pyramid.cu:250-280). */
+int psx_descriptors(psx_ctx* ctx);
+/* step1 + step2 in one call (popsift.cpp:321-324). */
+int psx_extract(psx_ctx* ctx);
+
+/* Waits for everything queued on the context's stream. */
+int psx_sync(psx_ctx* ctx);
+
+/* ---- results -------------------------------------------------------------------------- */
+
+/* Pyramid::readDescCountersFromDevice (sift_pyramid.cu:373-381): synchronises, returns the
+ * number of keypoints and descriptors of the last extraction. */
+int psx_counts(psx_ctx* ctx, int* num_features, int* num_descriptors);
+
+/* Pyramid::get_descriptors (sift_pyramid.cu:282-322): copies num_features psx_feature records
+ * and num_descriptors*128 floats to host memory (capacities in elements); synchronises. */
+int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity,
+                 float* descriptors, int descriptor_capacity);
+
+/* Device-resident results (FeaturesDev, features.h:104-122): pointers valid until the next
+ * extraction on this context. */
+int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float** d_descriptors,
+                       const int** d_feat_to_ext);
+
+/* ---- introspection for parity tests (Octave::download_and_save_array, sift_octave.cu:111-188) */
+
+#define PSX_PLANE_GAUSS 0
+#define PSX_PLANE_DOG   1
+/* Copies one W*H float plane (tight) of the current pyramid to host memory; synchronises. */
+int psx_dump_plane(psx_ctx* ctx, int kind, int octave, int level, float* host_out);
+/* Initial extrema of one octave (i_ext_dat, sift_pyramid.h:44-48); returns the count. */
+int psx_dump_iext(psx_ctx* ctx, int octave, psx_iext* host_out, int capacity, int* count);
+/* Oriented extrema (dobuf.extrema) in octave-major order. */
+int psx_dump_extrema(psx_ctx* ctx, psx_extremum* host_out, int capacity, int* count);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+
+/* Stage timers: when enabled, HIP events bracket each stage group on the context's stream;
+ * psx_stage_times synchronises and returns milliseconds of the last extraction
+ * [0]=pyramid [1]=extrema [2]=orientation+scan [3]=descriptors+features. */
+int psx_enable_timers(psx_ctx* ctx, int on);
+int psx_stage_times(psx_ctx* ctx, float ms[4]);
+
+/* Times `reps` launches of the separable-Gaussian kernel of (octave, level>=1) with HIP events
+ * on the context's stream and returns the average duration in ms plus the algorithmic bytes
+ * of one launch (8 bytes per pixel: plane read once, written once). */
+int psx_time_blur(psx_ctx* ctx, int octave, int level, int reps, float* avg_ms, double* bytes);
+
+/* The HIP stream of the context as an opaque handle (hipStream_t), for callers that need to
+ * order their own work (e.g. a torch tensor producer) against it. */
+void* psx_stream(psx_ctx* ctx);
+
+/* Library version / build info string. */
+const char* psx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POPSIFT_HIP_H */

@@ -1,0 +1,219 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from popsift_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MAX_OCTAVES = 20
+GAUSS_ALIGN = 32
+GAUSS_LEVELS = 12
+ORI_MAX = 4
+
+GAUSS_VLFEAT_COMPUTE, GAUSS_VLFEAT_RELATIVE, GAUSS_VLFEAT_RELATIVE_ALL, GAUSS_OPENCV_COMPUTE, \
+    GAUSS_FIXED9, GAUSS_FIXED15 = range(6)
+MODE_POPSIFT, MODE_OPENCV, MODE_VLFEAT = 0, 1, 2
+NORM_ROOTSIFT, NORM_CLASSIC = 0, 1
+FILTER_RANDOM, FILTER_LARGEST_FIRST, FILTER_SMALLEST_FIRST = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("octaves", C.c_int), ("levels", C.c_int), ("sigma", C.c_float),
+        ("edge_limit", C.c_float), ("threshold", C.c_float), ("upscale_factor", C.c_float),
+        ("gauss_mode", C.c_int), ("sift_mode", C.c_int), ("norm_mode", C.c_int),
+        ("norm_multi", C.c_int), ("max_extrema", C.c_int), ("assume_initial_blur", C.c_int),
+        ("initial_blur", C.c_float), ("filter_max_extrema", C.c_int),
+        ("filter_grid_size", C.c_int), ("grid_filter_mode", C.c_int), ("literal_tex", C.c_int),
+    ]
+
+
+class Tables(C.Structure):
+    _fields_ = [
+        ("inc_filter", C.c_float * (GAUSS_LEVELS * GAUSS_ALIGN)),
+        ("inc_sigma", C.c_float * GAUSS_LEVELS),
+        ("inc_span", C.c_int * GAUSS_LEVELS),
+        ("dd_filter", C.c_float * (MAX_OCTAVES * GAUSS_ALIGN)),
+        ("dd_sigma", C.c_float * MAX_OCTAVES),
+        ("dd_span", C.c_int * MAX_OCTAVES),
+    ]
+
+
+IEXT_DTYPE = np.dtype([("xpos", "<f4"), ("ypos", "<f4"), ("lpos", "<i4"), ("sigma", "<f4"),
+                       ("cell", "<i4"), ("ignore", "<i4")])
+EXT_DTYPE = np.dtype([("xpos", "<f4"), ("ypos", "<f4"), ("lpos", "<i4"), ("sigma", "<f4"),
+                      ("octave", "<i4"), ("num_ori", "<i4"), ("idx_ori", "<i4"),
+                      ("orientation", "<f4", (ORI_MAX,))])
+FEAT_DTYPE = np.dtype([("debug_octave", "<i4"), ("xpos", "<f4"), ("ypos", "<f4"), ("sigma", "<f4"),
+                       ("num_ori", "<i4"), ("orientation", "<f4", (ORI_MAX,)),
+                       ("desc_idx", "<i4", (ORI_MAX,))])
+
+
+def build(force=False):
+    """Compile liboracle.so (gcc, a second or two)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("sift_oracle.c", "sift_oracle.h", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.osift_config_default.argtypes = [C.POINTER(Config)]
+        L.osift_peak_threshold.argtypes = [C.POINTER(Config)]
+        L.osift_peak_threshold.restype = C.c_float
+        L.osift_gauss_tables.argtypes = [C.POINTER(Config), C.POINTER(Tables)]
+        L.osift_gauss_tables.restype = C.c_int
+        for name in ("osift_run", "osift_run_pyramid"):
+            f = getattr(L, name)
+            f.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int, C.c_int, C.c_int]
+            f.restype = C.c_void_p
+        L.osift_free.argtypes = [C.c_void_p]
+        for name in ("osift_num_octaves", "osift_num_levels", "osift_ext_total", "osift_ori_total"):
+            f = getattr(L, name)
+            f.argtypes = [C.c_void_p]
+            f.restype = C.c_int
+        for name in ("osift_octave_width", "osift_octave_height", "osift_iext_count"):
+            f = getattr(L, name)
+            f.argtypes = [C.c_void_p, C.c_int]
+            f.restype = C.c_int
+        for name in ("osift_gauss_plane", "osift_dog_plane"):
+            f = getattr(L, name)
+            f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            f.restype = C.c_void_p
+        L.osift_get_iext.argtypes = [C.c_void_p, C.c_int]
+        L.osift_get_iext.restype = C.c_void_p
+        for name in ("osift_extrema", "osift_features", "osift_descriptors", "osift_feat_to_ext"):
+            f = getattr(L, name)
+            f.argtypes = [C.c_void_p]
+            f.restype = C.c_void_p
+        L.osift_set_threads.argtypes = [C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def default_config(**kw):
+    c = Config()
+    lib().osift_config_default(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def gauss_tables(cfg):
+    t = Tables()
+    rc = lib().osift_gauss_tables(C.byref(cfg), C.byref(t))
+    if rc != 0:
+        raise RuntimeError("osift_gauss_tables failed: %d" % rc)
+    return {
+        "inc_filter": np.array(t.inc_filter, dtype=np.float32).reshape(GAUSS_LEVELS, GAUSS_ALIGN),
+        "inc_sigma": np.array(t.inc_sigma, dtype=np.float32),
+        "inc_span": np.array(t.inc_span, dtype=np.int32),
+        "dd_filter": np.array(t.dd_filter, dtype=np.float32).reshape(MAX_OCTAVES, GAUSS_ALIGN),
+        "dd_sigma": np.array(t.dd_sigma, dtype=np.float32),
+        "dd_span": np.array(t.dd_span, dtype=np.int32),
+    }
+
+
+def _arr(ptr, dtype, count):
+    if count == 0 or not ptr:
+        return np.zeros((0,), dtype=dtype)
+    nbytes = np.dtype(dtype).itemsize * count
+    buf = (C.c_char * nbytes).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+class Result:
+    """Owning view of an osift_result."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("oracle run failed")
+        self._h = handle
+        L = lib()
+        self.num_octaves = L.osift_num_octaves(handle)
+        self.num_levels = L.osift_num_levels(handle)
+        self.dims = [(L.osift_octave_width(handle, o), L.osift_octave_height(handle, o))
+                     for o in range(self.num_octaves)]
+
+    def gauss(self, o, l):
+        w, h = self.dims[o]
+        return _arr(lib().osift_gauss_plane(self._h, o, l), np.float32, w * h).reshape(h, w)
+
+    def dog(self, o, l):
+        w, h = self.dims[o]
+        return _arr(lib().osift_dog_plane(self._h, o, l), np.float32, w * h).reshape(h, w)
+
+    def iext(self, o):
+        n = lib().osift_iext_count(self._h, o)
+        return _arr(lib().osift_get_iext(self._h, o), IEXT_DTYPE, n)
+
+    @property
+    def ext_total(self):
+        return lib().osift_ext_total(self._h)
+
+    @property
+    def ori_total(self):
+        return lib().osift_ori_total(self._h)
+
+    def extrema(self):
+        return _arr(lib().osift_extrema(self._h), EXT_DTYPE, self.ext_total)
+
+    def features(self):
+        return _arr(lib().osift_features(self._h), FEAT_DTYPE, self.ext_total)
+
+    def descriptors(self):
+        return _arr(lib().osift_descriptors(self._h), np.float32, self.ori_total * 128).reshape(-1, 128)
+
+    def feat_to_ext(self):
+        return _arr(lib().osift_feat_to_ext(self._h), np.int32, self.ori_total)
+
+    def close(self):
+        if self._h:
+            lib().osift_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _img_args(img):
+    img = np.ascontiguousarray(img)
+    if img.dtype == np.uint8:
+        is_float = 0
+    elif img.dtype == np.float32:
+        is_float = 1
+    else:
+        raise TypeError("image must be uint8 or float32")
+    h, w = img.shape
+    return img, w, h, is_float
+
+
+def run(cfg, img, threads=0):
+    img, w, h, is_float = _img_args(img)
+    lib().osift_set_threads(threads)
+    return Result(lib().osift_run(C.byref(cfg), img.ctypes.data_as(C.c_void_p), w, h, is_float))
+
+
+def run_pyramid(cfg, img, threads=0):
+    img, w, h, is_float = _img_args(img)
+    lib().osift_set_threads(threads)
+    return Result(lib().osift_run_pyramid(C.byref(cfg), img.ctypes.data_as(C.c_void_p), w, h, is_float))

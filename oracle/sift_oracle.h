@@ -1,0 +1,145 @@
+/*
+ * oracle/sift_oracle.h -- CPU restatement of the PopSift extraction path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (popsift_amd/, include/) may
+ * include, link or call this.  Allowed users: tests/, __graft_entry__.smoke(),
+ * and the cpu_baseline leg of bench.py.
+ *
+ * The oracle restates, op by op, the arithmetic of the reference's default path
+ * (reference = alicevision/popsift, paths relative to /root/reference/src/popsift):
+ *   Gauss tables            gauss_filter.cu:127-371
+ *   octave-0 level-0 pass   s_pyramid_build_ra.cu:17-55, s_pyramid_build.cu:96-126
+ *   H / V blur              s_pyramid_build_aa.cu:17-86
+ *   2x decimation           s_pyramid_build.cu:50-71
+ *   DoG                     s_pyramid_build.cu:74-92
+ *   extrema + refinement    s_extrema.cu:56-503, s_solve.h:25-86
+ *   orientation             s_orientation.cu:39-259, s_gradiant.h:56-69
+ *   orientation scan        s_orientation.cu:320-362
+ *   descriptor (loop)       s_desc_loop.cu:19-139
+ *   normalisation           s_desc_norm_rs.h:42-77, s_desc_norm_l2.h:86-135
+ *   output mapping          sift_pyramid.cu:250-280
+ *   grid filter             s_filtergrid.cu:36-325
+ *
+ * PARITY PIN STATUS: the reference ships no golden vectors (its goldens are an
+ * external reference.tgz fetched by wget, testScripts/downloadOxfordDataset.sh.in:4-9).
+ * The restatement is pinned instead against the reference's own sources compiled
+ * for the CPU through a CUDA-emulation shim (oracle/_ref, see oracle/Makefile and
+ * oracle/ref_shim/); see DESIGN.md "Oracle".
+ */
+#ifndef SIFT_ORACLE_H
+#define SIFT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSIFT_MAX_OCTAVES 20
+#define OSIFT_GAUSS_ALIGN 32
+#define OSIFT_GAUSS_LEVELS 12
+#define OSIFT_ORI_MAX 4
+
+/* enum values mirror popsift::Config (sift_conf.h:38-136) */
+enum { OSIFT_GAUSS_VLFEAT_COMPUTE = 0, OSIFT_GAUSS_VLFEAT_RELATIVE = 1,
+       OSIFT_GAUSS_VLFEAT_RELATIVE_ALL = 2, OSIFT_GAUSS_OPENCV_COMPUTE = 3,
+       OSIFT_GAUSS_FIXED9 = 4, OSIFT_GAUSS_FIXED15 = 5 };
+enum { OSIFT_MODE_POPSIFT = 0, OSIFT_MODE_OPENCV = 1, OSIFT_MODE_VLFEAT = 2 };
+enum { OSIFT_NORM_ROOTSIFT = 0, OSIFT_NORM_CLASSIC = 1 };
+enum { OSIFT_FILTER_RANDOM = 0, OSIFT_FILTER_LARGEST_FIRST = 1, OSIFT_FILTER_SMALLEST_FIRST = 2 };
+
+typedef struct osift_config {
+    int   octaves;            /* -1 = auto (popsift.cpp:118-122) */
+    int   levels;             /* 3 */
+    float sigma;              /* 1.6 */
+    float edge_limit;         /* 10 */
+    float threshold;          /* 0.04 */
+    float upscale_factor;     /* 1.0 (= -downsampling) */
+    int   gauss_mode;         /* VLFeat_Compute */
+    int   sift_mode;          /* PopSift */
+    int   norm_mode;          /* RootSift */
+    int   norm_multi;         /* 0 */
+    int   max_extrema;        /* 100000 per octave */
+    int   assume_initial_blur;/* 1 */
+    float initial_blur;       /* 0.5 */
+    int   filter_max_extrema; /* -1 */
+    int   filter_grid_size;   /* 2 */
+    int   grid_filter_mode;   /* RandomScale */
+    int   literal_tex;        /* oracle-only: 1 = per-tap texture coordinates exactly as
+                                 s_pyramid_build_ra.cu:35-50; 0 = upsampled-row form */
+} osift_config;
+
+/* sift_extremum.h:25-39 (fields used on the path) */
+typedef struct osift_iext {
+    float xpos, ypos;
+    int   lpos;
+    float sigma;
+    int   cell;
+    int   ignore;
+} osift_iext;
+
+/* sift_extremum.h:47-63 */
+typedef struct osift_ext {
+    float xpos, ypos;
+    int   lpos;
+    float sigma;
+    int   octave;
+    int   num_ori;
+    int   idx_ori;
+    float orientation[OSIFT_ORI_MAX];
+} osift_ext;
+
+/* features.h:23-37, with descriptor pointers replaced by indices (-1 = nullptr) */
+typedef struct osift_feature {
+    int   debug_octave;
+    float xpos, ypos, sigma;
+    int   num_ori;
+    float orientation[OSIFT_ORI_MAX];
+    int   desc_idx[OSIFT_ORI_MAX];
+} osift_feature;
+
+typedef struct osift_tables {
+    float inc_filter[OSIFT_GAUSS_LEVELS * OSIFT_GAUSS_ALIGN];
+    float inc_sigma[OSIFT_GAUSS_LEVELS];
+    int   inc_span[OSIFT_GAUSS_LEVELS];
+    float dd_filter[OSIFT_MAX_OCTAVES * OSIFT_GAUSS_ALIGN];
+    float dd_sigma[OSIFT_MAX_OCTAVES];
+    int   dd_span[OSIFT_MAX_OCTAVES];
+} osift_tables;
+
+typedef struct osift_result osift_result;
+
+void  osift_config_default(osift_config* c);
+float osift_peak_threshold(const osift_config* c);               /* sift_conf.cu:276-279 */
+int   osift_gauss_tables(const osift_config* c, osift_tables* t);/* gauss_filter.cu:127-257 */
+
+/* Full run. img is w*h bytes (is_float=0, 0..255) or w*h floats (is_float=1, [0,1)). */
+osift_result* osift_run(const osift_config* c, const void* img, int w, int h, int is_float);
+/* Pyramid only (no extrema/orientation/descriptors); for stage-level parity tests. */
+osift_result* osift_run_pyramid(const osift_config* c, const void* img, int w, int h, int is_float);
+void  osift_free(osift_result* r);
+
+int   osift_num_octaves(const osift_result* r);
+int   osift_num_levels(const osift_result* r);        /* levels+3 Gaussian levels */
+int   osift_octave_width(const osift_result* r, int o);
+int   osift_octave_height(const osift_result* r, int o);
+const float* osift_gauss_plane(const osift_result* r, int o, int l);  /* W*H floats, tight */
+const float* osift_dog_plane(const osift_result* r, int o, int l);
+
+int   osift_iext_count(const osift_result* r, int o);
+const osift_iext* osift_get_iext(const osift_result* r, int o);
+
+int   osift_ext_total(const osift_result* r);
+int   osift_ori_total(const osift_result* r);
+const osift_ext*     osift_extrema(const osift_result* r);
+const osift_feature* osift_features(const osift_result* r);
+const float*         osift_descriptors(const osift_result* r);   /* ori_total * 128 */
+const int*           osift_feat_to_ext(const osift_result* r);   /* ori_total */
+
+/* set number of OpenMP threads used by osift_run (0 = library default) */
+void  osift_set_threads(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

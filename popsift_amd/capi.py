@@ -1,0 +1,280 @@
+"""ctypes binding of the C-ABI (include/popsift_hip.h) -> popsift_amd/lib/libpopsift_hip.so.
+
+This is plumbing for tests and bench.py; the product host side is the C++14 library
+(popsift_amd/csrc/host).  The binding fails loudly when the HIP library is missing: there is
+no CPU fallback anywhere in the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpopsift_hip.so")
+
+MAX_OCTAVES = 20
+GAUSS_ALIGN = 32
+GAUSS_LEVELS = 12
+ORI_MAX = 4
+
+GAUSS_VLFEAT_COMPUTE, GAUSS_VLFEAT_RELATIVE, GAUSS_VLFEAT_RELATIVE_ALL, GAUSS_OPENCV_COMPUTE, \
+    GAUSS_FIXED9, GAUSS_FIXED15 = range(6)
+MODE_POPSIFT, MODE_OPENCV, MODE_VLFEAT = 0, 1, 2
+SCALE_DIRECT, SCALE_DEFAULT = 0, 1
+DESC_LOOP, DESC_ILOOP, DESC_GRID, DESC_IGRID, DESC_NOTILE = range(5)
+NORM_ROOTSIFT, NORM_CLASSIC = 0, 1
+FILTER_RANDOM, FILTER_LARGEST_FIRST, FILTER_SMALLEST_FIRST = 0, 1, 2
+PLANE_GAUSS, PLANE_DOG = 0, 1
+
+
+class Config(C.Structure):
+    """POD image of popsift::Config (psx_config)."""
+    _fields_ = [
+        ("octaves", C.c_int), ("levels", C.c_int), ("sigma", C.c_float), ("edge_limit", C.c_float),
+        ("threshold", C.c_float), ("upscale_factor", C.c_float), ("gauss_mode", C.c_int),
+        ("sift_mode", C.c_int), ("scaling_mode", C.c_int), ("desc_mode", C.c_int),
+        ("norm_mode", C.c_int), ("norm_multi", C.c_int), ("max_extrema", C.c_int),
+        ("assume_initial_blur", C.c_int), ("initial_blur", C.c_float),
+        ("filter_max_extrema", C.c_int), ("filter_grid_size", C.c_int), ("grid_filter_mode", C.c_int),
+    ]
+
+
+FEATURE_DTYPE = np.dtype([("debug_octave", "<i4"), ("xpos", "<f4"), ("ypos", "<f4"), ("sigma", "<f4"),
+                          ("num_ori", "<i4"), ("orientation", "<f4", (ORI_MAX,)),
+                          ("desc_idx", "<i4", (ORI_MAX,))])
+IEXT_DTYPE = np.dtype([("xpos", "<f4"), ("ypos", "<f4"), ("lpos", "<i4"), ("sigma", "<f4"),
+                       ("cell", "<i4"), ("ignore", "<i4")])
+EXT_DTYPE = np.dtype([("xpos", "<f4"), ("ypos", "<f4"), ("lpos", "<i4"), ("sigma", "<f4"),
+                      ("octave", "<i4"), ("num_ori", "<i4"), ("idx_ori", "<i4"),
+                      ("orientation", "<f4", (ORI_MAX,))])
+
+# every symbol include/popsift_hip.h declares
+SYMBOLS = [
+    "psx_version", "psx_config_default", "psx_peak_threshold", "psx_gauss_tables", "psx_create",
+    "psx_destroy", "psx_last_error", "psx_resize", "psx_num_octaves", "psx_num_levels",
+    "psx_octave_dims", "psx_upload_u8", "psx_upload_f32", "psx_set_input_dev", "psx_build_pyramid",
+    "psx_find_extrema", "psx_orientation", "psx_descriptors", "psx_extract", "psx_sync", "psx_counts",
+    "psx_download", "psx_device_results", "psx_dump_plane", "psx_dump_iext", "psx_dump_extrema",
+    "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
+]
+
+_LIB = None
+
+
+class PopSiftError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise PopSiftError(
+                "%s is missing: build it with `python -m popsift_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+        L.psx_version.restype = C.c_char_p
+        L.psx_config_default.argtypes = [C.POINTER(Config)]
+        L.psx_peak_threshold.argtypes = [C.POINTER(Config)]
+        L.psx_peak_threshold.restype = C.c_float
+        L.psx_gauss_tables.argtypes = [C.POINTER(Config), fp, ip, fp, fp, ip, fp]
+        L.psx_create.argtypes = [C.c_int, C.POINTER(Config), C.POINTER(vp)]
+        L.psx_destroy.argtypes = [vp]
+        L.psx_last_error.argtypes = [vp]
+        L.psx_last_error.restype = C.c_char_p
+        L.psx_resize.argtypes = [vp, C.c_int, C.c_int]
+        L.psx_num_octaves.argtypes = [vp]
+        L.psx_num_levels.argtypes = [vp]
+        L.psx_octave_dims.argtypes = [vp, C.c_int, ip, ip]
+        L.psx_upload_u8.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.psx_upload_f32.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.psx_set_input_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+        for n in ("psx_build_pyramid", "psx_find_extrema", "psx_orientation", "psx_descriptors",
+                  "psx_extract", "psx_sync"):
+            getattr(L, n).argtypes = [vp]
+        L.psx_counts.argtypes = [vp, ip, ip]
+        L.psx_download.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+        L.psx_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        L.psx_dump_plane.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+        L.psx_dump_iext.argtypes = [vp, C.c_int, vp, C.c_int, ip]
+        L.psx_dump_extrema.argtypes = [vp, vp, C.c_int, ip]
+        L.psx_enable_timers.argtypes = [vp, C.c_int]
+        L.psx_stage_times.argtypes = [vp, fp]
+        L.psx_time_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, C.POINTER(C.c_double)]
+        L.psx_stream.argtypes = [vp]
+        L.psx_stream.restype = vp
+        _LIB = L
+    return _LIB
+
+
+def default_config(**kw):
+    c = Config()
+    lib().psx_config_default(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
+def gauss_tables(cfg):
+    inc_f = (C.c_float * (GAUSS_LEVELS * GAUSS_ALIGN))()
+    inc_sp = (C.c_int * GAUSS_LEVELS)()
+    inc_sg = (C.c_float * GAUSS_LEVELS)()
+    dd_f = (C.c_float * (MAX_OCTAVES * GAUSS_ALIGN))()
+    dd_sp = (C.c_int * MAX_OCTAVES)()
+    dd_sg = (C.c_float * MAX_OCTAVES)()
+    rc = lib().psx_gauss_tables(C.byref(cfg), inc_f, inc_sp, inc_sg, dd_f, dd_sp, dd_sg)
+    if rc != 0:
+        raise PopSiftError("psx_gauss_tables failed (%d)" % rc)
+    return {
+        "inc_filter": np.array(inc_f, dtype=np.float32).reshape(GAUSS_LEVELS, GAUSS_ALIGN),
+        "inc_sigma": np.array(inc_sg, dtype=np.float32),
+        "inc_span": np.array(inc_sp, dtype=np.int32),
+        "dd_filter": np.array(dd_f, dtype=np.float32).reshape(MAX_OCTAVES, GAUSS_ALIGN),
+        "dd_sigma": np.array(dd_sg, dtype=np.float32),
+        "dd_span": np.array(dd_sp, dtype=np.int32),
+    }
+
+
+class Context:
+    """One extraction context (pyramid + buffers + HIP stream) on one device."""
+
+    def __init__(self, cfg=None, device=0):
+        self._h = C.c_void_p()
+        self.cfg = cfg if cfg is not None else default_config()
+        rc = lib().psx_create(device, C.byref(self.cfg), C.byref(self._h))
+        if rc != 0:
+            msg = lib().psx_last_error(None)
+            raise PopSiftError("psx_create failed (%d): %s" % (rc, msg.decode() if msg else ""))
+        self._keep = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = lib().psx_last_error(self._h)
+            raise PopSiftError("C-ABI call failed (%d): %s" % (rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if self._h:
+            lib().psx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- input -------------------------------------------------------------------------------
+    def upload(self, img):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape
+        if img.dtype == np.uint8:
+            self._chk(lib().psx_upload_u8(self._h, img.ctypes.data_as(C.c_void_p), w, h))
+        elif img.dtype == np.float32:
+            self._chk(lib().psx_upload_f32(self._h, img.ctypes.data_as(C.c_void_p), w, h))
+        else:
+            raise TypeError("image must be uint8 or float32")
+        self._keep = img
+
+    def set_input_dev(self, dev_ptr, w, h, is_float):
+        self._chk(lib().psx_set_input_dev(self._h, C.c_void_p(dev_ptr), w, h, 1 if is_float else 0))
+
+    def set_input_tensor(self, t):
+        """t: contiguous 2-D torch tensor (uint8 or float32) already on this context's device."""
+        assert t.is_contiguous() and t.dim() == 2
+        import torch
+        is_float = t.dtype == torch.float32
+        assert is_float or t.dtype == torch.uint8
+        self._keep = t
+        self.set_input_dev(t.data_ptr(), t.shape[1], t.shape[0], is_float)
+
+    # ---- stages ------------------------------------------------------------------------------
+    def resize(self, w, h):
+        self._chk(lib().psx_resize(self._h, w, h))
+
+    def build_pyramid(self):
+        self._chk(lib().psx_build_pyramid(self._h))
+
+    def find_extrema(self):
+        self._chk(lib().psx_find_extrema(self._h))
+
+    def orientation(self):
+        self._chk(lib().psx_orientation(self._h))
+
+    def descriptors(self):
+        self._chk(lib().psx_descriptors(self._h))
+
+    def extract(self):
+        self._chk(lib().psx_extract(self._h))
+
+    def sync(self):
+        self._chk(lib().psx_sync(self._h))
+
+    # ---- results -----------------------------------------------------------------------------
+    @property
+    def num_octaves(self):
+        return lib().psx_num_octaves(self._h)
+
+    @property
+    def num_levels(self):
+        return lib().psx_num_levels(self._h)
+
+    def octave_dims(self, o):
+        w, h = C.c_int(), C.c_int()
+        self._chk(lib().psx_octave_dims(self._h, o, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def counts(self):
+        ne, no = C.c_int(), C.c_int()
+        self._chk(lib().psx_counts(self._h, C.byref(ne), C.byref(no)))
+        return ne.value, no.value
+
+    def download(self):
+        ne, no = self.counts()
+        feats = np.zeros((ne,), dtype=FEATURE_DTYPE)
+        desc = np.zeros((no, 128), dtype=np.float32)
+        self._chk(lib().psx_download(self._h, feats.ctypes.data_as(C.c_void_p), ne,
+                                     desc.ctypes.data_as(C.c_void_p), no))
+        return feats, desc
+
+    def dump_plane(self, kind, octave, level):
+        w, h = self.octave_dims(octave)
+        out = np.zeros((h, w), dtype=np.float32)
+        self._chk(lib().psx_dump_plane(self._h, kind, octave, level, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def dump_iext(self, octave):
+        n = C.c_int()
+        self._chk(lib().psx_dump_iext(self._h, octave, None, 0, C.byref(n)))
+        out = np.zeros((n.value,), dtype=IEXT_DTYPE)
+        if n.value:
+            self._chk(lib().psx_dump_iext(self._h, octave, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
+
+    def dump_extrema(self):
+        n = C.c_int()
+        self._chk(lib().psx_dump_extrema(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value,), dtype=EXT_DTYPE)
+        if n.value:
+            self._chk(lib().psx_dump_extrema(self._h, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
+
+    # ---- measurement -------------------------------------------------------------------------
+    def enable_timers(self, on=True):
+        self._chk(lib().psx_enable_timers(self._h, 1 if on else 0))
+
+    def stage_times(self):
+        ms = (C.c_float * 4)()
+        self._chk(lib().psx_stage_times(self._h, ms))
+        return [ms[i] for i in range(4)]
+
+    def time_blur(self, octave, level, reps=20):
+        ms, by = C.c_float(), C.c_double()
+        self._chk(lib().psx_time_blur(self._h, octave, level, reps, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    @property
+    def stream(self):
+        return lib().psx_stream(self._h)

@@ -1,0 +1,665 @@
+// api.hip -- implementation of the C-ABI declared in include/popsift_hip.h.
+//
+// One psx_ctx == one Pyramid of the reference (sift_pyramid.h:53-163) plus the state the
+// reference keeps in global __device__/__constant__/thread_local symbols (gauss tables
+// gauss_filter.cu:18-21, constants sift_constants.cu:19-20, counters and buffers
+// sift_pyramid.cu:41-49).  Because nothing is global, any number of contexts can live on one
+// device; the batch dispatcher uses that to keep several frames in flight per GPU.
+//
+// Stream model: every context owns one HIP stream; a frame is one stream-ordered chain
+//   memset(counters) -> k_level0 -> k_blur x (L-1) per octave -> k_extrema per octave
+//   -> k_orientation -> k_scan -> k_descriptors
+// with no host synchronisation inside the chain (the reference has four blocking counter
+// round-trips and four device-wide syncs per image).
+#include "psx_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline int imin(int a, int b) { return a < b ? a : b; }
+inline int imax(int a, int b) { return a > b ? a : b; }
+
+// ---- Gauss tables: restatement of gauss_filter.cu:127-371 (host arithmetic) -----------------
+int vlfeat_span(float sigma) { return imin((int)(ceilf(4.0f * sigma) + 1), PSX_GAUSS_ALIGN - 1); }
+int opencv_span(float sigma)
+{
+    int span = (int)(roundf(2.0f * 4.0f * sigma + 1.0f)) | 1;
+    span >>= 1;
+    span += 1;
+    return imin(span, PSX_GAUSS_ALIGN - 1);
+}
+int get_span(int mode, float sigma)
+{
+    switch (mode) {
+    case PSX_GAUSS_VLFEAT_RELATIVE_ALL:
+    case PSX_GAUSS_VLFEAT_COMPUTE: return vlfeat_span(sigma);
+    case PSX_GAUSS_VLFEAT_RELATIVE: { int s = vlfeat_span(sigma); if ((s & 1) == 0) s += 1; return s; }
+    case PSX_GAUSS_OPENCV_COMPUTE: return opencv_span(sigma);
+    case PSX_GAUSS_FIXED9: return 5;
+    case PSX_GAUSS_FIXED15: return 8;
+    default: return -1;
+    }
+}
+void blur_table(int mode, int nlev, const float* sigma, int* span, float* filter)
+{
+    for (int level = 0; level < nlev; level++)
+        span[level] = imin(get_span(mode, sigma[level]), PSX_GAUSS_ALIGN - 1);
+    for (int level = 0; level < nlev; level++) {
+        const float sig = sigma[level];
+        const int spn = span[level];
+        float* f = filter + level * PSX_GAUSS_ALIGN;
+        double sum = 1.0;
+        f[0] = 1.0f;
+        for (int x = 1; x < spn; x++) {
+            const float val = (float)std::exp(-0.5 * (std::pow(double(x) / sig, 2.0)));
+            f[x] = val;
+            sum += 2.0f * val;
+        }
+        for (int x = 0; x < spn; x++) f[x] = (float)(f[x] / sum);
+        for (int x = spn; x < PSX_GAUSS_ALIGN; x++) f[x] = 0.0f;
+    }
+}
+
+} // namespace
+
+struct psx_ctx {
+    int         device = 0;
+    psx_config  cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+
+    float inc_filter[PSX_GAUSS_LEVELS * PSX_GAUSS_ALIGN];
+    int   inc_span[PSX_GAUSS_LEVELS];
+    float inc_sigma[PSX_GAUSS_LEVELS];
+    float dd_filter[PSX_MAX_OCTAVES * PSX_GAUSS_ALIGN];
+    int   dd_span[PSX_MAX_OCTAVES];
+    float dd_sigma[PSX_MAX_OCTAVES];
+
+    int in_w = 0, in_h = 0;
+    int octaves_resolved = -1;         // sticky auto-octave value (popsift.cpp:118-122)
+    PsxParams    hp{};
+    PsxParams*   d_params = nullptr;
+    PsxCounters* d_cnt = nullptr;
+    PsxCounters* h_cnt = nullptr;      // pinned
+    bool counts_valid = false;
+
+    void*       d_input_own = nullptr; size_t input_cap = 0;
+    const void* d_input = nullptr;     int input_is_float = 0;
+
+    float* d_pyr = nullptr;            size_t pyr_cap = 0;      // floats
+    psx_iext* d_iext = nullptr;        size_t iext_cap = 0;
+    int* d_iext_off = nullptr;         size_t iext_off_cap = 0;
+    psx_extremum* d_extrema = nullptr; size_t extrema_cap = 0;
+    psx_feature* d_features = nullptr; size_t features_cap = 0;
+    float* d_desc = nullptr;           size_t desc_cap = 0;       // floats
+    int* d_feat_to_ext = nullptr;      size_t f2e_cap = 0;
+
+    bool timers = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+};
+
+namespace {
+
+int fail(psx_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define PSX_HIP(call)                                                                           \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            char buf__[512];                                                                    \
+            snprintf(buf__, sizeof(buf__), "%s:%d\n    %s failed: %s", __FILE__, __LINE__, #call, \
+                     hipGetErrorString(e__));                                                   \
+            return fail(ctx, PSX_ERR_HIP, buf__);                                               \
+        }                                                                                       \
+    } while (0)
+
+int compute_tables(const psx_config* cfg, float* inc_filter, int* inc_span, float* inc_sigma,
+                   float* dd_filter, int* dd_span, float* dd_sigma, std::string* why)
+{
+    const float sigma0 = cfg->sigma;
+    const int levels = cfg->levels;
+    if (sigma0 > 2.0) { if (why) *why = "ERROR:  Sigma > 2.0 is not supported."; return PSX_ERR_INVALID; }
+    if (levels + 3 > PSX_GAUSS_LEVELS) {
+        if (why) *why = "ERROR:  More than 12 levels not supported.";
+        return PSX_ERR_INVALID;
+    }
+    if (get_span(cfg->gauss_mode, 1.0f) < 0) {
+        if (why) *why = "ERROR: The mode for computing Gauss filter scan is invalid";
+        return PSX_ERR_INVALID;
+    }
+    memset(inc_filter, 0, sizeof(float) * PSX_GAUSS_LEVELS * PSX_GAUSS_ALIGN);
+    memset(inc_sigma, 0, sizeof(float) * PSX_GAUSS_LEVELS);
+    memset(dd_filter, 0, sizeof(float) * PSX_MAX_OCTAVES * PSX_GAUSS_ALIGN);
+    const int stages = levels + 3;
+    const float initial_blur = cfg->assume_initial_blur
+                             ? cfg->initial_blur * powf(2.0f, cfg->upscale_factor) : 0.0f;
+    inc_sigma[0] = cfg->assume_initial_blur
+                 ? sqrtf(fabsf(sigma0 * sigma0 - initial_blur * initial_blur)) : sigma0;
+    for (int lvl = 1; lvl < stages; lvl++) {
+        const float sigmaP = sigma0 * powf(2.0f, (float)(lvl - 1) / (float)levels);
+        const float sigmaS = sigma0 * powf(2.0f, (float)(lvl) / (float)levels);
+        inc_sigma[lvl] = sqrtf(sigmaS * sigmaS - sigmaP * sigmaP);
+    }
+    blur_table(cfg->gauss_mode, PSX_GAUSS_LEVELS, inc_sigma, inc_span, inc_filter);
+    for (int oct = 0; oct < PSX_MAX_OCTAVES; oct++) {
+        const float oct_sigma = scalbnf(sigma0, oct);
+        const float b = sqrtf(fabsf(oct_sigma * oct_sigma - initial_blur * initial_blur));
+        dd_sigma[oct] = scalbnf(b, -oct);
+    }
+    blur_table(cfg->gauss_mode, PSX_MAX_OCTAVES, dd_sigma, dd_span, dd_filter);
+    return PSX_OK;
+}
+
+PsxTaps taps_from(const float* row)
+{
+    PsxTaps t;
+    for (int i = 0; i < PSX_GAUSS_ALIGN; i++) t.g[i] = row[i];
+    return t;
+}
+
+template <class T>
+int grow(psx_ctx* ctx, T** ptr, size_t* cap, size_t need)
+{
+    if (need <= *cap && *ptr) return PSX_OK;
+    if (*ptr) { PSX_HIP(hipFree(*ptr)); *ptr = nullptr; *cap = 0; }
+    PSX_HIP(hipMalloc(reinterpret_cast<void**>(ptr), need * sizeof(T)));
+    *cap = need;
+    return PSX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* psx_version(void) { return "popsift-mi355x 0.1 (gfx950, HIP)"; }
+
+int psx_config_default(psx_config* c)
+{
+    if (!c) return PSX_ERR_INVALID;
+    memset(c, 0, sizeof(*c));
+    c->octaves = -1;
+    c->levels = 3;
+    c->sigma = 1.6f;
+    c->edge_limit = 10.0f;
+    c->threshold = (float)0.04;
+    c->upscale_factor = 1.0f;
+    c->gauss_mode = PSX_GAUSS_VLFEAT_COMPUTE;
+    c->sift_mode = PSX_MODE_POPSIFT;
+    c->scaling_mode = PSX_SCALE_DEFAULT;
+    c->desc_mode = PSX_DESC_LOOP;
+    c->norm_mode = PSX_NORM_ROOTSIFT;
+    c->norm_multi = 0;
+    c->max_extrema = 100000;
+    c->assume_initial_blur = 1;
+    c->initial_blur = 0.5f;
+    c->filter_max_extrema = -1;
+    c->filter_grid_size = 2;
+    c->grid_filter_mode = PSX_FILTER_RANDOM;
+    return PSX_OK;
+}
+
+float psx_peak_threshold(const psx_config* c) { return c->threshold * 0.5f * 255.0f / c->levels; }
+
+int psx_gauss_tables(const psx_config* cfg, float* inc_filter, int* inc_span, float* inc_sigma,
+                     float* dd_filter, int* dd_span, float* dd_sigma)
+{
+    if (!cfg || !inc_filter || !inc_span || !inc_sigma || !dd_filter || !dd_span || !dd_sigma)
+        return PSX_ERR_INVALID;
+    return compute_tables(cfg, inc_filter, inc_span, inc_sigma, dd_filter, dd_span, dd_sigma, nullptr);
+}
+
+const char* psx_last_error(const psx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int psx_create(int device, const psx_config* cfg, psx_ctx** out)
+{
+    psx_ctx* ctx = nullptr;   // PSX_HIP reports into g_create_error while ctx == nullptr
+    if (!cfg || !out) return fail(nullptr, PSX_ERR_INVALID, "psx_create: null argument");
+    *out = nullptr;
+    psx_config c = *cfg;
+    c.levels = imax(2, c.levels);                      // popsift.cpp:86
+    // branches of build_pyramid outside the default one, and descriptor modes other than loop
+    if (c.gauss_mode != PSX_GAUSS_VLFEAT_COMPUTE && c.gauss_mode != PSX_GAUSS_OPENCV_COMPUTE)
+        return fail(nullptr, PSX_ERR_INVALID, "gauss mode not supported by the HIP path (only vlfeat, opencv)");
+    if (c.scaling_mode != PSX_SCALE_DEFAULT)
+        return fail(nullptr, PSX_ERR_INVALID, "scaling mode ScaleDirect not supported by the HIP path");
+    if (c.desc_mode != PSX_DESC_LOOP)
+        return fail(nullptr, PSX_ERR_INVALID, "not yet");   // sift_desc.cu:80-82
+    if (c.sift_mode != PSX_MODE_POPSIFT && c.sift_mode != PSX_MODE_OPENCV && c.sift_mode != PSX_MODE_VLFEAT)
+        return fail(nullptr, PSX_ERR_INVALID, "invalid sift mode");
+    if (c.max_extrema <= 0 || c.filter_grid_size <= 0)
+        return fail(nullptr, PSX_ERR_INVALID, "invalid max_extrema / filter_grid_size");
+
+    PSX_HIP(hipSetDevice(device));
+    psx_ctx* n = new (std::nothrow) psx_ctx();
+    if (!n) return fail(nullptr, PSX_ERR_NOMEM, "out of host memory");
+    n->device = device;
+    n->cfg = c;
+    std::string why;
+    int rc = compute_tables(&n->cfg, n->inc_filter, n->inc_span, n->inc_sigma, n->dd_filter, n->dd_span,
+                            n->dd_sigma, &why);
+    if (rc != PSX_OK) { delete n; return fail(nullptr, rc, why); }
+    ctx = nullptr;
+#define PSX_HIPC(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            std::string m__ = std::string(#call) + " failed: " + hipGetErrorString(e__);         \
+            psx_destroy(n);                                                                     \
+            return fail(nullptr, PSX_ERR_HIP, m__);                                             \
+        }                                                                                       \
+    } while (0)
+    PSX_HIPC(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_params), sizeof(PsxParams)));
+    PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), sizeof(PsxCounters)));
+    PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_cnt), sizeof(PsxCounters), hipHostMallocDefault));
+    PSX_HIPC(hipMemset(n->d_cnt, 0, sizeof(PsxCounters)));
+    for (int i = 0; i < 5; i++) PSX_HIPC(hipEventCreate(&n->ev[i]));
+    PSX_HIPC(hipEventCreate(&n->ev_t0));
+    PSX_HIPC(hipEventCreate(&n->ev_t1));
+#undef PSX_HIPC
+    *out = n;
+    return PSX_OK;
+}
+
+int psx_destroy(psx_ctx* ctx)
+{
+    if (!ctx) return PSX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_params); (void)hipFree(ctx->d_cnt);
+    if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
+    (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr);
+    (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off);
+    (void)hipFree(ctx->d_extrema); (void)hipFree(ctx->d_features);
+    (void)hipFree(ctx->d_desc); (void)hipFree(ctx->d_feat_to_ext);
+    for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
+    if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PSX_OK;
+}
+
+int psx_resize(psx_ctx* ctx, int w, int h)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    if (w <= 0 || h <= 0) return fail(ctx, PSX_ERR_INVALID, "psx_resize: non-positive image size");
+    if (w == ctx->in_w && h == ctx->in_h && ctx->d_pyr) return PSX_OK;
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+
+    const psx_config& c = ctx->cfg;
+    // PopSift::private_apply_scale_factor, popsift.cpp:109-126
+    const float scaleFactor = 1.0f / powf(2.0f, -c.upscale_factor);
+    if (ctx->octaves_resolved < 0) {
+        if (c.octaves < 0)
+            ctx->octaves_resolved = imax((int)(floorf(logf((float)imin(w, h)) / logf(2.0f)) - 3.0f + scaleFactor), 1);
+        else
+            ctx->octaves_resolved = c.octaves;
+        ctx->octaves_resolved = imin(imax(ctx->octaves_resolved, 1), PSX_MAX_OCTAVES);
+    }
+    int ow = (int)ceilf(w * scaleFactor);
+    int oh = (int)ceilf(h * scaleFactor);
+    if (ow <= 0 || oh <= 0) return fail(ctx, PSX_ERR_INVALID, "psx_resize: scaled image is empty");
+
+    PsxParams& P = ctx->hp;
+    memset(&P, 0, sizeof(P));
+    P.num_octaves = ctx->octaves_resolved;
+    P.levels = c.levels;
+    P.L = c.levels + 3;
+    P.sift_mode = c.sift_mode;
+    P.norm_mode = c.norm_mode;
+    P.norm_multi = c.norm_multi;
+    P.max_extrema = c.max_extrema;
+    P.grid_size = c.filter_grid_size;
+    P.up_fac = (int)c.upscale_factor;
+    P.sigma0 = c.sigma;
+    P.sigma_k = powf(2.0f, 1.0f / c.levels);            // sift_constants.cu:27
+    P.threshold = psx_peak_threshold(&c);
+    P.edge_limit = c.edge_limit;
+
+    size_t total = 0;
+    size_t offs[PSX_MAX_OCTAVES];
+    for (int o = 0; o < P.num_octaves; o++) {
+        PsxOctave& oc = P.oct[o];
+        oc.w = ow; oc.h = oh;
+        oc.pitch = (ow + 63) & ~63;
+        oc.plane = (size_t)oc.pitch * oh;
+        offs[o] = total;
+        total += oc.plane * P.L;
+        P.w_grid_div[o] = float(ow) / c.filter_grid_size;   // sift_octave.cu:40-41
+        P.h_grid_div[o] = float(oh) / c.filter_grid_size;
+        ow = (int)ceilf(ow / 2.0f);                          // sift_pyramid.cu:132-133
+        oh = (int)ceilf(oh / 2.0f);
+    }
+    total += 64;   // slack: vector loads never run past the last plane
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_pyr, &ctx->pyr_cap, total)) != PSX_OK) return rc;
+    for (int o = 0; o < P.num_octaves; o++) P.oct[o].data = ctx->d_pyr + offs[o];
+
+    // buffers sized so that no counter read-back is needed before they are used
+    const size_t iext_need = (size_t)P.num_octaves * c.max_extrema;
+    const size_t ori_need = (size_t)imax(2 * (int)iext_need, c.max_extrema + c.max_extrema / 4);
+    if ((rc = grow(ctx, &ctx->d_iext, &ctx->iext_cap, iext_need)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_iext_off, &ctx->iext_off_cap, iext_need)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_extrema, &ctx->extrema_cap, iext_need)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_features, &ctx->features_cap, iext_need)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_desc, &ctx->desc_cap, ori_need * 128)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_feat_to_ext, &ctx->f2e_cap, ori_need)) != PSX_OK) return rc;
+    for (int o = 0; o < P.num_octaves; o++) {
+        P.iext[o] = ctx->d_iext + (size_t)o * c.max_extrema;
+        P.iext_off[o] = ctx->d_iext_off + (size_t)o * c.max_extrema;
+    }
+    P.ext_capacity = (int)iext_need;
+    P.ori_capacity = (int)ori_need;
+    P.extrema = ctx->d_extrema;
+    P.features = ctx->d_features;
+    P.desc = ctx->d_desc;
+    P.feat_to_ext = ctx->d_feat_to_ext;
+
+    PSX_HIP(hipMemcpy(ctx->d_params, &P, sizeof(P), hipMemcpyHostToDevice));
+    ctx->in_w = w; ctx->in_h = h;
+    ctx->counts_valid = false;
+    return PSX_OK;
+}
+
+int psx_num_octaves(const psx_ctx* ctx) { return ctx ? ctx->hp.num_octaves : 0; }
+int psx_num_levels(const psx_ctx* ctx) { return ctx ? ctx->hp.L : 0; }
+int psx_octave_dims(const psx_ctx* ctx, int o, int* w, int* h)
+{
+    if (!ctx || o < 0 || o >= ctx->hp.num_octaves) return PSX_ERR_INVALID;
+    if (w) *w = ctx->hp.oct[o].w;
+    if (h) *h = ctx->hp.oct[o].h;
+    return PSX_OK;
+}
+
+static int upload_common(psx_ctx* ctx, const void* host, int w, int h, int is_float)
+{
+    if (!ctx || !host) return PSX_ERR_INVALID;
+    int rc = psx_resize(ctx, w, h);
+    if (rc != PSX_OK) return rc;
+    PSX_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)w * h * (is_float ? 4 : 1);
+    if (bytes > ctx->input_cap) {
+        PSX_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_input_own) PSX_HIP(hipFree(ctx->d_input_own));
+        ctx->d_input_own = nullptr; ctx->input_cap = 0;
+        PSX_HIP(hipMalloc(&ctx->d_input_own, bytes + 64));
+        ctx->input_cap = bytes;
+    }
+    PSX_HIP(hipMemcpyAsync(ctx->d_input_own, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->d_input = ctx->d_input_own;
+    ctx->input_is_float = is_float;
+    return PSX_OK;
+}
+
+int psx_upload_u8(psx_ctx* ctx, const uint8_t* host, int w, int h) { return upload_common(ctx, host, w, h, 0); }
+int psx_upload_f32(psx_ctx* ctx, const float* host, int w, int h) { return upload_common(ctx, host, w, h, 1); }
+
+int psx_set_input_dev(psx_ctx* ctx, const void* dev_ptr, int w, int h, int is_float)
+{
+    if (!ctx || !dev_ptr) return PSX_ERR_INVALID;
+    int rc = psx_resize(ctx, w, h);
+    if (rc != PSX_OK) return rc;
+    ctx->d_input = dev_ptr;
+    ctx->input_is_float = is_float ? 1 : 0;
+    return PSX_OK;
+}
+
+static int launch_blur_level(psx_ctx* ctx, int o, int level)
+{
+    const PsxParams& P = ctx->hp;
+    const PsxOctave& oc = P.oct[o];
+    float* half_dst = nullptr; int half_pitch = 0;
+    if (level == P.L - 3 && o + 1 < P.num_octaves) {      // PREV_LEVEL 3, s_pyramid_build.cu:21,228
+        half_dst = P.oct[o + 1].data;
+        half_pitch = P.oct[o + 1].pitch;
+    }
+    PSX_HIP(psx_launch_blur(oc.data + (size_t)(level - 1) * oc.plane, oc.data + (size_t)level * oc.plane,
+                            oc.w, oc.h, oc.pitch, taps_from(ctx->inc_filter + level * PSX_GAUSS_ALIGN),
+                            ctx->inc_span[level], half_dst, half_pitch, ctx->stream));
+    return PSX_OK;
+}
+
+int psx_build_pyramid(psx_ctx* ctx)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    if (!ctx->d_input || !ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_build_pyramid: no input image");
+    PSX_HIP(hipSetDevice(ctx->device));
+    const PsxParams& P = ctx->hp;
+    const psx_config& c = ctx->cfg;
+    ctx->counts_valid = false;
+    if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    // Pyramid::reset_extrema_mgmt, sift_pyramid.cu:364-371
+    PSX_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(PsxCounters), ctx->stream));
+
+    PsxLevel0Args a;
+    a.img = ctx->d_input; a.w = ctx->in_w; a.h = ctx->in_h; a.is_float = ctx->input_is_float;
+    a.dst = P.oct[0].data; a.W = P.oct[0].w; a.H = P.oct[0].h; a.pitch = P.oct[0].pitch;
+    a.shift = 0.5f;                                                    // s_pyramid_build.cu:109-114
+    if (c.sift_mode == PSX_MODE_POPSIFT || c.sift_mode == PSX_MODE_VLFEAT)
+        a.shift = 0.5f * powf(2.0f, c.upscale_factor - 0);
+    a.taps_h = taps_from(ctx->dd_filter); a.span_h = ctx->dd_span[0];
+    a.taps_v = taps_from(ctx->inc_filter); a.span_v = ctx->inc_span[0];
+    PSX_HIP(psx_launch_level0(a, ctx->stream));
+
+    for (int o = 0; o < P.num_octaves; o++)
+        for (int level = 1; level < P.L; level++) {
+            int rc = launch_blur_level(ctx, o, level);
+            if (rc != PSX_OK) return rc;
+        }
+    if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    return PSX_OK;
+}
+
+int psx_find_extrema(psx_ctx* ctx)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_find_extrema: no pyramid");
+    PSX_HIP(hipSetDevice(ctx->device));
+    for (int o = 0; o < ctx->hp.num_octaves; o++)
+        PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+    if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    return PSX_OK;
+}
+
+int psx_orientation(psx_ctx* ctx)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_orientation: no pyramid");
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(psx_launch_orientation(ctx->d_params, ctx->d_cnt, ctx->stream));
+    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, ctx->stream));
+    if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    return PSX_OK;
+}
+
+int psx_descriptors(psx_ctx* ctx)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_descriptors: no pyramid");
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->stream));
+    if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    return PSX_OK;
+}
+
+int psx_extract(psx_ctx* ctx)
+{
+    int rc;
+    if ((rc = psx_build_pyramid(ctx)) != PSX_OK) return rc;
+    if ((rc = psx_find_extrema(ctx)) != PSX_OK) return rc;
+    if ((rc = psx_orientation(ctx)) != PSX_OK) return rc;
+    return psx_descriptors(ctx);
+}
+
+int psx_sync(psx_ctx* ctx)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    return PSX_OK;
+}
+
+static int fetch_counts(psx_ctx* ctx)
+{
+    if (ctx->counts_valid) return PSX_OK;
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->counts_valid = true;
+    return PSX_OK;
+}
+
+int psx_counts(psx_ctx* ctx, int* num_features, int* num_descriptors)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    int rc = fetch_counts(ctx);
+    if (rc != PSX_OK) return rc;
+    if (num_features) *num_features = ctx->h_cnt->ext_total;
+    if (num_descriptors) *num_descriptors = ctx->h_cnt->ori_total;
+    return PSX_OK;
+}
+
+int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity, float* descriptors,
+                 int descriptor_capacity)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    int rc = fetch_counts(ctx);
+    if (rc != PSX_OK) return rc;
+    const int ne = ctx->h_cnt->ext_total, no = ctx->h_cnt->ori_total;
+    if (ne > feature_capacity || no > descriptor_capacity)
+        return fail(ctx, PSX_ERR_INVALID, "psx_download: output capacity too small");
+    if (ne > 0 && !features) return fail(ctx, PSX_ERR_INVALID, "psx_download: null feature buffer");
+    if (no > 0 && !descriptors) return fail(ctx, PSX_ERR_INVALID, "psx_download: null descriptor buffer");
+    if (ne > 0)
+        PSX_HIP(hipMemcpyAsync(features, ctx->d_features, (size_t)ne * sizeof(psx_feature),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    if (no > 0)
+        PSX_HIP(hipMemcpyAsync(descriptors, ctx->d_desc, (size_t)no * 128 * sizeof(float),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    return PSX_OK;
+}
+
+int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float** d_descriptors,
+                       const int** d_feat_to_ext)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    if (d_features) *d_features = ctx->d_features;
+    if (d_descriptors) *d_descriptors = ctx->d_desc;
+    if (d_feat_to_ext) *d_feat_to_ext = ctx->d_feat_to_ext;
+    return PSX_OK;
+}
+
+int psx_dump_plane(psx_ctx* ctx, int kind, int octave, int level, float* host_out)
+{
+    if (!ctx || !host_out) return PSX_ERR_INVALID;
+    const PsxParams& P = ctx->hp;
+    if (!ctx->d_pyr || octave < 0 || octave >= P.num_octaves) return fail(ctx, PSX_ERR_INVALID, "bad octave");
+    const int nl = (kind == PSX_PLANE_DOG) ? P.L - 1 : P.L;
+    if (level < 0 || level >= nl) return fail(ctx, PSX_ERR_INVALID, "bad level");
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    const PsxOctave& oc = P.oct[octave];
+    const float* src = oc.data + (size_t)level * oc.plane;
+    if (kind == PSX_PLANE_GAUSS) {
+        PSX_HIP(hipMemcpy2D(host_out, (size_t)oc.w * 4, src, (size_t)oc.pitch * 4, (size_t)oc.w * 4, oc.h,
+                            hipMemcpyDeviceToHost));
+    } else {
+        // make_dog (s_pyramid_build.cu:74-92) into a scratch plane
+        float* tmp = nullptr;
+        PSX_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), oc.plane * sizeof(float)));
+        hipError_t e = psx_launch_dog(src, src + oc.plane, tmp, oc.w, oc.h, oc.pitch, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpy2D(host_out, (size_t)oc.w * 4, tmp, (size_t)oc.pitch * 4, (size_t)oc.w * 4, oc.h,
+                            hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        PSX_HIP(e);
+    }
+    return PSX_OK;
+}
+
+int psx_dump_iext(psx_ctx* ctx, int octave, psx_iext* host_out, int capacity, int* count)
+{
+    if (!ctx || octave < 0 || octave >= ctx->hp.num_octaves) return PSX_ERR_INVALID;
+    int rc = fetch_counts(ctx);
+    if (rc != PSX_OK) return rc;
+    int n = imin(ctx->h_cnt->ext_ct[octave], ctx->cfg.max_extrema);
+    if (count) *count = n;
+    if (host_out) {
+        n = imin(n, capacity);
+        if (n > 0) PSX_HIP(hipMemcpy(host_out, ctx->hp.iext[octave], (size_t)n * sizeof(psx_iext), hipMemcpyDeviceToHost));
+    }
+    return PSX_OK;
+}
+
+int psx_dump_extrema(psx_ctx* ctx, psx_extremum* host_out, int capacity, int* count)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    int rc = fetch_counts(ctx);
+    if (rc != PSX_OK) return rc;
+    int n = ctx->h_cnt->ext_total;
+    if (count) *count = n;
+    if (host_out) {
+        n = imin(n, capacity);
+        if (n > 0) PSX_HIP(hipMemcpy(host_out, ctx->d_extrema, (size_t)n * sizeof(psx_extremum), hipMemcpyDeviceToHost));
+    }
+    return PSX_OK;
+}
+
+int psx_enable_timers(psx_ctx* ctx, int on)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    ctx->timers = on != 0;
+    return PSX_OK;
+}
+
+int psx_stage_times(psx_ctx* ctx, float ms[4])
+{
+    if (!ctx || !ms) return PSX_ERR_INVALID;
+    if (!ctx->timers) return fail(ctx, PSX_ERR_STATE, "timers are not enabled");
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; i++) PSX_HIP(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    return PSX_OK;
+}
+
+int psx_time_blur(psx_ctx* ctx, int octave, int level, int reps, float* avg_ms, double* bytes)
+{
+    if (!ctx || !avg_ms) return PSX_ERR_INVALID;
+    const PsxParams& P = ctx->hp;
+    if (!ctx->d_pyr || octave < 0 || octave >= P.num_octaves || level < 1 || level >= P.L || reps < 1)
+        return fail(ctx, PSX_ERR_INVALID, "psx_time_blur: bad arguments");
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipEventRecord(ctx->ev_t0, ctx->stream));
+    for (int r = 0; r < reps; r++) {
+        int rc = launch_blur_level(ctx, octave, level);
+        if (rc != PSX_OK) return rc;
+    }
+    PSX_HIP(hipEventRecord(ctx->ev_t1, ctx->stream));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.0f;
+    PSX_HIP(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+    *avg_ms = ms / reps;
+    if (bytes) *bytes = 8.0 * (double)P.oct[octave].w * (double)P.oct[octave].h;
+    return PSX_OK;
+}
+
+void* psx_stream(psx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+} // extern "C"

@@ -1,0 +1,326 @@
+// extrema.hip -- 3x3x3 DoG extrema scan with sub-pixel refinement for gfx950.
+//
+// Replaces (behaviour) find_extrema_in_dog<HEIGHT,mode> and its helpers
+// (s_extrema.cu:22-558, s_solve.h:25-86) plus make_dog (s_pyramid_build.cu:74-92):
+// the DoG planes are never written to HBM.  A 256-thread workgroup stages a 64x16 tile (+1 px
+// halo) of all L-1 DoG levels in LDS, computed as G[l+1]-G[l] while loading the L Gaussian
+// planes once (24 B/pixel for L=6).  Candidates that pass the contrast pre-test and the strict
+// 26-neighbour test are queued in LDS; the refinement (<= 5 Newton steps, closed-form 3x3
+// solve) then runs one candidate per lane, reading DoG values on the fly from the Gaussian
+// planes (a single subtraction, bit-identical to a materialised DoG).  Survivors are compacted
+// with a 64-bit wave ballot and one atomicAdd per wave (wave64 re-design of extrema_count,
+// s_extrema.cu:22-44).
+#include "psx_internal.h"
+
+namespace {
+
+constexpr int ETW = 64, ETH = 16;          // tile
+constexpr int TWP = ETW + 2, THP = ETH + 2;
+constexpr int NT = 256;
+
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+    const int q = n >> 3, r = n & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// DoG "texture" read: clamp in x,y (sift_octave.cu:233-236), layer index clamped
+__device__ __forceinline__ float rdog(const PsxOctave& oc, int NL, int x, int y, int z)
+{
+    x = psx_clampi(x, 0, oc.w - 1);
+    y = psx_clampi(y, 0, oc.h - 1);
+    z = psx_clampi(z, 0, NL - 1);
+    const float* p = oc.data + (size_t)z * oc.plane + (size_t)y * oc.pitch + x;
+    return p[oc.plane] - p[0];
+}
+
+// s_solve.h:25-86 (closed-form inverse); compiled without contraction
+__device__ __forceinline__ bool solve3(float i[3][3], float b[3])
+{
+    float det0b = -i[1][2] * i[1][2];
+    float det0a =  i[1][1] * i[2][2];
+    float det0  = det0b + det0a;
+    float det1b = -i[0][1] * i[2][2];
+    float det1a =  i[1][2] * i[0][2];
+    float det1  = det1b + det1a;
+    float det2b = -i[1][1] * i[0][2];
+    float det2a =  i[0][1] * i[1][2];
+    float det2  = det2b + det2a;
+    float det3b = -i[0][2] * i[0][2];
+    float det3a =  i[0][0] * i[2][2];
+    float det3  = det3b + det3a;
+    float det4b = -i[0][0] * i[1][2];
+    float det4a =  i[0][1] * i[0][2];
+    float det4  = det4b + det4a;
+    float det5b = -i[0][1] * i[0][1];
+    float det5a =  i[0][0] * i[1][1];
+    float det5  = det5b + det5a;
+
+    float det;
+    det  = (i[0][0] * det0);
+    det += (i[0][1] * det1);
+    det += (i[0][2] * det2);
+    if (det == 0) return false;
+    const float rsd = 1.0f / det;
+
+    const float m00 = det0 * rsd, m10 = det1 * rsd, m20 = det2 * rsd;
+    const float m11 = det3 * rsd, m12 = det4 * rsd, m22 = det5 * rsd;
+    const float m01 = m10, m02 = m20, m21 = m12;
+
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+    v0 += (m00 * b[0]); v0 += (m01 * b[1]); v0 += (m02 * b[2]);
+    v1 += (m10 * b[0]); v1 += (m11 * b[1]); v1 += (m12 * b[2]);
+    v2 += (m20 * b[0]); v2 += (m21 * b[1]); v2 += (m22 * b[2]);
+    b[0] = v0; b[1] = v1; b[2] = v2;
+    return true;
+}
+
+// ModeFunctions<mode>::refine, s_extrema.cu:155-284
+template <int MODE>
+__device__ __forceinline__ int refine_step(const float d[3], int n[3], int width, int height, int maxlevel, bool last_it)
+{
+    if (MODE == PSX_MODE_OPENCV) {
+        const float tx = fabsf(d[0]), ty = fabsf(d[1]), tz = fabsf(d[2]);
+        if (tx < 0.5f && ty < 0.5f && tz < 0.5f) return 1;
+        n[0] += (int)roundf(d[0]);
+        n[1] += (int)roundf(d[1]);
+        n[2] += (int)roundf(d[2]);
+        return (n[0] < 5 || n[0] >= width - 5 || n[1] < 5 || n[1] >= height - 5 ||
+                n[2] < 1 || n[2] > maxlevel - 2) ? -1 : 0;
+    }
+    if (last_it) return 0;
+    const int tx = ((d[0] >= 0.6f && n[0] < width - 2) ? 1 : 0) + ((d[0] <= -0.6f && n[0] > 1) ? -1 : 0);
+    const int ty = ((d[1] >= 0.6f && n[1] < height - 2) ? 1 : 0) + ((d[1] <= -0.6f && n[1] > 1) ? -1 : 0);
+    int tz = 0;
+    if (MODE == PSX_MODE_POPSIFT)
+        tz = ((d[2] >= 0.6f && n[2] < maxlevel - 1) ? 1 : 0) + ((d[2] <= -0.6f && n[2] > 1) ? -1 : 0);
+    if (tx == 0 && ty == 0 && tz == 0) return 1;
+    n[0] += tx; n[1] += ty; n[2] += tz;
+    return 0;
+}
+
+// find_extrema_in_dog_sub after the extremum test, s_extrema.cu:341-503
+template <int MODE>
+__device__ bool refine(const PsxParams* P, const PsxOctave& oc, int octave, int x, int y, int level,
+                       float val, psx_iext& ec)
+{
+    const int width = oc.w, height = oc.h;
+    const int NL = P->L - 1;
+    const int maxlevel = P->L - 1;
+    const float thr = P->threshold;
+
+    float D[3], DD[3], DX[3], d[3] = {0.0f, 0.0f, 0.0f};
+    const float v = val;
+    int n[3] = {x, y, level};
+    int iter = 0;
+    constexpr int MAX_ITERATIONS = 5;
+    do {
+        iter++;
+        const float x2y1z1 = rdog(oc, NL, n[0] + 1, n[1], n[2]);
+        const float x0y1z1 = rdog(oc, NL, n[0] - 1, n[1], n[2]);
+        const float x1y2z1 = rdog(oc, NL, n[0], n[1] + 1, n[2]);
+        const float x1y0z1 = rdog(oc, NL, n[0], n[1] - 1, n[2]);
+        const float x1y1z2 = rdog(oc, NL, n[0], n[1], n[2] + 1);
+        const float x1y1z0 = rdog(oc, NL, n[0], n[1], n[2] - 1);
+        D[0] = 0.5f * (x2y1z1 - x0y1z1);
+        D[1] = 0.5f * (x1y2z1 - x1y0z1);
+        D[2] = 0.5f * (x1y1z2 - x1y1z0);
+
+        const float x1y1z1 = rdog(oc, NL, n[0], n[1], n[2]);
+        DD[0] = x2y1z1 + x0y1z1 - 2.0f * x1y1z1;
+        DD[1] = x1y2z1 + x1y0z1 - 2.0f * x1y1z1;
+        DD[2] = x1y1z2 + x1y1z0 - 2.0f * x1y1z1;
+
+        const float x0y0z1 = rdog(oc, NL, n[0] - 1, n[1] - 1, n[2]);
+        const float x0y1z0 = rdog(oc, NL, n[0] - 1, n[1], n[2] - 1);
+        const float x0y1z2 = rdog(oc, NL, n[0] - 1, n[1], n[2] + 1);
+        const float x0y2z1 = rdog(oc, NL, n[0] - 1, n[1] + 1, n[2]);
+        const float x1y0z0 = rdog(oc, NL, n[0], n[1] - 1, n[2] - 1);
+        const float x1y0z2 = rdog(oc, NL, n[0], n[1] - 1, n[2] + 1);
+        const float x1y2z0 = rdog(oc, NL, n[0], n[1] + 1, n[2] - 1);
+        const float x1y2z2 = rdog(oc, NL, n[0], n[1] + 1, n[2] + 1);
+        const float x2y0z1 = rdog(oc, NL, n[0] + 1, n[1] - 1, n[2]);
+        const float x2y1z0 = rdog(oc, NL, n[0] + 1, n[1], n[2] - 1);
+        const float x2y1z2 = rdog(oc, NL, n[0] + 1, n[1], n[2] + 1);
+        const float x2y2z1 = rdog(oc, NL, n[0] + 1, n[1] + 1, n[2]);
+        DX[0] = 0.25f * (x2y2z1 + x0y0z1 - x0y2z1 - x2y0z1);
+        DX[1] = 0.25f * (x2y1z2 + x0y1z0 - x0y1z2 - x2y1z0);
+        DX[2] = 0.25f * (x1y2z2 + x1y0z0 - x1y2z0 - x1y0z2);
+
+        float b[3];
+        float A[3][3];
+        A[0][0] = DD[0];
+        A[1][1] = DD[1];
+        A[2][2] = DD[2];
+        A[1][0] = A[0][1] = DX[0];
+        A[2][0] = A[0][2] = DX[1];
+        A[2][1] = A[1][2] = DX[2];
+        b[0] = -D[0]; b[1] = -D[1]; b[2] = -D[2];
+
+        if (!solve3(A, b)) { d[0] = d[1] = d[2] = 0.0f; break; }
+        d[0] = b[0]; d[1] = b[1]; d[2] = b[2];
+
+        const int retval = refine_step<MODE>(d, n, width, height, maxlevel, iter == MAX_ITERATIONS);
+        if (retval == -1) return false;
+        else if (retval == 1) break;
+    } while (iter < MAX_ITERATIONS);
+
+    if (MODE == PSX_MODE_OPENCV && iter >= MAX_ITERATIONS) return false;
+    if (MODE == PSX_MODE_POPSIFT || MODE == PSX_MODE_VLFEAT)
+        if (d[0] >= 1.5f || d[1] >= 1.5f || d[2] >= 1.5f) return false;
+
+    const float xn = n[0] + d[0];
+    const float yn = n[1] + d[1];
+    const float sn = n[2] + d[2];
+
+    if (MODE != PSX_MODE_OPENCV) {
+        if (xn < 0.0f || xn > width - 1.0f || yn < 0.0f || yn > height - 1.0f ||
+            sn < 0.0f || sn > maxlevel) return false;
+    }
+
+    const float contr   = v + 0.5f * (D[0] * d[0] + D[1] * d[1] + D[2] * d[2]);
+    const float tr      = DD[0] + DD[1];
+    const float det     = DD[0] * DD[1] - DX[0] * DX[0];
+    const float edgeval = tr * tr / det;
+
+    if (det <= 0.0f) return false;
+    if (fabsf(contr) < 2.0f * thr) return false;
+    if (edgeval >= (P->edge_limit + 1.0f) * (P->edge_limit + 1.0f) / P->edge_limit) return false;
+
+    ec.xpos  = xn;
+    ec.ypos  = yn;
+    ec.lpos  = (int)roundf(sn);
+    ec.sigma = P->sigma0 * powf(P->sigma_k, sn);
+    ec.cell  = (int)(floorf(yn / P->h_grid_div[octave]) * P->grid_size + floorf(xn / P->w_grid_div[octave]));
+    ec.ignore = 0;
+    return true;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P, PsxCounters* cnt, int octave,
+                                                int tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const PsxOctave oc = P->oct[octave];
+    const int L = P->L, NL = L - 1, NZ = L - 3;
+    float* sD = smem;                                    // [NL][THP][TWP]
+    int*   sQ = reinterpret_cast<int*>(smem + NL * THP * TWP);   // [NZ*ETH*ETW]
+    __shared__ int sCount;
+
+    const int t = threadIdx.x;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx0 = (lid % tiles_x) * ETW;
+    const int ty0 = (lid / tiles_x) * ETH;
+    if (t == 0) sCount = 0;
+
+    // ---- stage DoG tile ----
+    for (int e = t; e < THP * TWP; e += NT) {
+        const int ry = e / TWP, rx = e - ry * TWP;
+        const int gx = psx_clampi(tx0 - 1 + rx, 0, oc.w - 1);
+        const int gy = psx_clampi(ty0 - 1 + ry, 0, oc.h - 1);
+        const float* p = oc.data + (size_t)gy * oc.pitch + gx;
+        float prev = p[0];
+        for (int l = 0; l < NL; l++) {
+            const float cur = p[(size_t)(l + 1) * oc.plane];
+            sD[(l * THP + ry) * TWP + rx] = cur - prev;
+            prev = cur;
+        }
+    }
+    __syncthreads();
+
+    // ---- scan: contrast pre-test + strict 26-neighbour extremum (s_extrema.cu:56-120, 341-349) ----
+    const float thr = P->threshold;
+    const float thr1 = (MODE == PSX_MODE_OPENCV) ? floorf(thr)
+                     : (MODE == PSX_MODE_VLFEAT) ? 0.8f * 2.0f * thr : 1.6f * thr;
+    const int lx = t & (ETW - 1);
+    const int x = tx0 + lx;
+    for (int z = 1; z <= NZ; z++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int ly = (t >> 6) * 4 + r;
+            const int y = ty0 + ly;
+            bool valid = (x >= 1 && y >= 1 && x <= oc.w - 2 && y <= oc.h - 2);
+            if (MODE == PSX_MODE_OPENCV) valid = valid && (x >= 5 && y >= 5 && x < oc.w - 5 && y < oc.h - 5);
+            const float* c = &sD[(z * THP + ly + 1) * TWP + lx + 1];
+            const float v = c[0];
+            if (valid && fabsf(v) >= thr1) {
+                bool gt = true, lt = true;
+#pragma unroll
+                for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+                    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (dx == 0 && dy == 0 && dz == 0) continue;
+                            const float f = c[(dz * THP + dy) * TWP + dx];
+                            gt = gt && (v > f);
+                            lt = lt && (v < f);
+                        }
+                if (gt || lt) {
+                    const int slot = atomicAdd(&sCount, 1);
+                    sQ[slot] = (z << 16) | (ly << 8) | lx;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- refine queued candidates, one per lane; wave64 ballot compaction ----
+    const int nq = sCount;
+    const int lane = t & (PSX_WAVE - 1);
+    psx_iext* out = P->iext[octave];
+    int* out_off = P->iext_off[octave];
+    for (int base = 0; base < nq; base += NT) {
+        const int q = base + t;
+        bool ok = false;
+        psx_iext ec;
+        if (q < nq) {
+            const int code = sQ[q];
+            const int z = code >> 16, ly = (code >> 8) & 0xff, cx = code & 0xff;
+            const float v = sD[(z * THP + ly + 1) * TWP + cx + 1];
+            ok = refine<MODE>(P, oc, octave, tx0 + cx, ty0 + ly, z, v, ec);
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (mask != 0ull) {
+            const int n = __popcll(mask);
+            const int leader = __ffsll((long long)mask) - 1;
+            int wbase = 0;
+            if (lane == leader) wbase = atomicAdd(&cnt->ext_ct[octave], n);
+            wbase = __shfl(wbase, leader);
+            if (ok) {
+                const int idx = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+                if (idx < P->max_extrema) {
+                    out[idx] = ec;
+                    out_off[idx] = idx;
+                }
+            }
+        }
+    }
+}
+
+} // namespace
+
+hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& hp, PsxCounters* d_cnt,
+                              int octave, hipStream_t s)
+{
+    const PsxOctave& oc = hp.oct[octave];
+    const int tiles_x = (oc.w + ETW - 1) / ETW;
+    const int tiles_y = (oc.h + ETH - 1) / ETH;
+    const int NL = hp.L - 1, NZ = hp.L - 3;
+    if (NZ < 1) return hipSuccess;
+    const size_t smem = sizeof(float) * (size_t)NL * THP * TWP + sizeof(int) * (size_t)NZ * ETH * ETW;
+    const dim3 grid(tiles_x * tiles_y), block(NT);
+    switch (hp.sift_mode) {
+    case PSX_MODE_VLFEAT:
+        hipLaunchKernelGGL(k_extrema<PSX_MODE_VLFEAT>, grid, block, smem, s, d_params, d_cnt, octave, tiles_x);
+        break;
+    case PSX_MODE_OPENCV:
+        hipLaunchKernelGGL(k_extrema<PSX_MODE_OPENCV>, grid, block, smem, s, d_params, d_cnt, octave, tiles_x);
+        break;
+    default:
+        hipLaunchKernelGGL(k_extrema<PSX_MODE_POPSIFT>, grid, block, smem, s, d_params, d_cnt, octave, tiles_x);
+        break;
+    }
+    return hipGetLastError();
+}

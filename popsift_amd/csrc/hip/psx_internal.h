@@ -1,0 +1,90 @@
+// psx_internal.h -- device-side data layout shared by the HIP translation units.
+//
+// Design: no textures, no surfaces, no global __device__/__constant__ symbols.
+// Every Pyramid is a heap context; kernels receive a pointer to its PsxParams block (read
+// through scalar loads) and to its PsxCounters block.  Gaussian planes are plain pitched
+// float32 rows in HBM; texture clamp addressing is done by clamping integer coordinates.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "popsift_hip.h"
+
+#define PSX_WAVE 64
+
+struct PsxOctave {
+    float*   data;     // L planes, plane l at data + l*plane
+    int      w, h;
+    int      pitch;    // floats per row (multiple of 64)
+    int      pad;
+    size_t   plane;    // floats per plane = pitch*h
+};
+
+// Parameter block, uploaded whenever config or dimensions change (replaces d_consts,
+// sift_constants.h:58-69, and the per-octave texture objects, sift_octave.h:25-173).
+struct PsxParams {
+    int   num_octaves;
+    int   L;               // Gaussian levels per octave = levels+3
+    int   levels;
+    int   sift_mode;
+    int   norm_mode;
+    int   norm_multi;
+    int   max_extrema;     // per octave
+    int   ext_capacity;    // entries in extrema / features arrays
+    int   ori_capacity;    // entries in desc / feat_to_ext arrays
+    int   grid_size;
+    int   up_fac;          // int(upscale_factor), sift_pyramid.cu:250
+    float sigma0;
+    float sigma_k;         // 2^(1/levels), sift_constants.cu:27
+    float threshold;       // Config::getPeakThreshold()
+    float edge_limit;
+    float pad0;
+    PsxOctave oct[PSX_MAX_OCTAVES];
+    float w_grid_div[PSX_MAX_OCTAVES];   // sift_octave.cu:40-41
+    float h_grid_div[PSX_MAX_OCTAVES];
+    psx_iext* iext[PSX_MAX_OCTAVES];     // max_extrema entries each (dobuf.i_ext_dat)
+    int*      iext_off[PSX_MAX_OCTAVES]; // dobuf.i_ext_off
+    psx_extremum* extrema;               // dobuf.extrema
+    psx_feature*  features;              // dobuf.features
+    float*        desc;                  // dbuf.desc, 128 floats each
+    int*          feat_to_ext;           // dobuf.feat_to_ext_map
+};
+
+// ExtremaCounters (sift_pyramid.h:21-33), kept in device memory of the context.
+struct PsxCounters {
+    int ext_ct[PSX_MAX_OCTAVES];   // raw atomic counters (may exceed max_extrema)
+    int ext_ps[PSX_MAX_OCTAVES + 1];
+    int ori_ct[PSX_MAX_OCTAVES];
+    int ori_ps[PSX_MAX_OCTAVES + 1];
+    int ext_total;
+    int ori_total;
+    int pad[2];
+};
+
+struct PsxTaps { float g[PSX_GAUSS_ALIGN]; };
+
+// ---- host-side launch helpers implemented in the .hip files ---------------------------------
+struct PsxLevel0Args {
+    const void* img; int w, h, is_float;
+    float* dst; int W, H, pitch;
+    float shift;
+    PsxTaps taps_h; int span_h;   // dd table, octave 0
+    PsxTaps taps_v; int span_v;   // inc table, level 0
+};
+
+hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s);
+hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch,
+                           const PsxTaps& taps, int span,
+                           float* half_dst, int half_pitch, hipStream_t s);
+hipError_t psx_launch_downscale(const float* src, int sw, int sh, int spitch,
+                                float* dst, int W, int H, int pitch, hipStream_t s);
+hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s);
+hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt,
+                              int octave, hipStream_t s);
+hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
+hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
+hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, hipStream_t s);
+
+// ---- small device helpers --------------------------------------------------------------------
+__device__ __forceinline__ int psx_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -1,0 +1,393 @@
+// pyramid.hip -- Gaussian scale-space construction for gfx950 (MI355X).
+//
+// Replaces (behaviour, not code) the reference's default build_pyramid branch
+// (s_pyramid_build.cu:547-575):
+//   normalizedSource::horiz + absoluteSource::vert (level 0 of octave 0)   -> k_level0
+//   absoluteSource::horiz + absoluteSource::vert   (levels 1..L-1)         -> k_blur
+//   get_by_2_pick_every_second                                             -> fused into k_blur
+//                                                                             (k_downscale standalone)
+//   make_dog                                                               -> not materialised;
+//       the extrema kernel forms G[l+1]-G[l] on the fly (bit-identical single subtraction).
+//
+// Kernel shape (DESIGN.md "separable Gaussian"): one 256-thread workgroup owns a 64-column
+// strip and marches down a chunk of rows in steps of 32 rows.  Per step: 32 input rows (+halo
+// columns) are staged in LDS with row-coalesced float4 loads (the loads for step k+1 are issued
+// before the arithmetic of step k), the horizontal filter writes into an LDS ring of 64
+// H-filtered rows, the vertical filter reads 8+2R ring values per thread to produce 8 output
+// rows of one column.  Each plane is read once and written once (8 B/pixel algorithmic traffic);
+// the intermediate plane of the reference ("intm", 16 B/pixel more) never exists.
+//
+// Arithmetic order is the reference's, written with explicit fmaf (the file is compiled with
+// -ffp-contract=off), so planes are bit-identical to oracle/sift_oracle.c:
+//   H (s_pyramid_build_aa.cu:17-50): centre, then pairs (x-k)+(x+k) from k=span-1 down to 1
+//   V (s_pyramid_build_aa.cu:52-86): k=span-1..1: acc+=T[y-k]*g; acc+=T[y+k]*g; then centre
+//   level 0 H (s_pyramid_build_ra.cu:17-55): pairs outermost-in, then centre, then *255
+#include "psx_internal.h"
+
+namespace {
+
+constexpr int TW = 64;    // strip width (columns per workgroup)
+constexpr int BR = 32;    // rows per marching step
+constexpr int NT = 256;   // threads per workgroup
+
+// Blocks with equal (blockIdx % 8) run on the same XCD and share its L2 (MI355X_MICROARCH.md,
+// "Workgroup dispatch"); give them contiguous logical ids so that neighbouring strips, which
+// share halo columns, hit the same L2.  Bijective for any grid size.  Speed only.
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+    const int q = n >> 3, r = n & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+struct BlurArgs {
+    const float* src;
+    float*       dst;
+    float*       half_dst;      // next octave level 0 (pick every second), or nullptr
+    int W, H, pitch, half_pitch;
+    int nstrips, chunk_rows;
+    PsxTaps taps;
+};
+
+template <int R>
+struct Geom {
+    static constexpr int HALO = (R + 3) & ~3;
+    static constexpr int SW   = TW + 2 * HALO;     // staged row width (floats)
+    static constexpr int SW4  = SW / 4;
+    static constexpr int NLD  = (BR * SW4 + NT - 1) / NT;
+    static constexpr int RING = (BR + 2 * R <= 64) ? 64 : 128;
+};
+
+// horizontal filter of 8 adjacent outputs from a register window; win[HALO+i] is the centre
+// of output i.
+template <int R, int HALO, bool LEVEL0>
+__device__ __forceinline__ void hfilter8(const float* win, const PsxTaps& tp, float* out)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = HALO + i;
+        float o = 0.0f;
+        if (!LEVEL0) o = fmaf(win[c], tp.g[0], o);
+#pragma unroll
+        for (int k = R; k >= 1; k--) o = fmaf(win[c - k] + win[c + k], tp.g[k], o);
+        if (LEVEL0) { o = fmaf(win[c], tp.g[0], o); o = o * 255.0f; }
+        out[i] = o;
+    }
+}
+
+// vertical filter: v[j] = T[r_out0 - R + j]; output i is centred on v[R + i]
+template <int R>
+__device__ __forceinline__ float vfilter(const float* v, int i, const PsxTaps& tp)
+{
+    float o = 0.0f;
+#pragma unroll
+    for (int k = R; k >= 1; k--) {
+        o = fmaf(v[R + i - k], tp.g[k], o);
+        o = fmaf(v[R + i + k], tp.g[k], o);
+    }
+    o = fmaf(v[R + i], tp.g[0], o);
+    return o;
+}
+
+template <int R>
+__global__ __launch_bounds__(NT) void k_blur(BlurArgs a)
+{
+    using G = Geom<R>;
+    constexpr int HALO = G::HALO, SW = G::SW, SW4 = G::SW4, NLD = G::NLD, RING = G::RING;
+    __shared__ __attribute__((aligned(16))) float s_stage[BR * SW];
+    __shared__ __attribute__((aligned(16))) float s_ring[RING * TW];
+
+    const int t     = threadIdx.x;
+    const int lid   = xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = lid % a.nstrips;
+    const int chunk = lid / a.nstrips;
+    const int x0    = strip * TW;
+    const int Y0    = chunk * a.chunk_rows;
+    const int Y1    = min(Y0 + a.chunk_rows, a.H);
+    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
+
+    float4 pre[NLD];
+
+    auto issue = [&](int k) {
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int idx = t + j * NT;
+            if (idx < BR * SW4) {
+                const int row = idx / SW4, c4 = idx - row * SW4;
+                const int y = psx_clampi(Y0 - R + k * BR + row, 0, a.H - 1);
+                const int x = x0 - HALO + c4 * 4;
+                const float* rp = a.src + (size_t)y * a.pitch;
+                if (x >= 0 && x + 3 < a.W) {
+                    pre[j] = *reinterpret_cast<const float4*>(rp + x);
+                } else {
+                    pre[j].x = rp[psx_clampi(x + 0, 0, a.W - 1)];
+                    pre[j].y = rp[psx_clampi(x + 1, 0, a.W - 1)];
+                    pre[j].z = rp[psx_clampi(x + 2, 0, a.W - 1)];
+                    pre[j].w = rp[psx_clampi(x + 3, 0, a.W - 1)];
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int idx = t + j * NT;
+            if (idx < BR * SW4) *reinterpret_cast<float4*>(&s_stage[idx * 4]) = pre[j];
+        }
+    };
+
+    issue(0);
+    for (int k = 0; k < nsteps; k++) {
+        commit();
+        __syncthreads();
+        if (k + 1 < nsteps) issue(k + 1);
+
+        // ---- horizontal: thread = (row, 8-column segment) ----
+        {
+            const int row = t >> 3, seg = t & 7;
+            float win[8 + 2 * HALO];
+            const float4* sp = reinterpret_cast<const float4*>(&s_stage[row * SW + seg * 8]);
+#pragma unroll
+            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
+                const float4 v = sp[q];
+                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+            }
+            float out[8];
+            hfilter8<R, HALO, false>(win, a.taps, out);
+            const int slot = (k * BR + row) & (RING - 1);
+            float4* rp = reinterpret_cast<float4*>(&s_ring[slot * TW + seg * 8]);
+            rp[0] = make_float4(out[0], out[1], out[2], out[3]);
+            rp[1] = make_float4(out[4], out[5], out[6], out[7]);
+        }
+        __syncthreads();
+
+        // ---- vertical: thread = (column, group of 8 output rows) ----
+        {
+            const int col = t & (TW - 1), rg = t >> 6;
+            const int rel0 = k * BR - 2 * R + rg * 8;     // ring-relative index of T[r_out0 - R]
+            const int r_out0 = Y0 + rel0;
+            if (r_out0 + 7 >= Y0 && r_out0 < Y1) {        // wave-uniform
+                float v[8 + 2 * R];
+#pragma unroll
+                for (int j = 0; j < 8 + 2 * R; j++) v[j] = s_ring[((rel0 + j) & (RING - 1)) * TW + col];
+                const int x = x0 + col;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int r_out = r_out0 + i;
+                    const float o = vfilter<R>(v, i, a.taps);
+                    if (r_out >= Y0 && r_out < Y1 && x < a.W) {
+                        a.dst[(size_t)r_out * a.pitch + x] = o;
+                        if (a.half_dst != nullptr && ((r_out | x) & 1) == 0)
+                            a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (x >> 1)] = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Octave 0, level 0: resample the input image (software model of the reference's normalised,
+// clamped, bilinear texture, s_image.cu:138-167) + horizontal "dd" filter + x255 + vertical "inc"
+// filter.  U(X, y) = tex2D at the coordinate of output column X; tap k of output x reads U(x-k),
+// U(x+k)  (DESIGN.md "octave 0").
+// ---------------------------------------------------------------------------------------------
+struct Level0Dev {
+    const void* img; int w, h, is_float;
+    float* dst; int W, H, pitch;
+    float shift;
+    int nstrips, chunk_rows;
+    PsxTaps taps_h, taps_v;
+};
+
+__device__ __forceinline__ float l0_texel(const Level0Dev& a, int i, int j)
+{
+    i = psx_clampi(i, 0, a.w - 1);
+    j = psx_clampi(j, 0, a.h - 1);
+    if (a.is_float) return static_cast<const float*>(a.img)[(size_t)j * a.w + i];
+    return (float)static_cast<const uint8_t*>(a.img)[(size_t)j * a.w + i] / 255.0f;
+}
+__device__ __forceinline__ void l0_axis(float cn, int size, int& i0, float& al)
+{
+    const float tcoord = cn * (float)size;
+    const float tb = tcoord - 0.5f;
+    const float fl = floorf(tb);
+    float f = tb - fl;
+    f = rintf(f * 256.0f) * (1.0f / 256.0f);     // 1.8 fixed-point filter weight
+    i0 = (int)fl;
+    al = f;
+}
+__device__ __forceinline__ float l0_lerp(float p, float q, float a) { return fmaf(a, q, (1.0f - a) * p); }
+
+template <int R>
+__global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
+{
+    using G = Geom<R>;
+    constexpr int HALO = G::HALO, SW = G::SW, RING = G::RING;
+    __shared__ __attribute__((aligned(16))) float s_stage[BR * SW];
+    __shared__ __attribute__((aligned(16))) float s_ring[RING * TW];
+
+    const int t     = threadIdx.x;
+    const int lid   = xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = lid % a.nstrips;
+    const int chunk = lid / a.nstrips;
+    const int x0    = strip * TW;
+    const int Y0    = chunk * a.chunk_rows;
+    const int Y1    = min(Y0 + a.chunk_rows, a.H);
+    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
+
+    for (int k = 0; k < nsteps; k++) {
+        __syncthreads();   // previous H pass finished reading s_stage
+        for (int idx = t; idx < BR * SW; idx += NT) {
+            const int row = idx / SW, c = idx - row * SW;
+            const int y = psx_clampi(Y0 - R + k * BR + row, 0, a.H - 1);
+            const int X = x0 - HALO + c;
+            int i0, j0; float al, be;
+            l0_axis(((float)X + a.shift) / (float)a.W, a.w, i0, al);
+            l0_axis(((float)y + a.shift) / (float)a.H, a.h, j0, be);
+            const float r0 = l0_lerp(l0_texel(a, i0, j0),     l0_texel(a, i0 + 1, j0),     al);
+            const float r1 = l0_lerp(l0_texel(a, i0, j0 + 1), l0_texel(a, i0 + 1, j0 + 1), al);
+            s_stage[idx] = l0_lerp(r0, r1, be);
+        }
+        __syncthreads();
+        {
+            const int row = t >> 3, seg = t & 7;
+            float win[8 + 2 * HALO];
+            const float4* sp = reinterpret_cast<const float4*>(&s_stage[row * SW + seg * 8]);
+#pragma unroll
+            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
+                const float4 v = sp[q];
+                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+            }
+            float out[8];
+            hfilter8<R, HALO, true>(win, a.taps_h, out);
+            const int slot = (k * BR + row) & (RING - 1);
+            float4* rp = reinterpret_cast<float4*>(&s_ring[slot * TW + seg * 8]);
+            rp[0] = make_float4(out[0], out[1], out[2], out[3]);
+            rp[1] = make_float4(out[4], out[5], out[6], out[7]);
+        }
+        __syncthreads();
+        {
+            const int col = t & (TW - 1), rg = t >> 6;
+            const int rel0 = k * BR - 2 * R + rg * 8;
+            const int r_out0 = Y0 + rel0;
+            if (r_out0 + 7 >= Y0 && r_out0 < Y1) {
+                float v[8 + 2 * R];
+#pragma unroll
+                for (int j = 0; j < 8 + 2 * R; j++) v[j] = s_ring[((rel0 + j) & (RING - 1)) * TW + col];
+                const int x = x0 + col;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int r_out = r_out0 + i;
+                    const float o = vfilter<R>(v, i, a.taps_v);
+                    if (r_out >= Y0 && r_out < Y1 && x < a.W) a.dst[(size_t)r_out * a.pitch + x] = o;
+                }
+            }
+        }
+    }
+}
+
+// get_by_2_pick_every_second (s_pyramid_build.cu:50-71), used only when the fused path is off
+__global__ void k_downscale(const float* src, int sw, int sh, int spitch, float* dst, int W, int H, int pitch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const int rx = min(x << 1, sw - 1);
+    const int ry = min(y << 1, sh - 1);
+    dst[(size_t)y * pitch + x] = src[(size_t)ry * spitch + rx];
+}
+
+// make_dog (s_pyramid_build.cu:74-92) for one level pair; debug/dump use only
+__global__ void k_dog(const float* a, const float* b, float* d, int W, int H, int pitch)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * pitch + x;
+    d[i] = b[i] - a[i];
+}
+
+inline void chunking(int H, int R, int& chunk_rows, int& nchunks)
+{
+    // S marching steps per chunk: the 2R warm-up rows are ~2R/(S*BR) of the horizontal work
+    const int S = 5;
+    int cr = S * BR - 2 * R;
+    if (cr < BR) cr = BR;
+    if (cr > H) cr = H;
+    chunk_rows = cr;
+    nchunks = (H + cr - 1) / cr;
+}
+
+template <int R>
+hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, const PsxTaps& taps,
+                         float* half_dst, int half_pitch, hipStream_t s)
+{
+    BlurArgs a;
+    a.src = src; a.dst = dst; a.half_dst = half_dst;
+    a.W = W; a.H = H; a.pitch = pitch; a.half_pitch = half_pitch;
+    a.nstrips = (W + TW - 1) / TW;
+    int nchunks;
+    chunking(H, R, a.chunk_rows, nchunks);
+    a.taps = taps;
+    hipLaunchKernelGGL(k_blur<R>, dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int R>
+hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
+{
+    Level0Dev a;
+    a.img = h.img; a.w = h.w; a.h = h.h; a.is_float = h.is_float;
+    a.dst = h.dst; a.W = h.W; a.H = h.H; a.pitch = h.pitch;
+    a.shift = h.shift;
+    a.nstrips = (h.W + TW - 1) / TW;
+    int nchunks;
+    chunking(h.H, R, a.chunk_rows, nchunks);
+    a.taps_h = h.taps_h; a.taps_v = h.taps_v;
+    hipLaunchKernelGGL(k_level0<R>, dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+// span = one-sided tap count including the centre (GaussTable::span); radius R = span-1.
+// Kernels are instantiated for a set of radii; a smaller radius runs on the next larger
+// instantiation with zero weights, which is bit-exact (fma(x, 0, acc) == acc).
+hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch, const PsxTaps& taps,
+                           int span, float* half_dst, int half_pitch, hipStream_t s)
+{
+    const int R = span - 1;
+    if (R <= 5)  return launch_blur_r<5>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    if (R <= 7)  return launch_blur_r<7>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    if (R <= 8)  return launch_blur_r<8>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    if (R <= 10) return launch_blur_r<10>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    if (R <= 13) return launch_blur_r<13>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    if (R <= 16) return launch_blur_r<16>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    if (R <= 22) return launch_blur_r<22>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    if (R <= 30) return launch_blur_r<30>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s)
+{
+    const int R = (a.span_h > a.span_v ? a.span_h : a.span_v) - 1;
+    if (R <= 5)  return launch_level0_r<5>(a, s);
+    if (R <= 8)  return launch_level0_r<8>(a, s);
+    if (R <= 16) return launch_level0_r<16>(a, s);
+    if (R <= 30) return launch_level0_r<30>(a, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t psx_launch_downscale(const float* src, int sw, int sh, int spitch,
+                                float* dst, int W, int H, int pitch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_downscale, dim3((W + 255) / 256, H), dim3(256), 0, s, src, sw, sh, spitch, dst, W, H, pitch);
+    return hipGetLastError();
+}
+
+hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dog, dim3((W + 255) / 256, H), dim3(256), 0, s, a, b, d, W, H, pitch);
+    return hipGetLastError();
+}

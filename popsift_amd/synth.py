@@ -1,0 +1,75 @@
+"""Deterministic synthetic grayscale frames for tests and bench.
+
+synth(w, h, seed): band-limited u8 image = a 1/f-like stack of hash-noise layers at 1/2 .. 1/32
+resolution (bilinearly upsampled) plus K = w*h/4096 Gaussian blobs of random centre / sigma /
+amplitude; about 6 keypoints per 1000 input pixels with the default Config.
+All randomness comes from a counter-based 32-bit integer hash, so the image is a pure
+function of (w, h, seed) on every platform and numpy version.
+"""
+import numpy as np
+
+
+def _hash32(x):
+    """lowbias32-style integer finaliser on uint32 arrays."""
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x.astype(np.uint32)
+
+
+def _rand01(seed, stream, n):
+    idx = np.arange(n, dtype=np.uint64)
+    key = (np.uint64(seed) * np.uint64(0x9E3779B1) + np.uint64(stream) * np.uint64(0x85EBCA77)) & np.uint64(0xFFFFFFFF)
+    v = _hash32((idx * np.uint64(0xC2B2AE3D) + key) & np.uint64(0xFFFFFFFF))
+    return v.astype(np.float64) / 4294967296.0
+
+
+def _upsampled_noise(seed, stream, w, h, div):
+    """Hash noise at 1/div resolution, bilinearly upsampled to (h, w); values 0..255."""
+    cw, ch = (w + div - 1) // div + 2, (h + div - 1) // div + 2
+    coarse = (_rand01(seed, stream, cw * ch) * 255.0).reshape(ch, cw)
+    ys = (np.arange(h) + 0.5) / div + 0.5
+    xs = (np.arange(w) + 0.5) / div + 0.5
+    y0 = np.floor(ys).astype(int)
+    x0 = np.floor(xs).astype(int)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    y1 = np.minimum(y0 + 1, ch - 1)
+    x1 = np.minimum(x0 + 1, cw - 1)
+    return ((1 - fy) * ((1 - fx) * coarse[np.ix_(y0, x0)] + fx * coarse[np.ix_(y0, x1)])
+            + fy * ((1 - fx) * coarse[np.ix_(y1, x0)] + fx * coarse[np.ix_(y1, x1)]))
+
+
+# (divisor, amplitude, hash stream): a roughly 1/f stack so that keypoints appear in every octave
+_NOISE_STACK = ((2, 0.10, 10), (4, 0.20, 1), (8, 0.30, 7), (16, 0.30, 8), (32, 0.30, 9))
+
+
+def synth(w, h, seed=1000):
+    """Return an (h, w) uint8 frame."""
+    img = np.full((h, w), 128.0)
+    for div, amp, stream in _NOISE_STACK:
+        img += amp * (_upsampled_noise(seed, stream, w, h, div) - 128.0)
+
+    k = max(1, (w * h) // 4096)
+    cx = _rand01(seed, 2, k) * w
+    cy = _rand01(seed, 3, k) * h
+    sg = 1.5 + _rand01(seed, 4, k) * 10.5
+    am = (32.0 + _rand01(seed, 5, k) * 64.0) * np.where(_rand01(seed, 6, k) < 0.5, -1.0, 1.0)
+    for i in range(k):
+        r = int(np.ceil(4.0 * sg[i]))
+        xa, xb = max(0, int(cx[i]) - r), min(w, int(cx[i]) + r + 1)
+        ya, yb = max(0, int(cy[i]) - r), min(h, int(cy[i]) + r + 1)
+        if xa >= xb or ya >= yb:
+            continue
+        gx = np.exp(-0.5 * ((np.arange(xa, xb) - cx[i]) / sg[i]) ** 2)
+        gy = np.exp(-0.5 * ((np.arange(ya, yb) - cy[i]) / sg[i]) ** 2)
+        img[ya:yb, xa:xb] += am[i] * gy[:, None] * gx[None, :]
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synth_float(w, h, seed=1000):
+    """Float-image variant, value range [0,1) as PopSift::FloatImages expects (popsift.h:68-73)."""
+    return (synth(w, h, seed).astype(np.float32) / np.float32(256.0)).astype(np.float32)

@@ -1,0 +1,199 @@
+"""GPU parity tests: HIP path (through the C-ABI) vs the CPU oracle on identical seeded inputs.
+
+Bars: Gaussian planes and initial extrema bit-exact (both sides perform the same IEEE
+binary32 operations in the same order); orientation / descriptor within the north_star
+tolerances (coords, sigma 1e-3; descriptor L2 distance 1e-3) as set-match fractions.
+"""
+import numpy as np
+import pytest
+
+from popsift_amd.synth import synth, synth_float
+from tests.parity import match_features, sort_iext
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (w, h, seed, config overrides)
+    (640, 480, 1000, dict(octaves=5, sift_mode=2)),      # BASELINE config 1: VLFeat mode
+    (333, 251, 7, dict(octaves=4)),                       # ragged sizes, PopSift mode
+    (640, 480, 1001, dict(octaves=5, sift_mode=1, gauss_mode=3)),   # OpenCV mode + OpenCV spans
+    (257, 190, 3, dict(octaves=3, upscale_factor=0.0)),   # no upsampling
+]
+
+
+def _cfgs(oracle, capi, kw):
+    return oracle.default_config(**kw), capi.default_config(**kw)
+
+
+@pytest.mark.parametrize("w,h,seed,kw", CASES)
+def test_pyramid_bit_exact(oracle, capi, w, h, seed, kw):
+    img = synth(w, h, seed)
+    ocfg, gcfg = _cfgs(oracle, capi, kw)
+    ref = oracle.run_pyramid(ocfg, img)
+    ctx = capi.Context(gcfg)
+    ctx.upload(img)
+    ctx.build_pyramid()
+    ctx.sync()
+    assert ctx.num_octaves == ref.num_octaves
+    assert ctx.num_levels == ref.num_levels
+    for o in range(ref.num_octaves):
+        assert ctx.octave_dims(o) == ref.dims[o]
+        for l in range(ref.num_levels):
+            g = ctx.dump_plane(capi.PLANE_GAUSS, o, l)
+            r = ref.gauss(o, l)
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), \
+                "octave %d level %d: max abs err %g" % (o, l, np.abs(g - r).max())
+        for l in range(ref.num_levels - 1):
+            assert np.array_equal(ctx.dump_plane(capi.PLANE_DOG, o, l), ref.dog(o, l))
+    ctx.close()
+
+
+def test_pyramid_float_input(oracle, capi):
+    img = synth_float(320, 200, 11)
+    ocfg, gcfg = _cfgs(oracle, capi, dict(octaves=3))
+    ref = oracle.run_pyramid(ocfg, img)
+    ctx = capi.Context(gcfg)
+    ctx.upload(img)
+    ctx.build_pyramid()
+    for o in range(ref.num_octaves):
+        for l in range(ref.num_levels):
+            assert np.array_equal(ctx.dump_plane(capi.PLANE_GAUSS, o, l), ref.gauss(o, l))
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,seed,kw", CASES)
+def test_extrema_sets(oracle, capi, w, h, seed, kw):
+    img = synth(w, h, seed)
+    ocfg, gcfg = _cfgs(oracle, capi, kw)
+    ref = oracle.run(ocfg, img)
+    ctx = capi.Context(gcfg)
+    ctx.upload(img)
+    ctx.extract()
+    total = 0
+    for o in range(ref.num_octaves):
+        a = sort_iext(ref.iext(o))
+        b = sort_iext(ctx.dump_iext(o))
+        assert len(a) == len(b), "octave %d: %d vs %d initial extrema" % (o, len(a), len(b))
+        total += len(a)
+        # position, level and grid cell come from identical arithmetic: bit-exact
+        for f in ("xpos", "ypos", "lpos", "cell"):
+            assert np.array_equal(a[f], b[f]), "octave %d field %s differs" % (o, f)
+        # sigma goes through powf (libm vs ocml): relative 1e-6
+        assert np.allclose(a["sigma"], b["sigma"], rtol=2e-6, atol=0)
+    assert total > 50
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,seed,kw", CASES + [(640, 480, 5, dict(octaves=5, norm_mode=1, norm_multi=9))])
+def test_features_and_descriptors(oracle, capi, w, h, seed, kw):
+    img = synth(w, h, seed)
+    ocfg, gcfg = _cfgs(oracle, capi, kw)
+    ref = oracle.run(ocfg, img)
+    ctx = capi.Context(gcfg)
+    ctx.upload(img)
+    ctx.extract()
+    fb, db = ctx.download()
+    fa, da = ref.features(), ref.descriptors()
+    assert len(fa) == len(fb)
+    scale = float(2 ** kw.get("norm_multi", 0))
+    m = match_features(fa, da, fb, db, norm_scale=scale)
+    print(m)
+    assert m["kp_match"] >= 0.999
+    assert m["ori_match"] >= 0.995
+    assert m["desc_match"] >= 0.995
+    # and the other way round
+    m2 = match_features(fb, db, fa, da, norm_scale=scale)
+    assert m2["kp_match"] >= 0.999 and m2["ori_match"] >= 0.995 and m2["desc_match"] >= 0.995
+    # descriptor -> keypoint mapping is consistent (Feature.desc[i], sift_pyramid.cu:270-279)
+    assert abs(len(da) - len(db)) <= max(2, len(da) // 200)
+    ctx.close()
+
+
+def test_full_size_properties(capi):
+    """BASELINE config 2 size (1920x1080): size-independent properties of the HIP path."""
+    img = synth(1920, 1080, 1000)
+    ctx = capi.Context(capi.default_config(octaves=5))
+    ctx.upload(img)
+    ctx.extract()
+    f1, d1 = ctx.download()
+    assert ctx.octave_dims(0) == (3840, 2160)
+    assert len(f1) > 2000
+    # RootSift descriptors have unit L2 norm and are non-negative
+    nrm = np.sqrt((d1.astype(np.float64) ** 2).sum(1))
+    assert np.all(np.abs(nrm - 1.0) < 1e-4)
+    assert d1.min() >= 0.0
+    # coordinates inside the image, sigma above the base scale
+    assert f1["xpos"].min() >= 0 and f1["xpos"].max() <= 1920
+    assert f1["ypos"].min() >= 0 and f1["ypos"].max() <= 1080
+    assert f1["sigma"].min() > 0.5
+    assert f1["num_ori"].min() >= 1 and f1["num_ori"].max() <= 4
+    assert int(f1["num_ori"].sum()) == len(d1)
+    # every descriptor index is referenced exactly once
+    idx = np.concatenate([f["desc_idx"][: f["num_ori"]] for f in f1])
+    assert np.array_equal(np.sort(idx), np.arange(len(d1)))
+    # idempotence: a second extraction of the same frame gives the same feature *set*
+    ctx.extract()
+    f2, d2 = ctx.download()
+    assert len(f1) == len(f2) and len(d1) == len(d2)
+    k1 = np.sort(f1[["debug_octave", "xpos", "ypos"]], order=["debug_octave", "ypos", "xpos"])
+    k2 = np.sort(f2[["debug_octave", "xpos", "ypos"]], order=["debug_octave", "ypos", "xpos"])
+    assert np.array_equal(k1, k2)
+    # Gaussian semigroup: level l is the level l-1 blurred, so the plane variance decreases
+    v = [ctx.dump_plane(capi.PLANE_GAUSS, 0, l).var() for l in range(ctx.num_levels)]
+    assert all(v[i + 1] < v[i] for i in range(len(v) - 1))
+    # decimation: octave 1 level 0 == octave 0 level L-3 picked every second pixel
+    g03 = ctx.dump_plane(capi.PLANE_GAUSS, 0, ctx.num_levels - 3)
+    g10 = ctx.dump_plane(capi.PLANE_GAUSS, 1, 0)
+    assert np.array_equal(g10, g03[::2, ::2])
+    ctx.close()
+
+
+def test_empty_and_tiny_inputs(oracle, capi):
+    # constant image: no extrema, valid empty result ("Warning: no descriptors extracted")
+    img = np.full((64, 96), 77, np.uint8)
+    ctx = capi.Context(capi.default_config(octaves=2))
+    ctx.upload(img)
+    ctx.extract()
+    f, d = ctx.download()
+    assert len(f) == 0 and d.shape == (0, 128)
+    # tiny image, more octaves than it can carry
+    img = synth(20, 17, 3)
+    ocfg, gcfg = _cfgs(oracle, capi, dict(octaves=4))
+    ref = oracle.run(ocfg, img)
+    ctx2 = capi.Context(gcfg)
+    ctx2.upload(img)
+    ctx2.extract()
+    f, d = ctx2.download()
+    assert len(f) == ref.ext_total
+    for o in range(ref.num_octaves):
+        for l in range(ref.num_levels):
+            assert np.array_equal(ctx2.dump_plane(capi.PLANE_GAUSS, o, l), ref.gauss(o, l))
+    ctx.close()
+    ctx2.close()
+
+
+def test_context_reuse_and_resize(oracle, capi):
+    """One context, frames of different sizes (Pyramid::resetDimensions, sift_pyramid.cu:165-177)."""
+    ocfg, gcfg = _cfgs(oracle, capi, dict(octaves=3))
+    ctx = capi.Context(gcfg)
+    for (w, h, seed) in [(200, 150, 1), (320, 240, 2), (200, 150, 1)]:
+        img = synth(w, h, seed)
+        ref = oracle.run(ocfg, img)
+        ctx.upload(img)
+        ctx.extract()
+        f, d = ctx.download()
+        assert len(f) == ref.ext_total and len(d) == ref.ori_total
+    ctx.close()
+
+
+def test_two_contexts_same_device(oracle, capi):
+    """Two pyramids on one device are independent (unsafe in the reference: global symbols)."""
+    ocfg, gcfg = _cfgs(oracle, capi, dict(octaves=3))
+    a, b = capi.Context(gcfg), capi.Context(capi.default_config(octaves=3, sift_mode=2))
+    ia, ib = synth(300, 200, 21), synth(260, 180, 22)
+    a.upload(ia); b.upload(ib)
+    a.extract(); b.extract()
+    fa, _ = a.download(); fb, _ = b.download()
+    assert len(fa) == oracle.run(ocfg, ia).ext_total
+    assert len(fb) == oracle.run(oracle.default_config(octaves=3, sift_mode=2), ib).ext_total
+    a.close(); b.close()
