@@ -101,6 +101,7 @@ struct psx_ctx {
     psx_feature* d_features = nullptr; size_t features_cap = 0;
     float* d_desc = nullptr;           size_t desc_cap = 0;       // floats
     int* d_feat_to_ext = nullptr;      size_t f2e_cap = 0;
+    int* d_ext_nori = nullptr;         size_t nori_cap = 0;
 
     bool timers = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -284,7 +285,7 @@ int psx_destroy(psx_ctx* ctx)
     (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr);
     (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off);
     (void)hipFree(ctx->d_extrema); (void)hipFree(ctx->d_features);
-    (void)hipFree(ctx->d_desc); (void)hipFree(ctx->d_feat_to_ext);
+    (void)hipFree(ctx->d_desc); (void)hipFree(ctx->d_feat_to_ext); (void)hipFree(ctx->d_ext_nori);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
@@ -359,6 +360,7 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     if ((rc = grow(ctx, &ctx->d_features, &ctx->features_cap, iext_need)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_desc, &ctx->desc_cap, ori_need * 128)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_feat_to_ext, &ctx->f2e_cap, ori_need)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_ext_nori, &ctx->nori_cap, iext_need)) != PSX_OK) return rc;
     for (int o = 0; o < P.num_octaves; o++) {
         P.iext[o] = ctx->d_iext + (size_t)o * c.max_extrema;
         P.iext_off[o] = ctx->d_iext_off + (size_t)o * c.max_extrema;
@@ -369,6 +371,7 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     P.features = ctx->d_features;
     P.desc = ctx->d_desc;
     P.feat_to_ext = ctx->d_feat_to_ext;
+    P.ext_nori = ctx->d_ext_nori;
 
     PSX_HIP(hipMemcpy(ctx->d_params, &P, sizeof(P), hipMemcpyHostToDevice));
     ctx->in_w = w; ctx->in_h = h;

@@ -245,18 +245,30 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
             const float* c = &sD[(z * THP + ly + 1) * TWP + lx + 1];
             const float v = c[0];
             if (valid && fabsf(v) >= thr1) {
+                // same-level ring first: most candidates fail here (early-out groups of
+                // is_extremum, s_extrema.cu:71-118)
                 bool gt = true, lt = true;
 #pragma unroll
-                for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-                    for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (dx == 0 && dy == 0) continue;
+                        const float f = c[dy * TWP + dx];
+                        gt = gt && (v > f);
+                        lt = lt && (v < f);
+                    }
+                if (gt || lt) {
 #pragma unroll
-                        for (int dx = -1; dx <= 1; dx++) {
-                            if (dx == 0 && dy == 0 && dz == 0) continue;
-                            const float f = c[(dz * THP + dy) * TWP + dx];
-                            gt = gt && (v > f);
-                            lt = lt && (v < f);
-                        }
+                    for (int dz = -1; dz <= 1; dz += 2)
+#pragma unroll
+                        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                            for (int dx = -1; dx <= 1; dx++) {
+                                const float f = c[(dz * THP + dy) * TWP + dx];
+                                gt = gt && (v > f);
+                                lt = lt && (v < f);
+                            }
+                }
                 if (gt || lt) {
                     const int slot = atomicAdd(&sCount, 1);
                     sQ[slot] = (z << 16) | (ly << 8) | lx;

@@ -105,9 +105,12 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         const int loops = (wx > 0 && hy > 0) ? wx * hy : 0;
 
         float* myhist = hist + (lane & (HCOPIES - 1)) * ORI_NBINS;
+        const float rcp_wx = 1.0f / (float)max(wx, 1);
         for (int i = lane; i < loops; i += PSX_WAVE) {
-            const int yy = i / wx + ymin;
-            const int xx = i % wx + xmin;
+            // i / wx without integer division: (i+0.5)/wx is >= 0.5/wx away from an integer
+            const int q = (int)(((float)i + 0.5f) * rcp_wx);
+            const int yy = q + ymin;
+            const int xx = i - q * wx + xmin;
             const float* p = plane + (size_t)yy * oc.pitch + xx;
             const float gdx = p[1] - p[-1];
             const float gdy = p[oc.pitch] - p[-oc.pitch];
@@ -179,21 +182,43 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
             ex.xpos = ie.xpos; ex.ypos = ie.ypos; ex.lpos = ie.lpos; ex.sigma = ie.sigma;
             ex.octave = o; ex.num_ori = angles; ex.idx_ori = 0;
             P->extrema[e] = ex;
+            P->ext_nori[e] = angles;
         }
         wave_fence();
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Exclusive scan of num_ori over all extrema (octave-major), feat_to_ext map, counters and
-// Feature records.  One 1024-thread workgroup = 16 waves; wave-level __shfl_up scans.
+// Exclusive scan of num_ori over all extrema (octave-major) -> idx_ori, feat_to_ext map, counters.
+// One 1024-thread workgroup; every thread owns a contiguous run of K = ceil(total/1024) extrema
+// (sequential partial sum), one block-level scan of the 1024 partial sums (wave __shfl_up + 16
+// wave totals), then a second sequential pass writes the results.  Replaces the reference's
+// 32x32-thread ExclusivePrefixSum::Block (excl_blk_prefix_sum.h:34-145).
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_NT = 1024;
+
+__device__ __forceinline__ void write_feature(const PsxParams* P, int i, const psx_extremum& ex, int excl)
+{
+    // prep_features, sift_pyramid.cu:250-280 (descriptor pointers become indices, -1 == nullptr)
+    psx_feature f;
+    const float s = ldexpf(1.0f, ex.octave - P->up_fac);
+    f.debug_octave = ex.octave;
+    f.xpos = ex.xpos * s;
+    f.ypos = ex.ypos * s;
+    f.sigma = ex.sigma * s;
+    f.num_ori = ex.num_ori;
+#pragma unroll
+    for (int k = 0; k < PSX_ORI_MAX; k++) {
+        const bool on = k < ex.num_ori;
+        f.orientation[k] = on ? ex.orientation[k] : 0.0f;
+        f.desc_idx[k] = (on && excl + k < P->ori_capacity) ? excl + k : -1;
+    }
+    P->features[i] = f;
+}
 
 __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ P, PsxCounters* cnt)
 {
     __shared__ int s_wsum[SCAN_NT / PSX_WAVE];
-    __shared__ int s_carry;
     __shared__ int s_total;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
@@ -205,63 +230,52 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
         }
         cnt->ext_ps[PSX_MAX_OCTAVES] = ps;
         s_total = min(ps, P->ext_capacity);
-        s_carry = 0;
     }
     __syncthreads();
     const int total = s_total;
     const int cap = P->ori_capacity;
-    const int up_fac = P->up_fac;
+    const int K = (total + SCAN_NT - 1) / SCAN_NT;
+    const int i0 = min(t * K, total), i1 = min(i0 + K, total);
+    const int* nori = P->ext_nori;
 
-    for (int base = 0; base < total; base += SCAN_NT) {
-        const int i = base + t;
-        psx_extremum ex;
-        int n = 0;
-        if (i < total) { ex = P->extrema[i]; n = ex.num_ori; }
-        int v = n;
+    int local = 0;
+    for (int i = i0; i < i1; i++) local += nori[i];
+
+    int v = local;
 #pragma unroll
-        for (int off = 1; off < PSX_WAVE; off <<= 1) {
-            const int u = __shfl_up(v, off);
-            if (lane >= off) v += u;
-        }
-        if (lane == PSX_WAVE - 1) s_wsum[wave] = v;
-        __syncthreads();
-        if (wave == 0) {
-            int ws = (lane < SCAN_NT / PSX_WAVE) ? s_wsum[lane] : 0;
-#pragma unroll
-            for (int off = 1; off < SCAN_NT / PSX_WAVE; off <<= 1) {
-                const int u = __shfl_up(ws, off);
-                if (lane >= off) ws += u;
-            }
-            if (lane < SCAN_NT / PSX_WAVE) s_wsum[lane] = ws;   // inclusive over waves
-        }
-        __syncthreads();
-        const int carry = s_carry;
-        const int excl = v - n + (wave > 0 ? s_wsum[wave - 1] : 0) + carry;
-        if (i < total) {
-            P->extrema[i].idx_ori = excl;
-            // prep_features, sift_pyramid.cu:250-280
-            psx_feature f;
-            const float s = ldexpf(1.0f, ex.octave - up_fac);
-            f.debug_octave = ex.octave;
-            f.xpos = ex.xpos * s;
-            f.ypos = ex.ypos * s;
-            f.sigma = ex.sigma * s;
-            f.num_ori = n;
-#pragma unroll
-            for (int k = 0; k < PSX_ORI_MAX; k++) {
-                const bool on = k < n;
-                f.orientation[k] = on ? ex.orientation[k] : 0.0f;
-                f.desc_idx[k] = (on && excl + k < cap) ? excl + k : -1;
-                if (on && excl + k < cap) P->feat_to_ext[excl + k] = i;
-            }
-            P->features[i] = f;
-        }
-        __syncthreads();
-        if (t == SCAN_NT - 1) s_carry = excl + n;
-        __syncthreads();
+    for (int off = 1; off < PSX_WAVE; off <<= 1) {
+        const int u = __shfl_up(v, off);
+        if (lane >= off) v += u;
     }
+    if (lane == PSX_WAVE - 1) s_wsum[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        int ws = (lane < SCAN_NT / PSX_WAVE) ? s_wsum[lane] : 0;
+#pragma unroll
+        for (int off = 1; off < SCAN_NT / PSX_WAVE; off <<= 1) {
+            const int u = __shfl_up(ws, off);
+            if (lane >= off) ws += u;
+        }
+        if (lane < SCAN_NT / PSX_WAVE) s_wsum[lane] = ws;   // inclusive over waves
+    }
+    __syncthreads();
+    int excl = v - local + (wave > 0 ? s_wsum[wave - 1] : 0);
+    const int grand = s_wsum[SCAN_NT / PSX_WAVE - 1];
+    for (int i = i0; i < i1; i++) {
+        const int n = nori[i];
+        P->extrema[i].idx_ori = excl;
+        for (int k = 0; k < n; k++)
+            if (excl + k < cap) P->feat_to_ext[excl + k] = i;
+        if (excl >= cap) {                 // no descriptor wave will visit this extremum
+            psx_extremum ex = P->extrema[i];
+            ex.idx_ori = excl;
+            write_feature(P, i, ex, excl);
+        }
+        excl += n;
+    }
+    __syncthreads();
     if (t == 0) {
-        const int ori_total = min(s_carry, cap);
+        const int ori_total = min(grand, cap);
         cnt->ext_total = total;
         cnt->ori_total = ori_total;
         // per-octave orientation counts (dct.ori_ct / ori_ps, s_orientation.cu:340-360)
@@ -275,13 +289,45 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Descriptor ("loop" mode) + normalisation
+// Descriptor ("loop" mode) + normalisation + Feature record
+//
+// One wave64 per descriptor.  The wave walks the bounding box of the rotated 5x5-SBP window in
+// 16x4-pixel tiles (lane = (x&15, y&3)); tiles with no pixel inside the window are skipped with
+// one ballot.  Every pixel inside is visited once: gradient magnitude / angle once, Gaussian
+// weight once, then the classic trilinear scatter into <= 2x2 spatial tiles x 2 orientation bins
+// with ds_add_f32.  This is the same sum the reference forms by scanning the window from each of
+// its 16 tile warps (s_desc_loop.cu:60-124): a pixel contributes to tile (ix,iy) with weight
+// (1-|u-ix|)(1-|v-iy|) iff |u-ix|<1 and |v-iy|<1, where (u,v) are the pixel's coordinates in
+// tile units; only rounding differs (<= 1e-6 relative per sample; the test tolerance on the
+// normalised descriptor is 1e-3).  The reference's fast intrinsics (__expf, __sincosf,
+// __fdividef) are matched with gfx950 fast paths here: v_exp_f32, v_rcp_f32, v_sqrt_f32 and a
+// degree-13 odd minimax polynomial for atan (max error 3.3e-7 rad).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mn * __frcp_rn(fmaxf(mx, 1e-30f));
+    const float s = a * a;
+    float r = 0.006811792496591806f;
+    r = fmaf(r, s, -0.0336042195558548f);
+    r = fmaf(r, s, 0.07962366938591003f);
+    r = fmaf(r, s, -0.1323334127664566f);
+    r = fmaf(r, s, 0.19807815551757812f);
+    r = fmaf(r, s, -0.3331736922264099f);
+    r = fmaf(r, s, 0.9999961256980896f);
+    r = r * a;
+    if (ay > ax) r = 1.57079632679489662f - r;
+    if (x < 0.0f) r = PI_F - r;
+    return (y < 0.0f) ? -r : r;
+}
+
 __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt)
 {
     __shared__ float s_desc[WPB][128];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* acc = s_desc[wave];
+    const int lx = lane & 15, ly = lane >> 4;
 
     const int total = cnt->ori_total;
     const int nwaves = gridDim.x * WPB;
@@ -292,6 +338,8 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
         const float ang = ex.orientation[ori_num];
         const PsxOctave oc = P->oct[ex.octave];
         const int width = oc.w, height = oc.h;
+
+        if (ori_num == 0 && lane == 0) write_feature(P, ext_idx, ex, ex.idx_ori);
 
         acc[lane] = 0.0f;
         acc[lane + 64] = 0.0f;
@@ -311,7 +359,7 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
             const float srsbp = sin_t / SBP;
             const float bsz   = fabsf(csbp) + fabsf(ssbp);
 
-            // union of the 16 tile bounding boxes: extremes are at the four corner tiles
+            // union of the 16 tile bounding boxes (s_desc_loop.cu:66-70): extremes at the corner tiles
             int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -0x7fffffff, ymax = -0x7fffffff;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -326,59 +374,57 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
             }
             xmin = max(1, xmin); ymin = max(1, ymin);
             xmax = min(width - 2, xmax); ymax = min(height - 2, ymax);
-            const int wx = xmax - xmin + 1;
-            const int hy = ymax - ymin + 1;
-            const int loops = (wx > 0 && hy > 0) ? wx * hy : 0;
 
-            for (int i = lane; i < loops; i += PSX_WAVE) {
-                const int ii = i / wx + ymin;
-                const int jj = i % wx + xmin;
-                // tile coordinates of the pixel relative to the keypoint: u = n + 1.5
-                const float dxk = jj - x, dyk = ii - y;
-                const float u = fmaf(crsbp, dxk,  srsbp * dyk) + 1.5f;
-                const float v = fmaf(crsbp, dyk, -srsbp * dxk) + 1.5f;
-                if (u <= -1.0f || u >= 4.0f || v <= -1.0f || v >= 4.0f) continue;
-                const int ix0 = (int)floorf(u), iy0 = (int)floorf(v);
+            for (int ty = ymin; ty <= ymax; ty += 4) {
+                const int ii = ty + ly;
+                const float dyk = ii - y;
+                const float ub = fmaf(srsbp, dyk, 1.5f);      // u = crsbp*dx + srsbp*dy + 1.5
+                const float vb = fmaf(crsbp, dyk, 1.5f);      // v = crsbp*dy - srsbp*dx + 1.5
+                const float* prow = plane + (size_t)ii * oc.pitch;
+                for (int tx = xmin; tx <= xmax; tx += 16) {
+                    const int jj = tx + lx;
+                    const float dxk = jj - x;
+                    const float u = fmaf(crsbp, dxk, ub);
+                    const float v = fmaf(-srsbp, dxk, vb);
+                    const bool in = (ii <= ymax) && (jj <= xmax) &&
+                                    (u > -1.0f) && (u < 4.0f) && (v > -1.0f) && (v < 4.0f);
+                    if (__ballot(in) == 0ull) continue;
+                    if (in) {
+                        const float* p = prow + jj;
+                        const float gdx = p[1] - p[-1];
+                        const float gdy = p[oc.pitch] - p[-oc.pitch];
+                        const float mod = __fsqrt_rn(fmaf(gdx, gdx, gdy * gdy));
+                        float th = fast_atan2(gdy, gdx) - ang;
+                        th += (th <  0.0f  ? PI2_F : 0.0f);
+                        th -= (th >= PI2_F ? PI2_F : 0.0f);
+                        const float tth  = th * M_4RPI_F;
+                        const float ffo  = floorf(tth);
+                        const int   fo0  = (int)ffo;
+                        const float wgt2 = tth - ffo;
+                        const float wgt1 = 1.0f - wgt2;
+                        const int   fo   = fo0 & 7;
+                        const int   fo1  = (fo0 + 1) & 7;
 
-                const float* p = plane + (size_t)ii * oc.pitch + jj;
-                const float gdx = p[1] - p[-1];
-                const float gdy = p[oc.pitch] - p[-oc.pitch];
-                const float mod = hypotf(gdx, gdy);
-                float th = atan2f(gdy, gdx);
-                th -= ang;
-                th += (th <  0.0f  ? PI2_F : 0.0f);
-                th -= (th >= PI2_F ? PI2_F : 0.0f);
-                const float tth  = th * M_4RPI_F;
-                const int   fo0  = (int)floorf(tth);
-                const float do0  = tth - fo0;
-                const float wgt1 = 1.0f - do0;
-                const float wgt2 = do0;
-                const int   fo   = fo0 & 7;
-                const int   fo1  = (fo0 + 1) & 7;
-
+                        const float un = u - 1.5f, vn = v - 1.5f;
+                        const float ww = __expf(-0.125f * fmaf(un, un, vn * vn)) * mod;
+                        const float fu = floorf(u), fv = floorf(v);
+                        const int   ix0 = (int)fu, iy0 = (int)fv;
+                        const float ax1 = u - fu, ay1 = v - fv;      // weight of tile ix0+1 / iy0+1
+                        const float ax0 = 1.0f - ax1, ay0 = 1.0f - ay1;
 #pragma unroll
-                for (int ty = 0; ty < 2; ty++) {
-                    const int iy = iy0 + ty;
-                    if (iy < 0 || iy > 3) continue;
+                        for (int dy = 0; dy < 2; dy++) {
+                            const int iy = iy0 + dy;
+                            if (iy < 0 || iy > 3) continue;
+                            const float wy = (dy ? ay1 : ay0) * ww;
 #pragma unroll
-                    for (int tx = 0; tx < 2; tx++) {
-                        const int ix = ix0 + tx;
-                        if (ix < 0 || ix > 3) continue;
-                        // the reference's per-tile arithmetic, s_desc_loop.cu:60-103
-                        const float offx = ix - 1.5f, offy = iy - 1.5f;
-                        const float ptx = fmaf(csbp, offx, fmaf(-ssbp, offy, x));
-                        const float pty = fmaf(csbp, offy, fmaf( ssbp, offx, y));
-                        const float ddx = jj - ptx, ddy = ii - pty;
-                        const float nx = fmaf(crsbp, ddx,  srsbp * ddy);
-                        const float ny = fmaf(crsbp, ddy, -srsbp * ddx);
-                        const float nnx = fabsf(nx), nny = fabsf(ny);
-                        if (nnx < 1.0f && nny < 1.0f) {
-                            const float dnx = nx + offx, dny = ny + offy;
-                            const float ww  = expf(-0.125f * (dnx * dnx + dny * dny));
-                            const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod;
-                            float* tb = acc + ((iy << 2) + ix) * 8;
-                            atomicAdd(&tb[fo],  wgt1 * wgt);
-                            atomicAdd(&tb[fo1], wgt2 * wgt);
+                            for (int dx = 0; dx < 2; dx++) {
+                                const int ix = ix0 + dx;
+                                if (ix < 0 || ix > 3) continue;
+                                const float wgt = wy * (dx ? ax1 : ax0);
+                                float* tb = acc + ((iy << 2) + ix) * 8;
+                                atomicAdd(&tb[fo],  wgt1 * wgt);
+                                atomicAdd(&tb[fo1], wgt2 * wgt);
+                            }
                         }
                     }
                 }

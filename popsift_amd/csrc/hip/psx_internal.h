@@ -49,6 +49,7 @@ struct PsxParams {
     psx_feature*  features;              // dobuf.features
     float*        desc;                  // dbuf.desc, 128 floats each
     int*          feat_to_ext;           // dobuf.feat_to_ext_map
+    int*          ext_nori;              // num_ori per extremum (SoA copy for the scan)
 };
 
 // ExtremaCounters (sift_pyramid.h:21-33), kept in device memory of the context.

@@ -226,6 +226,11 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
     constexpr int HALO = G::HALO, SW = G::SW, RING = G::RING;
     __shared__ __attribute__((aligned(16))) float s_stage[BR * SW];
     __shared__ __attribute__((aligned(16))) float s_ring[RING * TW];
+    __shared__ float s_lut[256];      // u8 texel -> v/255 (cudaReadModeNormalizedFloat)
+    __shared__ int   s_ci[SW];        // per staged column: left texel index and 1.8 weight
+    __shared__ float s_ca[SW];
+    __shared__ int   s_rj[BR];        // per staged row
+    __shared__ float s_rb[BR];
 
     const int t     = threadIdx.x;
     const int lid   = xcd_remap(blockIdx.x, gridDim.x);
@@ -236,17 +241,39 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
     const int Y1    = min(Y0 + a.chunk_rows, a.H);
     const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
 
+    s_lut[t] = (float)t / 255.0f;
+    if (t < SW) {
+        int i0; float al;
+        l0_axis(((float)(x0 - HALO + t) + a.shift) / (float)a.W, a.w, i0, al);
+        s_ci[t] = i0; s_ca[t] = al;
+    }
+
     for (int k = 0; k < nsteps; k++) {
-        __syncthreads();   // previous H pass finished reading s_stage
+        if (t < BR) {
+            const int y = psx_clampi(Y0 - R + k * BR + t, 0, a.H - 1);
+            int j0; float be;
+            l0_axis(((float)y + a.shift) / (float)a.H, a.h, j0, be);
+            s_rj[t] = j0; s_rb[t] = be;
+        }
+        __syncthreads();   // tables ready; previous H pass finished reading s_stage
         for (int idx = t; idx < BR * SW; idx += NT) {
             const int row = idx / SW, c = idx - row * SW;
-            const int y = psx_clampi(Y0 - R + k * BR + row, 0, a.H - 1);
-            const int X = x0 - HALO + c;
-            int i0, j0; float al, be;
-            l0_axis(((float)X + a.shift) / (float)a.W, a.w, i0, al);
-            l0_axis(((float)y + a.shift) / (float)a.H, a.h, j0, be);
-            const float r0 = l0_lerp(l0_texel(a, i0, j0),     l0_texel(a, i0 + 1, j0),     al);
-            const float r1 = l0_lerp(l0_texel(a, i0, j0 + 1), l0_texel(a, i0 + 1, j0 + 1), al);
+            const int i0 = s_ci[c], j0 = s_rj[row];
+            const float al = s_ca[c], be = s_rb[row];
+            const int ia = psx_clampi(i0, 0, a.w - 1), ib = psx_clampi(i0 + 1, 0, a.w - 1);
+            const int ja = psx_clampi(j0, 0, a.h - 1), jb = psx_clampi(j0 + 1, 0, a.h - 1);
+            float t00, t10, t01, t11;
+            if (a.is_float) {
+                const float* f = static_cast<const float*>(a.img);
+                t00 = f[(size_t)ja * a.w + ia]; t10 = f[(size_t)ja * a.w + ib];
+                t01 = f[(size_t)jb * a.w + ia]; t11 = f[(size_t)jb * a.w + ib];
+            } else {
+                const uint8_t* b = static_cast<const uint8_t*>(a.img);
+                t00 = s_lut[b[(size_t)ja * a.w + ia]]; t10 = s_lut[b[(size_t)ja * a.w + ib]];
+                t01 = s_lut[b[(size_t)jb * a.w + ia]]; t11 = s_lut[b[(size_t)jb * a.w + ib]];
+            }
+            const float r0 = l0_lerp(t00, t10, al);
+            const float r1 = l0_lerp(t01, t11, al);
             s_stage[idx] = l0_lerp(r0, r1, be);
         }
         __syncthreads();

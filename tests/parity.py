@@ -29,20 +29,33 @@ def match_features(fa, da, fb, db, norm_scale=1.0):
     ka = np.stack([fa["xpos"], fa["ypos"], fa["debug_octave"] * 1e4, np.log2(fa["sigma"]) * 50.0], 1)
     kb = np.stack([fb["xpos"], fb["ypos"], fb["debug_octave"] * 1e4, np.log2(fb["sigma"]) * 50.0], 1)
     tree = cKDTree(kb)
-    dist, idx = tree.query(ka, k=1)
+    kq = min(4, len(fb))
+    _, idx_all = tree.query(ka, k=kq)
+    idx_all = idx_all.reshape(len(fa), kq)
     kp_ok = np.zeros(len(fa), bool)
     ori_ok = np.zeros(len(fa), bool)
     n_desc = 0
     n_desc_ok = 0
     max_dd = 0.0
     used = set()
-    for i, j in enumerate(idx):
-        a, b = fa[i], fb[j]
+    for i in range(len(fa)):
+        a = fa[i]
         tol = TOL_POS * max(1.0, float(a["sigma"]))
-        ok = (abs(a["xpos"] - b["xpos"]) <= tol and abs(a["ypos"] - b["ypos"]) <= tol
-              and abs(a["sigma"] - b["sigma"]) <= TOL_SIGMA_REL * a["sigma"] and j not in used)
-        if not ok:
+        j = -1
+        # the reference algorithm can emit exact duplicates (two start pixels refined to the same
+        # position), so take the nearest *unused* candidate within tolerance
+        for cand in idx_all[i]:
+            cand = int(cand)
+            b = fb[cand]
+            if cand in used:
+                continue
+            if (abs(a["xpos"] - b["xpos"]) <= tol and abs(a["ypos"] - b["ypos"]) <= tol
+                    and abs(a["sigma"] - b["sigma"]) <= TOL_SIGMA_REL * a["sigma"]):
+                j = cand
+                break
+        if j < 0:
             continue
+        b = fb[j]
         used.add(j)
         kp_ok[i] = True
         na, nb = int(a["num_ori"]), int(b["num_ori"])
