@@ -360,7 +360,7 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     if ((rc = grow(ctx, &ctx->d_features, &ctx->features_cap, iext_need)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_desc, &ctx->desc_cap, ori_need * 128)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_feat_to_ext, &ctx->f2e_cap, ori_need)) != PSX_OK) return rc;
-    if ((rc = grow(ctx, &ctx->d_ext_nori, &ctx->nori_cap, iext_need)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_ext_nori, &ctx->nori_cap, iext_need + 64)) != PSX_OK) return rc;
     for (int o = 0; o < P.num_octaves; o++) {
         P.iext[o] = ctx->d_iext + (size_t)o * c.max_extrema;
         P.iext_off[o] = ctx->d_iext_off + (size_t)o * c.max_extrema;

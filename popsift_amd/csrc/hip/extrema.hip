@@ -100,11 +100,29 @@ __device__ __forceinline__ int refine_step(const float d[3], int n[3], int width
     return 0;
 }
 
+// DoG access for the refinement: the staged LDS tile when (x,y) +- 1 lies inside it (always true
+// for the first Newton step), the Gaussian planes in HBM otherwise.  Both give the same bits:
+// the tile holds G[z+1]-G[z] of the clamped coordinates.
+struct DogView {
+    const PsxOctave& oc;
+    const float* sD;     // [NL][THP][TWP]
+    int NL, tx0, ty0;
+    __device__ __forceinline__ float at(int x, int y, int z, bool in_tile) const
+    {
+        if (in_tile) {
+            z = psx_clampi(z, 0, NL - 1);
+            return sD[(z * THP + (y - ty0 + 1)) * TWP + (x - tx0 + 1)];
+        }
+        return rdog(oc, NL, x, y, z);
+    }
+};
+
 // find_extrema_in_dog_sub after the extremum test, s_extrema.cu:341-503
 template <int MODE>
-__device__ bool refine(const PsxParams* P, const PsxOctave& oc, int octave, int x, int y, int level,
+__device__ bool refine(const PsxParams* P, const DogView& dv, int octave, int x, int y, int level,
                        float val, psx_iext& ec)
 {
+    const PsxOctave& oc = dv.oc;
     const int width = oc.w, height = oc.h;
     const int NL = P->L - 1;
     const int maxlevel = P->L - 1;
@@ -117,33 +135,35 @@ __device__ bool refine(const PsxParams* P, const PsxOctave& oc, int octave, int 
     constexpr int MAX_ITERATIONS = 5;
     do {
         iter++;
-        const float x2y1z1 = rdog(oc, NL, n[0] + 1, n[1], n[2]);
-        const float x0y1z1 = rdog(oc, NL, n[0] - 1, n[1], n[2]);
-        const float x1y2z1 = rdog(oc, NL, n[0], n[1] + 1, n[2]);
-        const float x1y0z1 = rdog(oc, NL, n[0], n[1] - 1, n[2]);
-        const float x1y1z2 = rdog(oc, NL, n[0], n[1], n[2] + 1);
-        const float x1y1z0 = rdog(oc, NL, n[0], n[1], n[2] - 1);
+        // x,y +- 1 inside the haloed tile [tx0-1, tx0+ETW] x [ty0-1, ty0+ETH]
+        const bool in_tile = (n[0] >= dv.tx0 && n[0] < dv.tx0 + ETW && n[1] >= dv.ty0 && n[1] < dv.ty0 + ETH);
+        const float x2y1z1 = dv.at(n[0] + 1, n[1], n[2], in_tile);
+        const float x0y1z1 = dv.at(n[0] - 1, n[1], n[2], in_tile);
+        const float x1y2z1 = dv.at(n[0], n[1] + 1, n[2], in_tile);
+        const float x1y0z1 = dv.at(n[0], n[1] - 1, n[2], in_tile);
+        const float x1y1z2 = dv.at(n[0], n[1], n[2] + 1, in_tile);
+        const float x1y1z0 = dv.at(n[0], n[1], n[2] - 1, in_tile);
         D[0] = 0.5f * (x2y1z1 - x0y1z1);
         D[1] = 0.5f * (x1y2z1 - x1y0z1);
         D[2] = 0.5f * (x1y1z2 - x1y1z0);
 
-        const float x1y1z1 = rdog(oc, NL, n[0], n[1], n[2]);
+        const float x1y1z1 = dv.at(n[0], n[1], n[2], in_tile);
         DD[0] = x2y1z1 + x0y1z1 - 2.0f * x1y1z1;
         DD[1] = x1y2z1 + x1y0z1 - 2.0f * x1y1z1;
         DD[2] = x1y1z2 + x1y1z0 - 2.0f * x1y1z1;
 
-        const float x0y0z1 = rdog(oc, NL, n[0] - 1, n[1] - 1, n[2]);
-        const float x0y1z0 = rdog(oc, NL, n[0] - 1, n[1], n[2] - 1);
-        const float x0y1z2 = rdog(oc, NL, n[0] - 1, n[1], n[2] + 1);
-        const float x0y2z1 = rdog(oc, NL, n[0] - 1, n[1] + 1, n[2]);
-        const float x1y0z0 = rdog(oc, NL, n[0], n[1] - 1, n[2] - 1);
-        const float x1y0z2 = rdog(oc, NL, n[0], n[1] - 1, n[2] + 1);
-        const float x1y2z0 = rdog(oc, NL, n[0], n[1] + 1, n[2] - 1);
-        const float x1y2z2 = rdog(oc, NL, n[0], n[1] + 1, n[2] + 1);
-        const float x2y0z1 = rdog(oc, NL, n[0] + 1, n[1] - 1, n[2]);
-        const float x2y1z0 = rdog(oc, NL, n[0] + 1, n[1], n[2] - 1);
-        const float x2y1z2 = rdog(oc, NL, n[0] + 1, n[1], n[2] + 1);
-        const float x2y2z1 = rdog(oc, NL, n[0] + 1, n[1] + 1, n[2]);
+        const float x0y0z1 = dv.at(n[0] - 1, n[1] - 1, n[2], in_tile);
+        const float x0y1z0 = dv.at(n[0] - 1, n[1], n[2] - 1, in_tile);
+        const float x0y1z2 = dv.at(n[0] - 1, n[1], n[2] + 1, in_tile);
+        const float x0y2z1 = dv.at(n[0] - 1, n[1] + 1, n[2], in_tile);
+        const float x1y0z0 = dv.at(n[0], n[1] - 1, n[2] - 1, in_tile);
+        const float x1y0z2 = dv.at(n[0], n[1] - 1, n[2] + 1, in_tile);
+        const float x1y2z0 = dv.at(n[0], n[1] + 1, n[2] - 1, in_tile);
+        const float x1y2z2 = dv.at(n[0], n[1] + 1, n[2] + 1, in_tile);
+        const float x2y0z1 = dv.at(n[0] + 1, n[1] - 1, n[2], in_tile);
+        const float x2y1z0 = dv.at(n[0] + 1, n[1], n[2] - 1, in_tile);
+        const float x2y1z2 = dv.at(n[0] + 1, n[1], n[2] + 1, in_tile);
+        const float x2y2z1 = dv.at(n[0] + 1, n[1] + 1, n[2], in_tile);
         DX[0] = 0.25f * (x2y2z1 + x0y0z1 - x0y2z1 - x2y0z1);
         DX[1] = 0.25f * (x2y1z2 + x0y1z0 - x0y1z2 - x2y1z0);
         DX[2] = 0.25f * (x1y2z2 + x1y0z0 - x1y2z0 - x1y0z2);
@@ -214,17 +234,43 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     const int ty0 = (lid / tiles_x) * ETH;
     if (t == 0) sCount = 0;
 
-    // ---- stage DoG tile ----
-    for (int e = t; e < THP * TWP; e += NT) {
-        const int ry = e / TWP, rx = e - ry * TWP;
-        const int gx = psx_clampi(tx0 - 1 + rx, 0, oc.w - 1);
-        const int gy = psx_clampi(ty0 - 1 + ry, 0, oc.h - 1);
-        const float* p = oc.data + (size_t)gy * oc.pitch + gx;
-        float prev = p[0];
-        for (int l = 0; l < NL; l++) {
-            const float cur = p[(size_t)(l + 1) * oc.plane];
-            sD[(l * THP + ry) * TWP + rx] = cur - prev;
-            prev = cur;
+    // ---- stage DoG tile: every thread owns <= NE elements; all their loads are issued before the
+    // first use so that one HBM round trip covers the whole tile ----
+    constexpr int NE = (THP * TWP + NT - 1) / NT;
+    if (L == 6) {
+        float g[NE][6];
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int e = t + k * NT;
+            const int ec = min(e, THP * TWP - 1);
+            const int ry = ec / TWP, rx = ec - ry * TWP;
+            const int gx = psx_clampi(tx0 - 1 + rx, 0, oc.w - 1);
+            const int gy = psx_clampi(ty0 - 1 + ry, 0, oc.h - 1);
+            const float* p = oc.data + (size_t)gy * oc.pitch + gx;
+#pragma unroll
+            for (int l = 0; l < 6; l++) g[k][l] = p[(size_t)l * oc.plane];
+        }
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int e = t + k * NT;
+            if (e < THP * TWP) {
+                const int ry = e / TWP, rx = e - ry * TWP;
+#pragma unroll
+                for (int l = 0; l < 5; l++) sD[(l * THP + ry) * TWP + rx] = g[k][l + 1] - g[k][l];
+            }
+        }
+    } else {
+        for (int e = t; e < THP * TWP; e += NT) {
+            const int ry = e / TWP, rx = e - ry * TWP;
+            const int gx = psx_clampi(tx0 - 1 + rx, 0, oc.w - 1);
+            const int gy = psx_clampi(ty0 - 1 + ry, 0, oc.h - 1);
+            const float* p = oc.data + (size_t)gy * oc.pitch + gx;
+            float prev = p[0];
+            for (int l = 0; l < NL; l++) {
+                const float cur = p[(size_t)(l + 1) * oc.plane];
+                sD[(l * THP + ry) * TWP + rx] = cur - prev;
+                prev = cur;
+            }
         }
     }
     __syncthreads();
@@ -283,6 +329,7 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     const int lane = t & (PSX_WAVE - 1);
     psx_iext* out = P->iext[octave];
     int* out_off = P->iext_off[octave];
+    const DogView dv{oc, sD, NL, tx0, ty0};
     for (int base = 0; base < nq; base += NT) {
         const int q = base + t;
         bool ok = false;
@@ -291,7 +338,7 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
             const int code = sQ[q];
             const int z = code >> 16, ly = (code >> 8) & 0xff, cx = code & 0xff;
             const float v = sD[(z * THP + ly + 1) * TWP + cx + 1];
-            ok = refine<MODE>(P, oc, octave, tx0 + cx, ty0 + ly, z, v, ec);
+            ok = refine<MODE>(P, dv, octave, tx0 + cx, ty0 + ly, z, v, ec);
         }
         const unsigned long long mask = __ballot(ok);
         if (mask != 0ull) {

@@ -255,45 +255,62 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
     __syncthreads();
     const int total = s_total;
     const int cap = P->ori_capacity;
-    const int K = (total + SCAN_NT - 1) / SCAN_NT;
-    const int i0 = min(t * K, total), i1 = min(i0 + K, total);
     const int* nori = P->ext_nori;
-
-    int local = 0;
-    for (int i = i0; i < i1; i++) local += nori[i];
-
-    int v = local;
+    // every thread owns SCAN_K consecutive extrema per pass; all 4 int4 loads are in flight at once
+    constexpr int SCAN_K = 16;
+    int carry = 0;
+    for (int base = 0; base < total; base += SCAN_NT * SCAN_K) {
+        const int i0 = base + t * SCAN_K;
+        int nv[SCAN_K];
 #pragma unroll
-    for (int off = 1; off < PSX_WAVE; off <<= 1) {
-        const int u = __shfl_up(v, off);
-        if (lane >= off) v += u;
-    }
-    if (lane == PSX_WAVE - 1) s_wsum[wave] = v;
-    __syncthreads();
-    if (wave == 0) {
-        int ws = (lane < SCAN_NT / PSX_WAVE) ? s_wsum[lane] : 0;
+        for (int q = 0; q < SCAN_K / 4; q++) {
+            int4 v4 = make_int4(0, 0, 0, 0);
+            if (i0 + 4 * q < total) v4 = reinterpret_cast<const int4*>(nori + i0)[q];   // buffer padded to x16
+            nv[4 * q + 0] = v4.x; nv[4 * q + 1] = v4.y; nv[4 * q + 2] = v4.z; nv[4 * q + 3] = v4.w;
+        }
+        int local = 0;
 #pragma unroll
-        for (int off = 1; off < SCAN_NT / PSX_WAVE; off <<= 1) {
-            const int u = __shfl_up(ws, off);
-            if (lane >= off) ws += u;
+        for (int k = 0; k < SCAN_K; k++) { if (i0 + k >= total) nv[k] = 0; local += nv[k]; }
+
+        int v = local;
+#pragma unroll
+        for (int off = 1; off < PSX_WAVE; off <<= 1) {
+            const int u = __shfl_up(v, off);
+            if (lane >= off) v += u;
         }
-        if (lane < SCAN_NT / PSX_WAVE) s_wsum[lane] = ws;   // inclusive over waves
-    }
-    __syncthreads();
-    int excl = v - local + (wave > 0 ? s_wsum[wave - 1] : 0);
-    const int grand = s_wsum[SCAN_NT / PSX_WAVE - 1];
-    for (int i = i0; i < i1; i++) {
-        const int n = nori[i];
-        P->extrema[i].idx_ori = excl;
-        for (int k = 0; k < n; k++)
-            if (excl + k < cap) P->feat_to_ext[excl + k] = i;
-        if (excl >= cap) {                 // no descriptor wave will visit this extremum
-            psx_extremum ex = P->extrema[i];
-            ex.idx_ori = excl;
-            write_feature(P, i, ex, excl);
+        __syncthreads();                      // s_wsum free (previous pass finished reading)
+        if (lane == PSX_WAVE - 1) s_wsum[wave] = v;
+        __syncthreads();
+        if (wave == 0) {
+            int ws = (lane < SCAN_NT / PSX_WAVE) ? s_wsum[lane] : 0;
+#pragma unroll
+            for (int off = 1; off < SCAN_NT / PSX_WAVE; off <<= 1) {
+                const int u = __shfl_up(ws, off);
+                if (lane >= off) ws += u;
+            }
+            if (lane < SCAN_NT / PSX_WAVE) s_wsum[lane] = ws;   // inclusive over waves
         }
-        excl += n;
+        __syncthreads();
+        int excl = carry + v - local + (wave > 0 ? s_wsum[wave - 1] : 0);
+        carry += s_wsum[SCAN_NT / PSX_WAVE - 1];
+#pragma unroll
+        for (int k = 0; k < SCAN_K; k++) {
+            const int i = i0 + k;
+            if (i < total) {
+                const int n = nv[k];
+                P->extrema[i].idx_ori = excl;
+                for (int q = 0; q < n; q++)
+                    if (excl + q < cap) P->feat_to_ext[excl + q] = i;
+                if (excl >= cap) {                 // no descriptor wave will visit this extremum
+                    psx_extremum ex = P->extrema[i];
+                    ex.idx_ori = excl;
+                    write_feature(P, i, ex, excl);
+                }
+                excl += n;
+            }
+        }
     }
+    const int grand = carry;
     __syncthreads();
     if (t == 0) {
         const int ori_total = min(grand, cap);

@@ -56,7 +56,18 @@ struct Geom {
     static constexpr int SW4  = SW / 4;
     static constexpr int NLD  = (BR * SW4 + NT - 1) / NT;
     static constexpr int RING = (BR + 2 * R <= 64) ? 64 : 128;
+    // LDS row stride of the staged rows: 96 or 160 floats, i.e. == 128 B (mod 256 B).  Together
+    // with the XOR swizzle below this makes the horizontal pass's ds_read_b128 conflict-free
+    // (checked against the gfx950 b128 lane groups, MI355X_MICROARCH.md "LDS").
+    static constexpr int SWA  = ((SW + 63) / 64) * 64 + 32;
 };
+
+// Staged rows are stored in 16-byte chunks; chunk c of row r lives at chunk (c ^ (r & 1)).
+__device__ __forceinline__ int stage_chunk(int row, int c4) { return c4 ^ (row & 1); }
+
+// Ring rows (64 H-filtered values) are stored permuted so that the horizontal pass writes two
+// conflict-free 128-byte runs per row: value of column col sits at ring_pos(col).
+__device__ __forceinline__ int ring_col_of_pos(int p) { return ((p & 31) >> 2) * 8 + (p & 3) + ((p >> 5) << 2); }
 
 // horizontal filter of 8 adjacent outputs from a register window; win[HALO+i] is the centre
 // of output i.
@@ -93,8 +104,8 @@ template <int R>
 __global__ __launch_bounds__(NT) void k_blur(BlurArgs a)
 {
     using G = Geom<R>;
-    constexpr int HALO = G::HALO, SW = G::SW, SW4 = G::SW4, NLD = G::NLD, RING = G::RING;
-    __shared__ __attribute__((aligned(16))) float s_stage[BR * SW];
+    constexpr int HALO = G::HALO, SW4 = G::SW4, NLD = G::NLD, RING = G::RING, SWA = G::SWA;
+    __shared__ __attribute__((aligned(16))) float s_stage[BR * SWA];
     __shared__ __attribute__((aligned(16))) float s_ring[RING * TW];
 
     const int t     = threadIdx.x;
@@ -132,7 +143,10 @@ __global__ __launch_bounds__(NT) void k_blur(BlurArgs a)
 #pragma unroll
         for (int j = 0; j < NLD; j++) {
             const int idx = t + j * NT;
-            if (idx < BR * SW4) *reinterpret_cast<float4*>(&s_stage[idx * 4]) = pre[j];
+            if (idx < BR * SW4) {
+                const int row = idx / SW4, c4 = idx - row * SW4;
+                *reinterpret_cast<float4*>(&s_stage[row * SWA + stage_chunk(row, c4) * 4]) = pre[j];
+            }
         }
     };
 
@@ -146,30 +160,31 @@ __global__ __launch_bounds__(NT) void k_blur(BlurArgs a)
         {
             const int row = t >> 3, seg = t & 7;
             float win[8 + 2 * HALO];
-            const float4* sp = reinterpret_cast<const float4*>(&s_stage[row * SW + seg * 8]);
+            const float4* sp = reinterpret_cast<const float4*>(&s_stage[row * SWA]);
 #pragma unroll
             for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
-                const float4 v = sp[q];
+                const float4 v = sp[stage_chunk(row, seg * 2 + q)];
                 win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
             }
             float out[8];
             hfilter8<R, HALO, false>(win, a.taps, out);
             const int slot = (k * BR + row) & (RING - 1);
-            float4* rp = reinterpret_cast<float4*>(&s_ring[slot * TW + seg * 8]);
+            float4* rp = reinterpret_cast<float4*>(&s_ring[slot * TW + seg * 4]);
             rp[0] = make_float4(out[0], out[1], out[2], out[3]);
-            rp[1] = make_float4(out[4], out[5], out[6], out[7]);
+            rp[8] = make_float4(out[4], out[5], out[6], out[7]);
         }
         __syncthreads();
 
         // ---- vertical: thread = (column, group of 8 output rows) ----
         {
-            const int col = t & (TW - 1), rg = t >> 6;
+            const int pos = t & (TW - 1), rg = t >> 6;
+            const int col = ring_col_of_pos(pos);
             const int rel0 = k * BR - 2 * R + rg * 8;     // ring-relative index of T[r_out0 - R]
             const int r_out0 = Y0 + rel0;
             if (r_out0 + 7 >= Y0 && r_out0 < Y1) {        // wave-uniform
                 float v[8 + 2 * R];
 #pragma unroll
-                for (int j = 0; j < 8 + 2 * R; j++) v[j] = s_ring[((rel0 + j) & (RING - 1)) * TW + col];
+                for (int j = 0; j < 8 + 2 * R; j++) v[j] = s_ring[((rel0 + j) & (RING - 1)) * TW + pos];
                 const int x = x0 + col;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -223,14 +238,16 @@ template <int R>
 __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
 {
     using G = Geom<R>;
-    constexpr int HALO = G::HALO, SW = G::SW, RING = G::RING;
-    __shared__ __attribute__((aligned(16))) float s_stage[BR * SW];
+    constexpr int HALO = G::HALO, SW = G::SW, RING = G::RING, SWA = G::SWA;
+    __shared__ __attribute__((aligned(16))) float s_stage[BR * SWA];
     __shared__ __attribute__((aligned(16))) float s_ring[RING * TW];
     __shared__ float s_lut[256];      // u8 texel -> v/255 (cudaReadModeNormalizedFloat)
     __shared__ int   s_ci[SW];        // per staged column: left texel index and 1.8 weight
     __shared__ float s_ca[SW];
     __shared__ int   s_rj[BR];        // per staged row
     __shared__ float s_rb[BR];
+    constexpr int TEXW = 104, TEXH = 40;   // input-texel footprint of one step (upscale >= 0)
+    __shared__ float s_tex[TEXH * TEXW];
 
     const int t     = threadIdx.x;
     const int lid   = xcd_remap(blockIdx.x, gridDim.x);
@@ -256,6 +273,21 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
             s_rj[t] = j0; s_rb[t] = be;
         }
         __syncthreads();   // tables ready; previous H pass finished reading s_stage
+        // texel footprint of this step (index tables are monotone in row / column)
+        const int jlo = psx_clampi(s_rj[0], 0, a.h - 1), jhi = psx_clampi(s_rj[BR - 1] + 1, 0, a.h - 1);
+        const int ilo = psx_clampi(s_ci[0], 0, a.w - 1), ihi = psx_clampi(s_ci[SW - 1] + 1, 0, a.w - 1);
+        const int nrows = jhi - jlo + 1, ncols = ihi - ilo + 1;
+        const bool via_lds = (nrows <= TEXH && ncols <= TEXW);     // uniform over the workgroup
+        if (via_lds) {
+            // phase 1: input texels (as float, v/255 for bytes) -> LDS, each read from HBM once
+            for (int idx = t; idx < nrows * ncols; idx += NT) {
+                const int jr = idx / ncols, ic = idx - jr * ncols;
+                const size_t g = (size_t)(jlo + jr) * a.w + (ilo + ic);
+                s_tex[jr * TEXW + ic] = a.is_float ? static_cast<const float*>(a.img)[g]
+                                                   : s_lut[static_cast<const uint8_t*>(a.img)[g]];
+            }
+            __syncthreads();
+        }
         for (int idx = t; idx < BR * SW; idx += NT) {
             const int row = idx / SW, c = idx - row * SW;
             const int i0 = s_ci[c], j0 = s_rj[row];
@@ -263,7 +295,11 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
             const int ia = psx_clampi(i0, 0, a.w - 1), ib = psx_clampi(i0 + 1, 0, a.w - 1);
             const int ja = psx_clampi(j0, 0, a.h - 1), jb = psx_clampi(j0 + 1, 0, a.h - 1);
             float t00, t10, t01, t11;
-            if (a.is_float) {
+            if (via_lds) {
+                const float* ra = &s_tex[(ja - jlo) * TEXW - ilo];
+                const float* rb = &s_tex[(jb - jlo) * TEXW - ilo];
+                t00 = ra[ia]; t10 = ra[ib]; t01 = rb[ia]; t11 = rb[ib];
+            } else if (a.is_float) {
                 const float* f = static_cast<const float*>(a.img);
                 t00 = f[(size_t)ja * a.w + ia]; t10 = f[(size_t)ja * a.w + ib];
                 t01 = f[(size_t)jb * a.w + ia]; t11 = f[(size_t)jb * a.w + ib];
@@ -274,34 +310,35 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
             }
             const float r0 = l0_lerp(t00, t10, al);
             const float r1 = l0_lerp(t01, t11, al);
-            s_stage[idx] = l0_lerp(r0, r1, be);
+            s_stage[row * SWA + stage_chunk(row, c >> 2) * 4 + (c & 3)] = l0_lerp(r0, r1, be);
         }
         __syncthreads();
         {
             const int row = t >> 3, seg = t & 7;
             float win[8 + 2 * HALO];
-            const float4* sp = reinterpret_cast<const float4*>(&s_stage[row * SW + seg * 8]);
+            const float4* sp = reinterpret_cast<const float4*>(&s_stage[row * SWA]);
 #pragma unroll
             for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
-                const float4 v = sp[q];
+                const float4 v = sp[stage_chunk(row, seg * 2 + q)];
                 win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
             }
             float out[8];
             hfilter8<R, HALO, true>(win, a.taps_h, out);
             const int slot = (k * BR + row) & (RING - 1);
-            float4* rp = reinterpret_cast<float4*>(&s_ring[slot * TW + seg * 8]);
+            float4* rp = reinterpret_cast<float4*>(&s_ring[slot * TW + seg * 4]);
             rp[0] = make_float4(out[0], out[1], out[2], out[3]);
-            rp[1] = make_float4(out[4], out[5], out[6], out[7]);
+            rp[8] = make_float4(out[4], out[5], out[6], out[7]);
         }
         __syncthreads();
         {
-            const int col = t & (TW - 1), rg = t >> 6;
+            const int pos = t & (TW - 1), rg = t >> 6;
+            const int col = ring_col_of_pos(pos);
             const int rel0 = k * BR - 2 * R + rg * 8;
             const int r_out0 = Y0 + rel0;
             if (r_out0 + 7 >= Y0 && r_out0 < Y1) {
                 float v[8 + 2 * R];
 #pragma unroll
-                for (int j = 0; j < 8 + 2 * R; j++) v[j] = s_ring[((rel0 + j) & (RING - 1)) * TW + col];
+                for (int j = 0; j < 8 + 2 * R; j++) v[j] = s_ring[((rel0 + j) & (RING - 1)) * TW + pos];
                 const int x = x0 + col;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -335,12 +372,19 @@ __global__ void k_dog(const float* a, const float* b, float* d, int W, int H, in
     d[i] = b[i] - a[i];
 }
 
-inline void chunking(int H, int R, int& chunk_rows, int& nchunks)
+inline void chunking(int W, int H, int R, int& chunk_rows, int& nchunks)
 {
-    // S marching steps per chunk: the 2R warm-up rows are ~2R/(S*BR) of the horizontal work
-    const int S = 5;
+    // S marching steps per chunk: the 2R warm-up rows cost ~2R/(S*BR) extra horizontal work, but a
+    // chunk is a serial chain of S steps.  Large planes take S=5; small octaves trade efficiency
+    // for more, shorter workgroups (they are latency bound, not bandwidth bound).
+    const int nstrips = (W + TW - 1) / TW;
+    int S = 5;
+    for (; S > 2; S--) {
+        const int cr = S * BR - 2 * R;
+        if (cr >= BR && nstrips * ((H + cr - 1) / cr) >= 384) break;
+    }
     int cr = S * BR - 2 * R;
-    if (cr < BR) cr = BR;
+    if (cr < BR / 2) cr = BR / 2;
     if (cr > H) cr = H;
     chunk_rows = cr;
     nchunks = (H + cr - 1) / cr;
@@ -355,7 +399,7 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
     a.W = W; a.H = H; a.pitch = pitch; a.half_pitch = half_pitch;
     a.nstrips = (W + TW - 1) / TW;
     int nchunks;
-    chunking(H, R, a.chunk_rows, nchunks);
+    chunking(W, H, R, a.chunk_rows, nchunks);
     a.taps = taps;
     hipLaunchKernelGGL(k_blur<R>, dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
     return hipGetLastError();
@@ -370,7 +414,7 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
     a.shift = h.shift;
     a.nstrips = (h.W + TW - 1) / TW;
     int nchunks;
-    chunking(h.H, R, a.chunk_rows, nchunks);
+    chunking(h.W, h.H, R, a.chunk_rows, nchunks);
     a.taps_h = h.taps_h; a.taps_v = h.taps_v;
     hipLaunchKernelGGL(k_level0<R>, dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
     return hipGetLastError();
