@@ -181,6 +181,18 @@ int psx_counts(psx_ctx* ctx, int* num_features, int* num_descriptors);
 int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity,
                  float* descriptors, int descriptor_capacity);
 
+/* Zero-copy export.  Replaces the per-image cudaHostRegister + 2x cudaMemcpyAsync + unregister of
+ * Pyramid::get_descriptors / FeaturesHost::pin (sift_pyramid.cu:300-318, features.cu:86-111):
+ * the caller attaches two host buffers (any host memory; they are registered once with the HIP
+ * runtime, or pass memory that is already pinned) and the descriptor kernel streams every Feature
+ * record and every normalised descriptor straight into them over PCIe while it computes, the scan
+ * kernel deposits the two counters.  After psx_sync()/psx_counts() the results are in the buffers;
+ * no copy is queued and the host never waits for a transfer.  Capacities are in elements;
+ * results beyond a capacity are dropped from the export (the device copy stays complete).
+ * Pass NULL/0 to detach. */
+int psx_attach_export(psx_ctx* ctx, psx_feature* host_features, int feature_capacity,
+                      float* host_descriptors, int descriptor_capacity);
+
 /* Device-resident results (FeaturesDev, features.h:104-122): pointers valid until the next
  * extraction on this context. */
 int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float** d_descriptors,

@@ -54,7 +54,7 @@ SYMBOLS = [
     "psx_destroy", "psx_last_error", "psx_resize", "psx_num_octaves", "psx_num_levels",
     "psx_octave_dims", "psx_upload_u8", "psx_upload_f32", "psx_set_input_dev", "psx_build_pyramid",
     "psx_find_extrema", "psx_orientation", "psx_descriptors", "psx_extract", "psx_sync", "psx_counts",
-    "psx_download", "psx_device_results", "psx_dump_plane", "psx_dump_iext", "psx_dump_extrema",
+    "psx_download", "psx_attach_export", "psx_device_results", "psx_dump_plane", "psx_dump_iext", "psx_dump_extrema",
     "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
 ]
 
@@ -95,6 +95,7 @@ def lib():
             getattr(L, n).argtypes = [vp]
         L.psx_counts.argtypes = [vp, ip, ip]
         L.psx_download.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+        L.psx_attach_export.argtypes = [vp, vp, C.c_int, vp, C.c_int]
         L.psx_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         L.psx_dump_plane.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.psx_dump_iext.argtypes = [vp, C.c_int, vp, C.c_int, ip]
@@ -237,6 +238,33 @@ class Context:
         desc = np.zeros((no, 128), dtype=np.float32)
         self._chk(lib().psx_download(self._h, feats.ctypes.data_as(C.c_void_p), ne,
                                      desc.ctypes.data_as(C.c_void_p), no))
+        return feats, desc
+
+    def attach_export(self, feat_buf, desc_buf):
+        """Attach host buffers for zero-copy export.  feat_buf: uint8 buffer (numpy array or pinned
+        torch tensor) of n*52 bytes, desc_buf: float32 buffer of m*128 floats.  None detaches."""
+        if feat_buf is None:
+            self._chk(lib().psx_attach_export(self._h, None, 0, None, 0))
+            self._export = None
+            return
+
+        def ptr_n(b, itemsize):
+            if hasattr(b, "data_ptr"):
+                return b.data_ptr(), b.numel() * b.element_size() // itemsize
+            return b.ctypes.data, b.nbytes // itemsize
+        fp_, fn = ptr_n(feat_buf, FEATURE_DTYPE.itemsize)
+        dp_, dn = ptr_n(desc_buf, 128 * 4)
+        self._chk(lib().psx_attach_export(self._h, C.c_void_p(fp_), fn, C.c_void_p(dp_), dn))
+        self._export = (feat_buf, desc_buf)
+
+    def exported(self):
+        """After counts(): numpy views (no copy) of the exported features / descriptors."""
+        ne, no = self.counts()
+        fb, db = self._export
+        fa = fb.numpy() if hasattr(fb, "numpy") else fb
+        da = db.numpy() if hasattr(db, "numpy") else db
+        feats = fa.view(np.uint8).reshape(-1)[: ne * FEATURE_DTYPE.itemsize].view(FEATURE_DTYPE)
+        desc = da.view(np.float32).reshape(-1)[: no * 128].reshape(no, 128)
         return feats, desc
 
     def dump_plane(self, kind, octave, level):

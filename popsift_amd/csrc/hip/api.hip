@@ -90,6 +90,7 @@ struct psx_ctx {
     PsxCounters* d_cnt = nullptr;
     PsxCounters* h_cnt = nullptr;      // pinned
     bool counts_valid = false;
+    bool counts_partial = false;       // only ext_total / ori_total valid (export fast path)
 
     void*       d_input_own = nullptr; size_t input_cap = 0;
     const void* d_input = nullptr;     int input_is_float = 0;
@@ -102,6 +103,13 @@ struct psx_ctx {
     float* d_desc = nullptr;           size_t desc_cap = 0;       // floats
     int* d_feat_to_ext = nullptr;      size_t f2e_cap = 0;
     int* d_ext_nori = nullptr;         size_t nori_cap = 0;
+
+    // zero-copy export
+    psx_feature* x_host_feat = nullptr; float* x_host_desc = nullptr;
+    psx_feature* x_dev_feat = nullptr;  float* x_dev_desc = nullptr;
+    int x_feat_cap = 0, x_desc_cap = 0;
+    bool x_registered_feat = false, x_registered_desc = false;
+    int* h_xcnt = nullptr;             // pinned [2]
 
     bool timers = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -267,6 +275,8 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), sizeof(PsxCounters)));
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_cnt), sizeof(PsxCounters), hipHostMallocDefault));
     PSX_HIPC(hipMemset(n->d_cnt, 0, sizeof(PsxCounters)));
+    PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_xcnt), 2 * sizeof(int), hipHostMallocDefault));
+    n->h_xcnt[0] = n->h_xcnt[1] = 0;
     for (int i = 0; i < 5; i++) PSX_HIPC(hipEventCreate(&n->ev[i]));
     PSX_HIPC(hipEventCreate(&n->ev_t0));
     PSX_HIPC(hipEventCreate(&n->ev_t1));
@@ -282,6 +292,9 @@ int psx_destroy(psx_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_params); (void)hipFree(ctx->d_cnt);
     if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
+    if (ctx->x_registered_feat) (void)hipHostUnregister(ctx->x_host_feat);
+    if (ctx->x_registered_desc) (void)hipHostUnregister(ctx->x_host_desc);
+    if (ctx->h_xcnt) (void)hipHostFree(ctx->h_xcnt);
     (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr);
     (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off);
     (void)hipFree(ctx->d_extrema); (void)hipFree(ctx->d_features);
@@ -372,6 +385,11 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     P.desc = ctx->d_desc;
     P.feat_to_ext = ctx->d_feat_to_ext;
     P.ext_nori = ctx->d_ext_nori;
+    P.x_features = ctx->x_dev_feat;
+    P.x_desc = ctx->x_dev_desc;
+    P.x_counts = ctx->x_dev_feat || ctx->x_dev_desc ? ctx->h_xcnt : nullptr;
+    P.x_feat_capacity = ctx->x_feat_cap;
+    P.x_desc_capacity = ctx->x_desc_cap;
 
     PSX_HIP(hipMemcpy(ctx->d_params, &P, sizeof(P), hipMemcpyHostToDevice));
     ctx->in_w = w; ctx->in_h = h;
@@ -517,13 +535,34 @@ int psx_sync(psx_ctx* ctx)
     return PSX_OK;
 }
 
-static int fetch_counts(psx_ctx* ctx)
+static int fetch_counts_full(psx_ctx* ctx)
 {
-    if (ctx->counts_valid) return PSX_OK;
+    if (ctx->counts_valid && !ctx->counts_partial) return PSX_OK;
     PSX_HIP(hipSetDevice(ctx->device));
     PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
     PSX_HIP(hipStreamSynchronize(ctx->stream));
     ctx->counts_valid = true;
+    ctx->counts_partial = false;
+    return PSX_OK;
+}
+
+static int fetch_counts(psx_ctx* ctx)
+{
+    if (ctx->counts_valid) return PSX_OK;
+    PSX_HIP(hipSetDevice(ctx->device));
+    if (ctx->hp.x_counts != nullptr) {
+        // export attached: the scan kernel already deposited the counters in pinned memory
+        PSX_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->h_cnt->ext_total = ctx->h_xcnt[0];
+        ctx->h_cnt->ori_total = ctx->h_xcnt[1];
+        ctx->counts_valid = true;
+        ctx->counts_partial = true;
+        return PSX_OK;
+    }
+    PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->counts_valid = true;
+    ctx->counts_partial = false;
     return PSX_OK;
 }
 
@@ -548,13 +587,65 @@ int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity, floa
         return fail(ctx, PSX_ERR_INVALID, "psx_download: output capacity too small");
     if (ne > 0 && !features) return fail(ctx, PSX_ERR_INVALID, "psx_download: null feature buffer");
     if (no > 0 && !descriptors) return fail(ctx, PSX_ERR_INVALID, "psx_download: null descriptor buffer");
-    if (ne > 0)
+    const bool feat_exported = (features == ctx->x_host_feat && ne <= ctx->x_feat_cap);
+    const bool desc_exported = (descriptors == ctx->x_host_desc && no <= ctx->x_desc_cap);
+    if (ne > 0 && !feat_exported)
         PSX_HIP(hipMemcpyAsync(features, ctx->d_features, (size_t)ne * sizeof(psx_feature),
                                hipMemcpyDeviceToHost, ctx->stream));
-    if (no > 0)
+    if (no > 0 && !desc_exported)
         PSX_HIP(hipMemcpyAsync(descriptors, ctx->d_desc, (size_t)no * 128 * sizeof(float),
                                hipMemcpyDeviceToHost, ctx->stream));
     PSX_HIP(hipStreamSynchronize(ctx->stream));
+    return PSX_OK;
+}
+
+static int map_host(psx_ctx* ctx, void* host, size_t bytes, void** dev, bool* registered)
+{
+    *registered = false;
+    *dev = nullptr;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, host);
+    if (e != hipSuccess || attr.type == hipMemoryTypeUnregistered) {
+        (void)hipGetLastError();
+        PSX_HIP(hipHostRegister(host, bytes, hipHostRegisterMapped));
+        *registered = true;
+    }
+    PSX_HIP(hipHostGetDevicePointer(dev, host, 0));
+    return PSX_OK;
+}
+
+int psx_attach_export(psx_ctx* ctx, psx_feature* host_features, int feature_capacity,
+                      float* host_descriptors, int descriptor_capacity)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->x_registered_feat) { (void)hipHostUnregister(ctx->x_host_feat); ctx->x_registered_feat = false; }
+    if (ctx->x_registered_desc) { (void)hipHostUnregister(ctx->x_host_desc); ctx->x_registered_desc = false; }
+    ctx->x_host_feat = nullptr; ctx->x_host_desc = nullptr;
+    ctx->x_dev_feat = nullptr; ctx->x_dev_desc = nullptr;
+    ctx->x_feat_cap = ctx->x_desc_cap = 0;
+    if (host_features && feature_capacity > 0) {
+        void* d = nullptr;
+        int rc = map_host(ctx, host_features, (size_t)feature_capacity * sizeof(psx_feature), &d, &ctx->x_registered_feat);
+        if (rc != PSX_OK) return rc;
+        ctx->x_host_feat = host_features; ctx->x_dev_feat = static_cast<psx_feature*>(d);
+        ctx->x_feat_cap = feature_capacity;
+    }
+    if (host_descriptors && descriptor_capacity > 0) {
+        void* d = nullptr;
+        int rc = map_host(ctx, host_descriptors, (size_t)descriptor_capacity * 128 * sizeof(float), &d, &ctx->x_registered_desc);
+        if (rc != PSX_OK) return rc;
+        ctx->x_host_desc = host_descriptors; ctx->x_dev_desc = static_cast<float*>(d);
+        ctx->x_desc_cap = descriptor_capacity;
+    }
+    PsxParams& P = ctx->hp;
+    P.x_features = ctx->x_dev_feat;
+    P.x_desc = ctx->x_dev_desc;
+    P.x_counts = (ctx->x_dev_feat || ctx->x_dev_desc) ? ctx->h_xcnt : nullptr;
+    P.x_feat_capacity = ctx->x_feat_cap;
+    P.x_desc_capacity = ctx->x_desc_cap;
+    if (ctx->d_pyr) PSX_HIP(hipMemcpy(ctx->d_params, &P, sizeof(P), hipMemcpyHostToDevice));
     return PSX_OK;
 }
 
@@ -600,7 +691,8 @@ int psx_dump_plane(psx_ctx* ctx, int kind, int octave, int level, float* host_ou
 int psx_dump_iext(psx_ctx* ctx, int octave, psx_iext* host_out, int capacity, int* count)
 {
     if (!ctx || octave < 0 || octave >= ctx->hp.num_octaves) return PSX_ERR_INVALID;
-    int rc = fetch_counts(ctx);
+    if (ctx->counts_partial) { ctx->counts_valid = false; }
+    int rc = fetch_counts_full(ctx);
     if (rc != PSX_OK) return rc;
     int n = imin(ctx->h_cnt->ext_ct[octave], ctx->cfg.max_extrema);
     if (count) *count = n;
@@ -662,6 +754,14 @@ int psx_time_blur(psx_ctx* ctx, int octave, int level, int reps, float* avg_ms, 
     if (bytes) *bytes = 8.0 * (double)P.oct[octave].w * (double)P.oct[octave].h;
     return PSX_OK;
 }
+
+#ifdef PSX_PHASE_TIMING
+int psx_debug_launch_extrema(psx_ctx* ctx, int o)
+{
+    PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+    return PSX_OK;
+}
+#endif
 
 void* psx_stream(psx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 

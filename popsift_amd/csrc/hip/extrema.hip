@@ -217,10 +217,18 @@ __device__ bool refine(const PsxParams* P, const DogView& dv, int octave, int x,
     return true;
 }
 
+#ifdef PSX_PHASE_TIMING
+__device__ long long* g_dbg = nullptr;
+#define STAMP(i) if (threadIdx.x == 0 && g_dbg) g_dbg[blockIdx.x * 8 + (i)] = clock64()
+#else
+#define STAMP(i)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P, PsxCounters* cnt, int octave,
                                                 int tiles_x)
 {
+    STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PsxOctave oc = P->oct[octave];
     const int L = P->L, NL = L - 1, NZ = L - 3;
@@ -233,6 +241,7 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     const int tx0 = (lid % tiles_x) * ETW;
     const int ty0 = (lid / tiles_x) * ETH;
     if (t == 0) sCount = 0;
+    STAMP(1);
 
     // ---- stage DoG tile: every thread owns <= NE elements; all their loads are issued before the
     // first use so that one HBM round trip covers the whole tile ----
@@ -274,55 +283,66 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
         }
     }
     __syncthreads();
+    STAMP(2);
 
     // ---- scan: contrast pre-test + strict 26-neighbour extremum (s_extrema.cu:56-120, 341-349) ----
     const float thr = P->threshold;
     const float thr1 = (MODE == PSX_MODE_OPENCV) ? floorf(thr)
                      : (MODE == PSX_MODE_VLFEAT) ? 0.8f * 2.0f * thr : 1.6f * thr;
+    // Register-tiled: a thread owns 4 vertically adjacent pixels of one column.  Per DoG level it
+    // pulls the 6x3 window of each of the 3 levels (54 LDS reads in flight, one latency), reduces
+    // rows with max3/min3 and tests the 4 pixels against the max / min of their 26 neighbours
+    // (strict, same predicate as is_extremum, s_extrema.cu:56-120).  A wave skips a level when none
+    // of its 256 pixels passes the contrast pre-test.
     const int lx = t & (ETW - 1);
+    const int ly0 = (t >> 6) * 4;
     const int x = tx0 + lx;
     for (int z = 1; z <= NZ; z++) {
+        bool pre[4];
+        bool anyp = false;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int ly = (t >> 6) * 4 + r;
-            const int y = ty0 + ly;
+            const int y = ty0 + ly0 + r;
             bool valid = (x >= 1 && y >= 1 && x <= oc.w - 2 && y <= oc.h - 2);
             if (MODE == PSX_MODE_OPENCV) valid = valid && (x >= 5 && y >= 5 && x < oc.w - 5 && y < oc.h - 5);
-            const float* c = &sD[(z * THP + ly + 1) * TWP + lx + 1];
-            const float v = c[0];
-            if (valid && fabsf(v) >= thr1) {
-                // same-level ring first: most candidates fail here (early-out groups of
-                // is_extremum, s_extrema.cu:71-118)
-                bool gt = true, lt = true;
+            const float v = sD[(z * THP + ly0 + r + 1) * TWP + lx + 1];
+            pre[r] = valid && fabsf(v) >= thr1;
+            anyp = anyp || pre[r];
+        }
+        if (__ballot(anyp) == 0ull) continue;
+
+        float mx[3][6], mn[3][6], lft[4], rgt[4], ctr[4];
 #pragma unroll
-                for (int dy = -1; dy <= 1; dy++)
+        for (int dz = 0; dz < 3; dz++) {
 #pragma unroll
-                    for (int dx = -1; dx <= 1; dx++) {
-                        if (dx == 0 && dy == 0) continue;
-                        const float f = c[dy * TWP + dx];
-                        gt = gt && (v > f);
-                        lt = lt && (v < f);
-                    }
-                if (gt || lt) {
-#pragma unroll
-                    for (int dz = -1; dz <= 1; dz += 2)
-#pragma unroll
-                        for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                            for (int dx = -1; dx <= 1; dx++) {
-                                const float f = c[(dz * THP + dy) * TWP + dx];
-                                gt = gt && (v > f);
-                                lt = lt && (v < f);
-                            }
+            for (int rr = 0; rr < 6; rr++) {
+                const float* q = &sD[((z + dz - 1) * THP + ly0 + rr) * TWP + lx];
+                const float a = q[0], b = q[1], c = q[2];
+                if (dz == 1 && rr >= 1 && rr <= 4) {
+                    // own level: the centre is excluded from its own row
+                    lft[rr - 1] = a; rgt[rr - 1] = c; ctr[rr - 1] = b;
                 }
-                if (gt || lt) {
-                    const int slot = atomicAdd(&sCount, 1);
-                    sQ[slot] = (z << 16) | (ly << 8) | lx;
-                }
+                mx[dz][rr] = fmaxf(fmaxf(a, b), c);
+                mn[dz][rr] = fminf(fminf(a, b), c);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = ctr[r];
+            float M = fmaxf(fmaxf(mx[0][r], mx[0][r + 1]), mx[0][r + 2]);
+            M = fmaxf(M, fmaxf(fmaxf(mx[2][r], mx[2][r + 1]), mx[2][r + 2]));
+            M = fmaxf(M, fmaxf(fmaxf(mx[1][r], mx[1][r + 2]), fmaxf(lft[r], rgt[r])));
+            float N = fminf(fminf(mn[0][r], mn[0][r + 1]), mn[0][r + 2]);
+            N = fminf(N, fminf(fminf(mn[2][r], mn[2][r + 1]), mn[2][r + 2]));
+            N = fminf(N, fminf(fminf(mn[1][r], mn[1][r + 2]), fminf(lft[r], rgt[r])));
+            if (pre[r] && (v > M || v < N)) {
+                const int slot = atomicAdd(&sCount, 1);
+                sQ[slot] = (z << 16) | ((ly0 + r) << 8) | lx;
             }
         }
     }
     __syncthreads();
+    STAMP(3);
 
     // ---- refine queued candidates, one per lane; wave64 ballot compaction ----
     const int nq = sCount;
@@ -356,9 +376,17 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
             }
         }
     }
+    STAMP(4);
+#ifdef PSX_PHASE_TIMING
+    if (threadIdx.x == 0 && g_dbg) g_dbg[blockIdx.x * 8 + 5] = nq;
+#endif
 }
 
 } // namespace
+
+#ifdef PSX_PHASE_TIMING
+extern "C" void psx_debug_set_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &d, sizeof(d)); }
+#endif
 
 hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& hp, PsxCounters* d_cnt,
                               int octave, hipStream_t s)

@@ -235,6 +235,7 @@ __device__ __forceinline__ void write_feature(const PsxParams* P, int i, const p
         f.desc_idx[k] = (on && excl + k < P->ori_capacity) ? excl + k : -1;
     }
     P->features[i] = f;
+    if (P->x_features != nullptr && i < P->x_feat_capacity) P->x_features[i] = f;
 }
 
 __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ P, PsxCounters* cnt)
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
         const int ori_total = min(grand, cap);
         cnt->ext_total = total;
         cnt->ori_total = ori_total;
+        if (P->x_counts != nullptr) { P->x_counts[0] = total; P->x_counts[1] = ori_total; }
         // per-octave orientation counts (dct.ori_ct / ori_ps, s_orientation.cu:340-360)
         for (int o = 0; o < PSX_MAX_OCTAVES; o++) {
             const int fe = cnt->ext_ps[o];
@@ -497,6 +499,8 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
             b = b * norm;
         }
         reinterpret_cast<float2*>(P->desc + (size_t)j * 128)[lane] = make_float2(a, b);
+        if (P->x_desc != nullptr && j < P->x_desc_capacity)
+            reinterpret_cast<float2*>(P->x_desc + (size_t)j * 128)[lane] = make_float2(a, b);
         wave_fence();
     }
 }

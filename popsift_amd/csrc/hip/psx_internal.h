@@ -50,6 +50,12 @@ struct PsxParams {
     float*        desc;                  // dbuf.desc, 128 floats each
     int*          feat_to_ext;           // dobuf.feat_to_ext_map
     int*          ext_nori;              // num_ori per extremum (SoA copy for the scan)
+    // zero-copy export into mapped host memory (nullptr when detached)
+    psx_feature*  x_features;
+    float*        x_desc;
+    int*          x_counts;              // [0]=ext_total [1]=ori_total, pinned host memory
+    int           x_feat_capacity;
+    int           x_desc_capacity;
 };
 
 // ExtremaCounters (sift_pyramid.h:21-33), kept in device memory of the context.

@@ -197,3 +197,27 @@ def test_two_contexts_same_device(oracle, capi):
     assert len(fa) == oracle.run(ocfg, ia).ext_total
     assert len(fb) == oracle.run(oracle.default_config(octaves=3, sift_mode=2), ib).ext_total
     a.close(); b.close()
+
+
+def test_zero_copy_export_matches_download(capi):
+    """psx_attach_export: kernels write results straight into host memory; must equal psx_download."""
+    import numpy as np
+    img = synth(480, 360, 77)
+    ctx = capi.Context(capi.default_config(octaves=4))
+    fbuf = np.zeros(20000 * capi.FEATURE_DTYPE.itemsize, np.uint8)
+    dbuf = np.zeros(40000 * 128, np.float32)
+    ctx.attach_export(fbuf, dbuf)
+    ctx.upload(img)
+    ctx.extract()
+    fe, de = ctx.exported()
+    fd, dd = ctx.download()
+    assert len(fe) == len(fd) > 100 and len(de) == len(dd)
+    assert np.array_equal(fe, fd)
+    assert np.array_equal(de, dd)
+    # detach: later frames no longer touch the host buffers
+    ctx.attach_export(None, None)
+    fbuf[:] = 0
+    ctx.extract()
+    ctx.sync()
+    assert not fbuf.any()
+    ctx.close()

@@ -33,3 +33,13 @@ for i in range(n):
 for c in ctxs: c.sync()
 dt = (time.time() - t) / (n * len(ctxs))
 print("4-stream %.3f ms/frame -> %.1f Mpix/s" % (dt * 1e3, w * h / dt / 1e6))
+for nc in (2, 8, 16):
+    ctxs = [capi.Context(capi.default_config(octaves=5)) for _ in range(nc)]
+    for c in ctxs: c.upload(img); c.extract(); c.sync()
+    t = time.time()
+    for i in range(n):
+        for c in ctxs: c.extract()
+    for c in ctxs: c.sync()
+    dt = (time.time() - t) / (n * len(ctxs))
+    print("%d-stream %.3f ms/frame -> %.1f Mpix/s" % (nc, dt * 1e3, w * h / dt / 1e6))
+    for c in ctxs: c.close()
