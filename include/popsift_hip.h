@@ -198,6 +198,17 @@ int psx_attach_export(psx_ctx* ctx, psx_feature* host_features, int feature_capa
 int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float** d_descriptors,
                        const int** d_feat_to_ext);
 
+/* FeaturesDev support (MatchingMode, popsift.cpp:346-383, sift_pyramid.cu:324-362): device
+ * buffers owned by the caller and a device-to-device clone of the last results
+ * (features as psx_feature records, descriptors, descriptor->extremum map). */
+int psx_dev_alloc(int device, size_t bytes, void** out);
+int psx_dev_free(int device, void* ptr);
+int psx_clone_results(psx_ctx* ctx, void* d_features, void* d_descriptors, int* d_reverse_map);
+
+/* device_prop_t (common/device_prop.h:23-108): enumeration only; there are no texture limits. */
+int psx_device_count(int* count);
+int psx_device_info(int device, char* name, int name_len, size_t* total_mem, int* compute_units, int* clock_khz);
+
 /* ---- introspection for parity tests (Octave::download_and_save_array, sift_octave.cu:111-188) */
 
 #define PSX_PLANE_GAUSS 0

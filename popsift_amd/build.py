@@ -28,8 +28,7 @@ HIP_FLAGS = [
 
 HOST_SOURCES = ["popsift.cpp", "sift_conf.cpp", "features.cpp", "device_prop.cpp"]
 HOST_FLAGS = ["-O2", "-std=c++14", "-fPIC", "-Wall", "-pthread",
-              "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "include"),
-              "-I", os.path.join(CSRC, "include", "popsift")]
+              "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "include")]
 
 
 def _hipcc():

@@ -659,6 +659,64 @@ int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float
     return PSX_OK;
 }
 
+int psx_dev_alloc(int device, size_t bytes, void** out)
+{
+    psx_ctx* ctx = nullptr;
+    if (!out) return PSX_ERR_INVALID;
+    PSX_HIP(hipSetDevice(device));
+    PSX_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return PSX_OK;
+}
+
+int psx_dev_free(int device, void* ptr)
+{
+    psx_ctx* ctx = nullptr;
+    if (!ptr) return PSX_OK;
+    PSX_HIP(hipSetDevice(device));
+    PSX_HIP(hipFree(ptr));
+    return PSX_OK;
+}
+
+int psx_clone_results(psx_ctx* ctx, void* d_features, void* d_descriptors, int* d_reverse_map)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    int rc = fetch_counts(ctx);
+    if (rc != PSX_OK) return rc;
+    const int ne = ctx->h_cnt->ext_total, no = ctx->h_cnt->ori_total;
+    if (ne > 0 && d_features)
+        PSX_HIP(hipMemcpyAsync(d_features, ctx->d_features, (size_t)ne * sizeof(psx_feature),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    if (no > 0 && d_descriptors)
+        PSX_HIP(hipMemcpyAsync(d_descriptors, ctx->d_desc, (size_t)no * 128 * sizeof(float),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    if (no > 0 && d_reverse_map)
+        PSX_HIP(hipMemcpyAsync(d_reverse_map, ctx->d_feat_to_ext, (size_t)no * sizeof(int),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    return PSX_OK;
+}
+
+int psx_device_count(int* count)
+{
+    psx_ctx* ctx = nullptr;
+    if (!count) return PSX_ERR_INVALID;
+    *count = 0;
+    PSX_HIP(hipGetDeviceCount(count));
+    return PSX_OK;
+}
+
+int psx_device_info(int device, char* name, int name_len, size_t* total_mem, int* compute_units, int* clock_khz)
+{
+    psx_ctx* ctx = nullptr;
+    hipDeviceProp_t p;
+    PSX_HIP(hipGetDeviceProperties(&p, device));
+    if (name && name_len > 0) { strncpy(name, p.name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+    if (total_mem) *total_mem = p.totalGlobalMem;
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (clock_khz) *clock_khz = p.clockRate;
+    return PSX_OK;
+}
+
 int psx_dump_plane(psx_ctx* ctx, int kind, int octave, int level, float* host_out)
 {
     if (!ctx || !host_out) return PSX_ERR_INVALID;

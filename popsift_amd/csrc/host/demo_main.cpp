@@ -1,0 +1,78 @@
+// demo_main.cpp -- minimal driver over the C++ API (used by the tests; the reference's
+// popsift-demo needs Boost and DevIL, which are not part of this hot-path build).
+//
+// usage: popsift_demo <w> <h> <raw-u8-or-f32-file> <out.txt> [--float] [--vlfeat|--opencv]
+//                     [--octaves N] [--repeat N] [--norm-multi M] [--classic]
+// writes: one line per descriptor:  x y sigma orientation d0..d127  (full float precision)
+#include <popsift/popsift.h>
+#include <popsift/features.h>
+#include <popsift/sift_conf.h>
+#include <popsift/version.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <queue>
+#include <vector>
+
+int main( int argc, char** argv )
+{
+    if( argc < 5 ) { std::cerr << "usage: " << argv[0] << " w h in.raw out.txt [options]" << std::endl; return 2; }
+    const int w = atoi( argv[1] ), h = atoi( argv[2] );
+    bool is_float = false;
+    int repeat = 1;
+    popsift::Config config;
+    for( int i = 5; i < argc; i++ ) {
+        if( !strcmp( argv[i], "--float" ) ) is_float = true;
+        else if( !strcmp( argv[i], "--vlfeat" ) ) config.setMode( popsift::Config::VLFeat );
+        else if( !strcmp( argv[i], "--opencv" ) ) config.setMode( popsift::Config::OpenCV );
+        else if( !strcmp( argv[i], "--classic" ) ) config.setNormMode( popsift::Config::Classic );
+        else if( !strcmp( argv[i], "--octaves" ) && i + 1 < argc ) config.setOctaves( atoi( argv[++i] ) );
+        else if( !strcmp( argv[i], "--norm-multi" ) && i + 1 < argc ) config.setNormalizationMultiplier( atoi( argv[++i] ) );
+        else if( !strcmp( argv[i], "--repeat" ) && i + 1 < argc ) repeat = atoi( argv[++i] );
+    }
+    std::vector<unsigned char> raw( (size_t)w * h * ( is_float ? 4 : 1 ) );
+    {
+        std::ifstream in( argv[3], std::ios::binary );
+        if( !in.read( (char*)raw.data(), (std::streamsize)raw.size() ) ) { std::cerr << "short read" << std::endl; return 3; }
+    }
+    std::cout << "PopSift version: " << POPSIFT_VERSION_STRING << std::endl;
+
+    PopSift sift( config, popsift::Config::ExtractingMode, is_float ? PopSift::FloatImages : PopSift::ByteImages );
+
+    std::queue<SiftJob*> jobs;
+    for( int r = 0; r < repeat; r++ ) {
+        SiftJob* job = is_float ? sift.enqueue( w, h, (const float*)raw.data() ) : sift.enqueue( w, h, raw.data() );
+        if( !job ) return 4;
+        jobs.push( job );
+    }
+    int rc = 0;
+    bool first = true;
+    size_t nf = 0, nd = 0;
+    while( !jobs.empty() ) {
+        SiftJob* job = jobs.front(); jobs.pop();
+        popsift::Features* fl = job->get();
+        if( !fl ) { rc = 5; delete job; continue; }
+        if( first ) {
+            nf = fl->getFeatureCount(); nd = fl->getDescriptorCount();
+            std::ofstream of( argv[4] );
+            of.precision( 9 );
+            for( const popsift::Feature& f : *fl )
+                for( int o = 0; o < f.num_ori; o++ ) {
+                    of << f.xpos << " " << f.ypos << " " << f.sigma << " " << f.orientation[o];
+                    for( int i = 0; i < 128; i++ ) of << " " << f.desc[o]->features[i];
+                    of << "\n";
+                }
+            first = false;
+        } else if( (size_t)fl->getFeatureCount() != nf || (size_t)fl->getDescriptorCount() != nd ) {
+            std::cerr << "repeat mismatch" << std::endl; rc = 6;
+        }
+        delete fl;
+        delete job;
+    }
+    std::cerr << "Number of feature points: " << nf << " number of feature descriptors: " << nd << std::endl;
+    sift.uninit();
+    return rc;
+}

@@ -1,0 +1,145 @@
+// features.cpp -- FeaturesHost / FeaturesDev / Feature::print
+// (reference behaviour: features.cu:27-128, 306-330)
+#include "popsift/features.h"
+#include "popsift/sift_extremum.h"
+
+#include "popsift_hip.h"
+
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <iomanip>
+#include <sstream>
+#include <stdexcept>
+#include <unistd.h>
+
+namespace popsift {
+
+namespace {
+[[noreturn]] void fatal( const char* file, int line, const std::string& msg )
+{
+    std::ostringstream o;
+    o << file << ":" << line << std::endl << "    " << msg;
+    throw std::runtime_error( o.str() );
+}
+void* page_alloc( size_t bytes )
+{
+    void* p = nullptr;
+    const size_t page = (size_t)sysconf( _SC_PAGESIZE );
+    const int err = posix_memalign( &p, page, bytes ? bytes : page );
+    if( err != 0 ) { errno = err; return nullptr; }
+    return p;
+}
+} // namespace
+
+FeaturesBase::FeaturesBase( ) : _num_ext( 0 ), _num_ori( 0 ) { }
+FeaturesBase::~FeaturesBase( ) = default;
+
+FeaturesHost::FeaturesHost( ) : _ext( nullptr ), _ori( nullptr ) { }
+
+FeaturesHost::FeaturesHost( int num_ext, int num_ori ) : _ext( nullptr ), _ori( nullptr )
+{
+    reset( num_ext, num_ori );
+}
+
+FeaturesHost::~FeaturesHost( )
+{
+    free( _ext );
+    free( _ori );
+}
+
+void FeaturesHost::reset( int num_ext, int num_ori )
+{
+    free( _ext ); _ext = nullptr;
+    free( _ori ); _ori = nullptr;
+
+    _ext = (Feature*)page_alloc( (size_t)num_ext * sizeof(Feature) );
+    if( _ext == nullptr ) {
+        std::ostringstream ss;
+        ss << "Runtime error:" << std::endl
+           << "    Failed to (re)allocate memory for downloading " << num_ext << " features";
+        fatal( __FILE__, __LINE__, ss.str() );
+    }
+    _ori = (Descriptor*)page_alloc( (size_t)num_ori * sizeof(Descriptor) );
+    if( _ori == nullptr ) {
+        std::ostringstream ss;
+        ss << "Runtime error:" << std::endl
+           << "    Failed to (re)allocate memory for downloading " << num_ori << " descriptors";
+        fatal( __FILE__, __LINE__, ss.str() );
+    }
+    setFeatureCount( num_ext );
+    setDescriptorCount( num_ori );
+}
+
+void FeaturesHost::pin( )   { }
+void FeaturesHost::unpin( ) { }
+
+void FeaturesHost::print( std::ostream& ostr, bool write_as_uchar ) const
+{
+    for( int i = 0; i < size(); i++ ) _ext[i].print( ostr, write_as_uchar );
+}
+
+std::ostream& operator<<( std::ostream& ostr, const FeaturesHost& feature )
+{
+    feature.print( ostr, false );
+    return ostr;
+}
+
+// output-features.txt line format (features.cu:310-330): x y 1/s^2 0 1/s^2 d0..d127
+void Feature::print( std::ostream& ostr, bool write_as_uchar ) const
+{
+    const float sigval = 1.0f / ( sigma * sigma );
+    for( int ori = 0; ori < num_ori; ori++ ) {
+        ostr << xpos << " " << ypos << " " << sigval << " 0 " << sigval << " ";
+        if( write_as_uchar ) {
+            for( int i = 0; i < 128; i++ ) ostr << roundf( desc[ori]->features[i] ) << " ";
+        } else {
+            ostr << std::setprecision(3);
+            for( int i = 0; i < 128; i++ ) ostr << desc[ori]->features[i] << " ";
+            ostr << std::setprecision(6);
+        }
+        ostr << std::endl;
+    }
+}
+
+std::ostream& operator<<( std::ostream& ostr, const Feature& feature )
+{
+    feature.print( ostr, false );
+    return ostr;
+}
+
+FeaturesDev::FeaturesDev( ) : _ext( nullptr ), _ori( nullptr ), _rev( nullptr ), _device( 0 ) { }
+
+FeaturesDev::FeaturesDev( int num_ext, int num_ori ) : _ext( nullptr ), _ori( nullptr ), _rev( nullptr ), _device( 0 )
+{
+    reset( num_ext, num_ori );
+}
+
+FeaturesDev::~FeaturesDev( )
+{
+    psx_dev_free( _device, _ext );
+    psx_dev_free( _device, _ori );
+    psx_dev_free( _device, _rev );
+}
+
+void FeaturesDev::reset( int num_ext, int num_ori )
+{
+    psx_dev_free( _device, _ext ); _ext = nullptr;
+    psx_dev_free( _device, _ori ); _ori = nullptr;
+    psx_dev_free( _device, _rev ); _rev = nullptr;
+    void *e = nullptr, *o = nullptr, *r = nullptr;
+    if( psx_dev_alloc( _device, (size_t)num_ext * sizeof(psx_feature), &e ) != PSX_OK ||
+        psx_dev_alloc( _device, (size_t)num_ori * sizeof(Descriptor), &o ) != PSX_OK ||
+        psx_dev_alloc( _device, (size_t)num_ori * sizeof(int), &r ) != PSX_OK )
+        fatal( __FILE__, __LINE__, "Runtime error:\n    Failed to allocate device memory for features" );
+    _ext = (Feature*)e; _ori = (Descriptor*)o; _rev = (int*)r;
+    setFeatureCount( num_ext );
+    setDescriptorCount( num_ori );
+}
+
+void FeaturesDev::match( FeaturesDev* )
+{
+    fatal( __FILE__, __LINE__, "not yet" );
+}
+
+} // namespace popsift

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_*.npz from the REFERENCE's own code (oracle/_ref/libpopsift_ref.so:
+/root/reference/src/popsift compiled for the CPU through the CUDA emulation in oracle/ref_shim).
+
+Run in the build container (where /root/reference exists):
+    make -C oracle ref && python tests/golden/make_golden.py
+The fixtures are small (a few tens of kB each) and are committed; the GPU box has no reference.
+Each fixture holds the input image, the config overrides, every Gaussian plane's SHA-1, the
+initial extrema per octave, the Feature records and the descriptors as produced by the reference.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle as po, pyref as pr   # noqa: E402
+from popsift_amd.synth import synth, synth_float  # noqa: E402
+
+CASES = {
+    # name: (w, h, seed, float_input, config overrides)
+    "popsift_96x72": (96, 72, 101, False, dict(octaves=3)),
+    "vlfeat_112x80": (112, 80, 102, False, dict(octaves=3, sift_mode=po.MODE_VLFEAT)),
+    "opencv_96x80": (96, 80, 103, False, dict(octaves=3, sift_mode=po.MODE_OPENCV, gauss_mode=po.GAUSS_OPENCV_COMPUTE)),
+    "float_up0_classic_160x120": (160, 120, 104, True, dict(octaves=3, upscale_factor=0.0, norm_mode=po.NORM_CLASSIC, norm_multi=9)),
+    "auto_octaves_75x61": (75, 61, 105, False, dict()),
+}
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for name, (w, h, seed, is_float, kw) in CASES.items():
+        img = synth_float(w, h, seed) if is_float else synth(w, h, seed)
+        cfg = po.default_config(**kw)
+        r = pr.run(cfg, img)
+        planes = {}
+        for o in range(r.num_octaves):
+            for l in range(r.num_levels):
+                planes["g_%d_%d" % (o, l)] = hashlib.sha1(np.ascontiguousarray(r.gauss(o, l)).tobytes()).hexdigest()
+        data = dict(
+            image=img, config=json.dumps(kw), dims=np.array(r.dims, dtype=np.int32),
+            num_levels=r.num_levels, plane_sha1=json.dumps(planes),
+            gauss_last=r.gauss(r.num_octaves - 1, r.num_levels - 1),
+            features=r.features(), descriptors=r.descriptors(),
+        )
+        for o in range(r.num_octaves):
+            data["iext_%d" % o] = r.iext(o)
+        # the public API path (PopSift::enqueue / SiftJob::get) must agree with the direct drive
+        ra = pr.run(cfg, img, api=True)
+        assert ra.ext_total == r.ext_total and ra.ori_total == r.ori_total
+        np.savez_compressed(os.path.join(out_dir, "ref_%s.npz" % name), **data)
+        print(name, "octaves", r.num_octaves, "features", r.ext_total, "descriptors", r.ori_total)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""CPU tests of the product's host logic: the C-ABI library loads and exports every symbol
+include/popsift_hip.h declares, its device-free entry points agree with the oracle, and the
+product fails loudly (never falls back to a CPU path) without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    hdr = open(os.path.join(ROOT, "include", "popsift_hip.h")).read()
+    declared = set(re.findall(r"\b(psx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = capi.lib()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(capi.SYMBOLS) == declared
+
+
+def test_header_cites_reference_and_has_no_device_types():
+    hdr = open(os.path.join(ROOT, "include", "popsift_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)      # strip comments
+    for forbidden in ("hipStream_t", "hipError_t", "hipEvent_t", "#include <hip", "torch", "std::", "at::Tensor"):
+        assert forbidden not in code, forbidden
+    assert hdr.count(".cu:") + hdr.count(".cpp:") + hdr.count(".h:") > 25      # file:line citations
+
+
+def test_config_defaults_match_oracle(capi, oracle):
+    a, b = capi.default_config(), oracle.default_config()
+    for name, _ in a._fields_:
+        if hasattr(b, name):
+            assert getattr(a, name) == getattr(b, name), name
+    assert a.scaling_mode == capi.SCALE_DEFAULT and a.desc_mode == capi.DESC_LOOP
+    assert abs(capi.lib().psx_peak_threshold(C.byref(a)) - oracle.lib().osift_peak_threshold(C.byref(b))) == 0
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(gauss_mode=3), dict(upscale_factor=0.0), dict(upscale_factor=-1.0),
+                                dict(levels=5, sigma=1.2), dict(levels=2, sigma=2.0), dict(assume_initial_blur=0)])
+def test_gauss_tables_bit_equal_oracle(capi, oracle, kw):
+    a = capi.gauss_tables(capi.default_config(**kw))
+    b = oracle.gauss_tables(oracle.default_config(**kw))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_gauss_table_errors(capi):
+    with pytest.raises(capi.PopSiftError):
+        capi.gauss_tables(capi.default_config(sigma=2.5))      # gauss_filter.cu:131-137
+    with pytest.raises(capi.PopSiftError):
+        capi.gauss_tables(capi.default_config(levels=10))      # gauss_filter.cu:138-144
+
+
+def test_unsupported_modes_are_rejected_before_touching_a_device(capi):
+    for kw in (dict(desc_mode=capi.DESC_GRID), dict(gauss_mode=capi.GAUSS_FIXED9), dict(scaling_mode=capi.SCALE_DIRECT)):
+        with pytest.raises(capi.PopSiftError):
+            capi.Context(capi.default_config(**kw))
+
+
+def test_no_cpu_fallback_without_gpu(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.PopSiftError) as e:
+        capi.Context(capi.default_config())
+    assert "hipSetDevice" in str(e.value) or "device" in str(e.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "popsift_amd")):
+        if os.sep + "build" in base or os.sep + "lib" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip", ".c")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"\boracle\b", txt) and "oracle/sift_oracle.c" not in txt:
+                    bad.append(os.path.join(base, f))
+                elif "liboracle" in txt or "pyoracle" in txt:
+                    bad.append(os.path.join(base, f))
+    hdr = open(os.path.join(ROOT, "include", "popsift_hip.h")).read()
+    assert "oracle" not in hdr
+    assert not bad, bad
+
+
+def test_shard_range_partitions_every_frame():
+    from popsift_amd.dispatch import shard_range, round_robin
+    for n in (0, 1, 7, 64, 65):
+        for world in (1, 2, 4, 8):
+            seen = []
+            for r in range(world):
+                b, e = shard_range(n, world, r)
+                assert 0 <= b <= e <= n
+                seen += list(range(b, e))
+            assert seen == list(range(n))
+            sizes = [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert round_robin(5, 2) == [0, 1, 0, 1, 0]
+
+
+def _host_lib():
+    p = os.path.join(ROOT, "popsift_amd", "lib", "libpopsift.so")
+    if not os.path.exists(p):
+        from popsift_amd import build
+        build.build_all()
+    return p
+
+
+def test_cpp_host_library_api(tmp_path):
+    """Compile and run tests/cpp/test_host_api.cpp against libpopsift.so: Config surface, error
+    convention, and that a job is always fulfilled (get() throws instead of hanging) with no GPU."""
+    _host_lib()
+    exe = str(tmp_path / "test_host_api")
+    inc = [os.path.join(ROOT, "popsift_amd", "csrc", "include"), os.path.join(ROOT, "include")]
+    libdir = os.path.join(ROOT, "popsift_amd", "lib")
+    cmd = ["g++", "-std=c++14", "-O1", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_host_api.cpp"), "-o", exe]
+    for i in inc:
+        cmd += ["-I", i]
+    cmd += ["-L", libdir, "-lpopsift", "-lpopsift_hip", "-Wl,-rpath," + libdir]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout
+    assert "ALL OK" in out.stdout

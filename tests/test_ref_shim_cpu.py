@@ -1,0 +1,46 @@
+"""Live comparison of the oracle with the reference's own code on the CPU (oracle/_ref).
+
+Only runs where oracle/_ref/libpopsift_ref.so has been built (needs /root/reference at build time;
+the library travels with the snapshot, the sources do not).  Slow (fiber emulation of every CUDA
+thread), so the images are tiny; the committed fixtures in tests/golden cover more cases.
+"""
+import numpy as np
+import pytest
+
+from popsift_amd.synth import synth
+from tests.parity import match_features
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import pyref
+    if not pyref.available():
+        pytest.skip("oracle/_ref/libpopsift_ref.so not built (no /root/reference here)")
+    pyref.lib()
+    return pyref
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(gauss_mode=3), dict(upscale_factor=0.0), dict(levels=4, sigma=1.4)])
+def test_gauss_tables_bit_equal_reference(oracle, ref, kw):
+    a = ref.gauss_tables(oracle.default_config(**kw))
+    b = oracle.gauss_tables(oracle.default_config(**kw))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_pipeline_matches_reference(oracle, ref):
+    img = synth(88, 64, 31)
+    cfg = oracle.default_config(octaves=3)
+    r, o = ref.run(cfg, img), oracle.run(cfg, img)
+    assert r.dims == o.dims and r.num_levels == o.num_levels
+    for oc in range(r.num_octaves):
+        for l in range(r.num_levels):
+            assert np.array_equal(r.gauss(oc, l), o.gauss(oc, l)), (oc, l)     # bit-identical planes
+        for l in range(r.num_levels - 1):
+            assert np.array_equal(r.dog(oc, l), o.dog(oc, l))
+        assert len(r.iext(oc)) == len(o.iext(oc))
+    m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors())
+    assert m["kp_match"] == 1.0 and m["ori_match"] == 1.0 and m["desc_match"] == 1.0
+    # the public API (PopSift::enqueue -> SiftJob::get, worker threads) gives the same counts
+    ra = ref.run(cfg, img, api=True)
+    assert (ra.ext_total, ra.ori_total) == (r.ext_total, r.ori_total)
