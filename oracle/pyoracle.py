@@ -207,13 +207,25 @@ def _img_args(img):
     return img, w, h, is_float
 
 
+def default_threads():
+    """OpenMP threads for the oracle: usable cores (affinity and cgroup quota), at most 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def run(cfg, img, threads=0):
     img, w, h, is_float = _img_args(img)
-    lib().osift_set_threads(threads)
+    lib().osift_set_threads(threads if threads > 0 else default_threads())
     return Result(lib().osift_run(C.byref(cfg), img.ctypes.data_as(C.c_void_p), w, h, is_float))
 
 
 def run_pyramid(cfg, img, threads=0):
     img, w, h, is_float = _img_args(img)
-    lib().osift_set_threads(threads)
+    lib().osift_set_threads(threads if threads > 0 else default_threads())
     return Result(lib().osift_run_pyramid(C.byref(cfg), img.ctypes.data_as(C.c_void_p), w, h, is_float))

@@ -20,11 +20,15 @@
  *   output mapping          sift_pyramid.cu:250-280
  *   grid filter             s_filtergrid.cu:36-325
  *
- * PARITY PIN STATUS: the reference ships no golden vectors (its goldens are an
- * external reference.tgz fetched by wget, testScripts/downloadOxfordDataset.sh.in:4-9).
- * The restatement is pinned instead against the reference's own sources compiled
- * for the CPU through a CUDA-emulation shim (oracle/_ref, see oracle/Makefile and
- * oracle/ref_shim/); see DESIGN.md "Oracle".
+ * PARITY PIN STATUS: PINNED.  The reference ships no golden vectors of its own (its goldens are
+ * an external reference.tgz fetched by wget, testScripts/downloadOxfordDataset.sh.in:4-9), so
+ * the restatement is pinned against OUTPUTS OF THE REFERENCE ITSELF RUN HERE: its sources are
+ * compiled for the CPU through the CUDA-emulation shim in oracle/ref_shim (recipe: `make -C
+ * oracle ref`, output oracle/_ref/libpopsift_ref.so) and compared with this file
+ *   - live in tests/test_ref_shim_cpu.py (Gauss tables and every pyramid plane bit-identical,
+ *     feature sets identical within 2e-5 px, descriptors within 2e-6), and
+ *   - through the committed fixtures tests/golden/ref_*.npz (tests/golden/make_golden.py).
+ * See DESIGN.md "Oracle".
  */
 #ifndef SIFT_ORACLE_H
 #define SIFT_ORACLE_H
