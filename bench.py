@@ -160,11 +160,18 @@ def main():
             tot_bytes += by
             nl += 1
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9     # GB/s, algorithmic 8 B/pixel
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
+        # and --pmc WRITE_SIZE in separate runs, 2x FETCH_SIZE correction); null when not collected
+        traffic = None
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["k_blur_octave0_hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": "k_blur (octave 0, 3840x2160, levels 1..5)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "avg_launch_ms": round(tot_ms / nl, 5), "bytes_per_launch": tot_bytes / nl,
-                    "traffic": None}
+                    "traffic": traffic}
 
         # per-stage device time of one frame (HIP events on the context's stream)
         c0.enable_timers(True)
