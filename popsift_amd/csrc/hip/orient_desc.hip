@@ -46,17 +46,11 @@ __device__ __forceinline__ void wave_fence()
 // the order in which lanes and waves arrive (the reference's shared-memory float atomicAdd,
 // s_orientation.cu:159, is order dependent).
 typedef unsigned long long fix64;
-__device__ __forceinline__ fix64 to_fix(float w)
-{
-    const float fl = floorf(w);
-    const unsigned hi = (unsigned)fl;
-    const unsigned lo = (unsigned)((w - fl) * 4294967296.0f);
-    return ((fix64)hi << 32) | (fix64)lo;
-}
-__device__ __forceinline__ float from_fix(fix64 v)
-{
-    return __ull2float_rn(v) * (1.0f / 4294967296.0f);
-}
+// A single contribution is grad * weight <= |gradient| <= 255*sqrt(2) < 512, so 9.23 fixed point fits
+// one v_cvt_u32_f32; the 64-bit accumulator leaves 2^32 of headroom for the sum.
+constexpr float FIX_SCALE = 8388608.0f;           // 2^23
+__device__ __forceinline__ fix64 to_fix(float w) { return (fix64)(unsigned)(w * FIX_SCALE); }
+__device__ __forceinline__ float from_fix(fix64 v) { return __ull2float_rn(v) * (1.0f / FIX_SCALE); }
 
 __device__ __forceinline__ float wave_max(float v)
 {
@@ -372,7 +366,7 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     fix64* acc = s_desc[wave];
     const int lx = lane & 15, ly = lane >> 4;
-    fix64* myacc = acc + (lx & (DCOPIES - 1)) * DSTRIDE;
+    fix64* myacc = acc + (lane & (DCOPIES - 1)) * DSTRIDE;
 
     const int total = cnt->ori_total;
     const int nwaves = gridDim.x * WPB;

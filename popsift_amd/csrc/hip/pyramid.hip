@@ -24,6 +24,8 @@
 //   level 0 H (s_pyramid_build_ra.cu:17-55): pairs outermost-in, then centre, then *255
 #include "psx_internal.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TW = 64;    // strip width (columns per workgroup)
@@ -100,8 +102,18 @@ __device__ __forceinline__ float vfilter(const float* v, int i, const PsxTaps& t
     return o;
 }
 
+#ifdef PSX_PHASE_TIMING
+__device__ long long* g_blur_dbg = nullptr;
+extern "C" void psx_debug_set_blur_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blur_dbg), &d, sizeof(d)); }
+#define BSTAMP(i) do { long long c_ = clock64(); tacc[i] += c_ - tprev; tprev = c_; } while (0)
+#else
+#define BSTAMP(i)
+#endif
 template <int R>
-__global__ __launch_bounds__(NT) void k_blur(BlurArgs a)
+#ifndef PSX_BLUR_MINW
+#define PSX_BLUR_MINW 1
+#endif
+__global__ __launch_bounds__(NT, PSX_BLUR_MINW) void k_blur(BlurArgs a)
 {
     using G = Geom<R>;
     constexpr int HALO = G::HALO, SW4 = G::SW4, NLD = G::NLD, RING = G::RING, SWA = G::SWA;
@@ -150,10 +162,17 @@ __global__ __launch_bounds__(NT) void k_blur(BlurArgs a)
         }
     };
 
+#ifdef PSX_PHASE_TIMING
+    long long tacc[5] = {0, 0, 0, 0, 0};
+    long long tprev = clock64();
+    const long long tstart = tprev;
+#endif
     issue(0);
     for (int k = 0; k < nsteps; k++) {
         commit();
+        BSTAMP(0);
         __syncthreads();
+        BSTAMP(1);
         if (k + 1 < nsteps) issue(k + 1);
 
         // ---- horizontal: thread = (row, 8-column segment) ----
@@ -173,7 +192,9 @@ __global__ __launch_bounds__(NT) void k_blur(BlurArgs a)
             rp[0] = make_float4(out[0], out[1], out[2], out[3]);
             rp[8] = make_float4(out[4], out[5], out[6], out[7]);
         }
+        BSTAMP(2);
         __syncthreads();
+        BSTAMP(3);
 
         // ---- vertical: thread = (column, group of 8 output rows) ----
         {
@@ -198,7 +219,14 @@ __global__ __launch_bounds__(NT) void k_blur(BlurArgs a)
                 }
             }
         }
+        BSTAMP(4);
     }
+#ifdef PSX_PHASE_TIMING
+    if (threadIdx.x == 0 && g_blur_dbg) {
+        for (int q = 0; q < 5; q++) g_blur_dbg[blockIdx.x * 8 + q] = tacc[q];
+        g_blur_dbg[blockIdx.x * 8 + 5] = clock64() - tstart; g_blur_dbg[blockIdx.x * 8 + 6] = nsteps;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -244,9 +272,9 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
     __shared__ float s_lut[256];      // u8 texel -> v/255 (cudaReadModeNormalizedFloat)
     __shared__ int   s_ci[SW];        // per staged column: left texel index and 1.8 weight
     __shared__ float s_ca[SW];
-    __shared__ int   s_rj[BR];        // per staged row
-    __shared__ float s_rb[BR];
-    constexpr int TEXW = 104, TEXH = 40;   // input-texel footprint of one step (upscale >= 0)
+    __shared__ int   s_rj[2 * BR];    // per staged row (double buffered)
+    __shared__ float s_rb[2 * BR];
+    constexpr int TEXW = 56, TEXH = 24;    // input-texel footprint of one step (covers upscale >= 1; else direct loads)
     __shared__ float s_tex[TEXH * TEXW];
 
     const int t     = threadIdx.x;
@@ -264,54 +292,124 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
         l0_axis(((float)(x0 - HALO + t) + a.shift) / (float)a.W, a.w, i0, al);
         s_ci[t] = i0; s_ca[t] = al;
     }
-
-    for (int k = 0; k < nsteps; k++) {
+    // row tables are double buffered: the table of step k+1 is built during step k so that the
+    // texel loads of step k+1 can be issued a whole step ahead (software prefetch into registers)
+    auto build_rows = [&](int k) {
         if (t < BR) {
             const int y = psx_clampi(Y0 - R + k * BR + t, 0, a.H - 1);
             int j0; float be;
             l0_axis(((float)y + a.shift) / (float)a.H, a.h, j0, be);
-            s_rj[t] = j0; s_rb[t] = be;
+            s_rj[(k & 1) * BR + t] = j0; s_rb[(k & 1) * BR + t] = be;
         }
-        __syncthreads();   // tables ready; previous H pass finished reading s_stage
-        // texel footprint of this step (index tables are monotone in row / column)
-        const int jlo = psx_clampi(s_rj[0], 0, a.h - 1), jhi = psx_clampi(s_rj[BR - 1] + 1, 0, a.h - 1);
-        const int ilo = psx_clampi(s_ci[0], 0, a.w - 1), ihi = psx_clampi(s_ci[SW - 1] + 1, 0, a.w - 1);
-        const int nrows = jhi - jlo + 1, ncols = ihi - ilo + 1;
-        const bool via_lds = (nrows <= TEXH && ncols <= TEXW);     // uniform over the workgroup
-        if (via_lds) {
-            // phase 1: input texels (as float, v/255 for bytes) -> LDS, each read from HBM once
-            for (int idx = t; idx < nrows * ncols; idx += NT) {
-                const int jr = idx / ncols, ic = idx - jr * ncols;
+    };
+    constexpr int NTEX = (TEXH * 64 + NT - 1) / NT;          // texel loads per thread (64-wide rows)
+    float treg[NTEX];
+    int jlo = 0, ilo = 0, nrows = 0, ncols = 0;
+    bool via_lds = false;
+    auto footprint = [&](int k) {
+        const int* rj = &s_rj[(k & 1) * BR];
+        jlo = psx_clampi(rj[0], 0, a.h - 1);
+        const int jhi = psx_clampi(rj[BR - 1] + 1, 0, a.h - 1);
+        ilo = psx_clampi(s_ci[0], 0, a.w - 1);
+        const int ihi = psx_clampi(s_ci[SW - 1] + 1, 0, a.w - 1);
+        nrows = jhi - jlo + 1; ncols = ihi - ilo + 1;
+        via_lds = (nrows <= TEXH && ncols <= TEXW);             // uniform over the workgroup
+    };
+    auto issue_texels = [&]() {
+        if (!via_lds) return;
+        const int ic = t & 63;
+#pragma unroll
+        for (int q = 0; q < NTEX; q++) {
+            const int jr = (t >> 6) + q * (NT / 64);
+            treg[q] = 0.0f;
+            if (jr < nrows && ic < ncols) {
                 const size_t g = (size_t)(jlo + jr) * a.w + (ilo + ic);
-                s_tex[jr * TEXW + ic] = a.is_float ? static_cast<const float*>(a.img)[g]
-                                                   : s_lut[static_cast<const uint8_t*>(a.img)[g]];
+                treg[q] = a.is_float ? static_cast<const float*>(a.img)[g]
+                                     : (float)static_cast<const uint8_t*>(a.img)[g];    // LUT applied at commit
             }
-            __syncthreads();
         }
-        for (int idx = t; idx < BR * SW; idx += NT) {
-            const int row = idx / SW, c = idx - row * SW;
-            const int i0 = s_ci[c], j0 = s_rj[row];
-            const float al = s_ca[c], be = s_rb[row];
-            const int ia = psx_clampi(i0, 0, a.w - 1), ib = psx_clampi(i0 + 1, 0, a.w - 1);
-            const int ja = psx_clampi(j0, 0, a.h - 1), jb = psx_clampi(j0 + 1, 0, a.h - 1);
-            float t00, t10, t01, t11;
-            if (via_lds) {
-                const float* ra = &s_tex[(ja - jlo) * TEXW - ilo];
-                const float* rb = &s_tex[(jb - jlo) * TEXW - ilo];
-                t00 = ra[ia]; t10 = ra[ib]; t01 = rb[ia]; t11 = rb[ib];
-            } else if (a.is_float) {
-                const float* f = static_cast<const float*>(a.img);
-                t00 = f[(size_t)ja * a.w + ia]; t10 = f[(size_t)ja * a.w + ib];
-                t01 = f[(size_t)jb * a.w + ia]; t11 = f[(size_t)jb * a.w + ib];
-            } else {
-                const uint8_t* b = static_cast<const uint8_t*>(a.img);
-                t00 = s_lut[b[(size_t)ja * a.w + ia]]; t10 = s_lut[b[(size_t)ja * a.w + ib]];
-                t01 = s_lut[b[(size_t)jb * a.w + ia]]; t11 = s_lut[b[(size_t)jb * a.w + ib]];
+    };
+
+#ifdef PSX_PHASE_TIMING
+    long long tacc[5] = {0, 0, 0, 0, 0};
+    long long tprev = clock64();
+    const long long tstart = tprev;
+#endif
+    build_rows(0);
+    __syncthreads();
+    footprint(0);
+    issue_texels();
+
+    for (int k = 0; k < nsteps; k++) {
+        // commit the prefetched texels of this step (previous U staging has passed two barriers)
+        if (via_lds) {
+            const int ic = t & 63;
+#pragma unroll
+            for (int q = 0; q < NTEX; q++) {
+                const int jr = (t >> 6) + q * (NT / 64);
+                if (jr < nrows && ic < ncols)
+                    s_tex[jr * TEXW + ic] = a.is_float ? treg[q] : s_lut[(int)treg[q]];
             }
-            const float r0 = l0_lerp(t00, t10, al);
-            const float r1 = l0_lerp(t01, t11, al);
-            s_stage[row * SWA + stage_chunk(row, c >> 2) * 4 + (c & 3)] = l0_lerp(r0, r1, be);
         }
+        const int cjlo = jlo, cilo = ilo;
+        const bool cvia = via_lds;
+        if (k + 1 < nsteps) build_rows(k + 1);
+        BSTAMP(0);
+        __syncthreads();   // texels + next row table visible; previous H pass finished reading s_stage
+        BSTAMP(1);
+        if (k + 1 < nsteps) { footprint(k + 1); issue_texels(); }
+        const int* rjk = &s_rj[(k & 1) * BR];
+        const float* rbk = &s_rb[(k & 1) * BR];
+        // U(X, y) = lerp_y( lerp_x(T[j0]), lerp_x(T[j0+1]) ): same operations, same order as the texture
+        // model of the oracle
+        // All LDS / global reads of a thread's elements are issued before the first lerp: the loops are
+        // fully unrolled with a static trip count, and the (workgroup-uniform) source selection is
+        // hoisted OUTSIDE them -- a per-element select makes hipcc branch and wait per element.
+        {
+            constexpr int NPT = (BR * SW + NT - 1) / NT;
+            auto stage_elems = [&](auto mode) {
+                constexpr int MODE = decltype(mode)::value;     // 0: LDS texels, 1: float image, 2: u8 image
+                float t00[NPT], t10[NPT], t01[NPT], t11[NPT], al[NPT], be[NPT];
+#pragma unroll
+                for (int q = 0; q < NPT; q++) {
+                    const int idx = min(t + q * NT, BR * SW - 1);
+                    const int row = idx / SW, c = idx - row * SW;
+                    const int i0 = s_ci[c], j0 = rjk[row];
+                    al[q] = s_ca[c]; be[q] = rbk[row];
+                    const int ia = psx_clampi(i0, 0, a.w - 1), ib = psx_clampi(i0 + 1, 0, a.w - 1);
+                    const int ja = psx_clampi(j0, 0, a.h - 1), jb = psx_clampi(j0 + 1, 0, a.h - 1);
+                    if (MODE == 0) {
+                        const float* ra = &s_tex[(ja - cjlo) * TEXW - cilo];
+                        const float* rb = &s_tex[(jb - cjlo) * TEXW - cilo];
+                        t00[q] = ra[ia]; t10[q] = ra[ib]; t01[q] = rb[ia]; t11[q] = rb[ib];
+                    } else if (MODE == 1) {
+                        const float* f = static_cast<const float*>(a.img);
+                        t00[q] = f[(size_t)ja * a.w + ia]; t10[q] = f[(size_t)ja * a.w + ib];
+                        t01[q] = f[(size_t)jb * a.w + ia]; t11[q] = f[(size_t)jb * a.w + ib];
+                    } else {
+                        const uint8_t* b = static_cast<const uint8_t*>(a.img);
+                        t00[q] = (float)b[(size_t)ja * a.w + ia]; t10[q] = (float)b[(size_t)ja * a.w + ib];
+                        t01[q] = (float)b[(size_t)jb * a.w + ia]; t11[q] = (float)b[(size_t)jb * a.w + ib];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NPT; q++) {
+                    const int idx = t + q * NT;
+                    if (idx < BR * SW) {
+                        const int row = idx / SW, c = idx - row * SW;
+                        float p00 = t00[q], p10 = t10[q], p01 = t01[q], p11 = t11[q];
+                        if (MODE == 2) { p00 = s_lut[(int)p00]; p10 = s_lut[(int)p10]; p01 = s_lut[(int)p01]; p11 = s_lut[(int)p11]; }
+                        const float r0 = l0_lerp(p00, p10, al[q]);
+                        const float r1 = l0_lerp(p01, p11, al[q]);
+                        s_stage[row * SWA + stage_chunk(row, c >> 2) * 4 + (c & 3)] = l0_lerp(r0, r1, be[q]);
+                    }
+                }
+            };
+            if (cvia) stage_elems(std::integral_constant<int, 0>{});
+            else if (a.is_float) stage_elems(std::integral_constant<int, 1>{});
+            else stage_elems(std::integral_constant<int, 2>{});
+        }
+        BSTAMP(2);
         __syncthreads();
         {
             const int row = t >> 3, seg = t & 7;
@@ -329,6 +427,7 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
             rp[0] = make_float4(out[0], out[1], out[2], out[3]);
             rp[8] = make_float4(out[4], out[5], out[6], out[7]);
         }
+        BSTAMP(3);
         __syncthreads();
         {
             const int pos = t & (TW - 1), rg = t >> 6;
@@ -348,7 +447,15 @@ __global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
                 }
             }
         }
+        BSTAMP(4);
     }
+#ifdef PSX_PHASE_TIMING
+    if (threadIdx.x == 0 && g_blur_dbg) {
+        long long* d_ = g_blur_dbg + 1100 * 8;     // level-0 region of the debug buffer
+        for (int q = 0; q < 5; q++) d_[blockIdx.x * 8 + q] = tacc[q];
+        d_[blockIdx.x * 8 + 5] = clock64() - tstart; d_[blockIdx.x * 8 + 6] = nsteps;
+    }
+#endif
 }
 
 // get_by_2_pick_every_second (s_pyramid_build.cu:50-71), used only when the fused path is off
