@@ -158,8 +158,12 @@ int psx_set_input_dev(psx_ctx* ctx, const void* dev_ptr, int w, int h, int is_fl
 int psx_build_pyramid(psx_ctx* ctx);
 /* Pyramid::find_extrema (s_extrema.cu:560-640). */
 int psx_find_extrema(psx_ctx* ctx);
-/* Pyramid::orientation incl. ori_prefix_sum (s_orientation.cu:364-441) and the optional
- * extrema_filter_grid (s_filtergrid.cu:113-325). */
+/* Pyramid::orientation incl. ori_prefix_sum (s_orientation.cu:364-441) and, when
+ * filter_max_extrema > 0, extrema_filter_grid (s_filtergrid.cu:113-325) on the device.  As in the
+ * reference the filter reads the extrema counts on the host first (one stream sync per frame); it
+ * runs only if int(filter_max_extrema*1.1) < number of extrema (s_orientation.cu:378-383).
+ * LargestScaleFirst / SmallestScaleFirst results are deterministic; RandomScale keeps the first
+ * extrema of each cell in buffer (atomicAdd arrival) order, as the reference does. */
 int psx_orientation(psx_ctx* ctx);
 /* Pyramid::descriptors incl. normalize_histogram (sift_desc.cu:55-110) and prep_features
  * (sift_pyramid.cu:250-280). */

@@ -4,5 +4,11 @@
 #define POPSIFT_IS_DEFINED(F) F() == 1
 #define POPSIFT_HAVE_SHFL_DOWN_SYNC() 0
 #define POPSIFT_HAVE_NORMF()          0
-#define POPSIFT_DISABLE_GRID_FILTER() 1   /* s_filtergrid.cu needs Thrust; the filter is off by default */
+/* s_filtergrid.cu needs Thrust: the Makefile compiles it against rocThrust's headers with the serial
+ * CPP device system (SHIM_HAVE_THRUST); without them the reference's own disabled branch is built. */
+#ifdef SHIM_HAVE_THRUST
+#define POPSIFT_DISABLE_GRID_FILTER() 0
+#else
+#define POPSIFT_DISABLE_GRID_FILTER() 1
+#endif
 #define POPSIFT_USE_NVTX()            0

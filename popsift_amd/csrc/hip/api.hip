@@ -104,6 +104,13 @@ struct psx_ctx {
     int* d_feat_to_ext = nullptr;      size_t f2e_cap = 0;
     int* d_ext_nori = nullptr;         size_t nori_cap = 0;
 
+    // grid filter scratch (allocated on first use)
+    unsigned long long* d_gf_keys = nullptr; size_t gf_keys_cap = 0;    // 2 x total
+    unsigned* d_gf_vals = nullptr;           size_t gf_vals_cap = 0;    // 2 x total
+    unsigned char* d_gf_temp = nullptr;      size_t gf_temp_cap = 0;
+    int* d_gf_scratch = nullptr;             size_t gf_scratch_cap = 0;
+    bool filtered = false;             // the grid filter ran on the current frame
+
     // zero-copy export
     psx_feature* x_host_feat = nullptr; float* x_host_desc = nullptr;
     psx_feature* x_dev_feat = nullptr;  float* x_dev_desc = nullptr;
@@ -250,6 +257,11 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
         return fail(nullptr, PSX_ERR_INVALID, "invalid sift mode");
     if (c.max_extrema <= 0 || c.filter_grid_size <= 0)
         return fail(nullptr, PSX_ERR_INVALID, "invalid max_extrema / filter_grid_size");
+    if (c.filter_max_extrema > 0 && c.filter_grid_size > 64)
+        return fail(nullptr, PSX_ERR_INVALID, "filter_grid_size > 64 not supported by the HIP grid filter");
+    if (c.grid_filter_mode != PSX_FILTER_RANDOM && c.grid_filter_mode != PSX_FILTER_LARGEST_FIRST &&
+        c.grid_filter_mode != PSX_FILTER_SMALLEST_FIRST)
+        return fail(nullptr, PSX_ERR_INVALID, "invalid grid_filter_mode");
 
     PSX_HIP(hipSetDevice(device));
     psx_ctx* n = new (std::nothrow) psx_ctx();
@@ -296,6 +308,8 @@ int psx_destroy(psx_ctx* ctx)
     if (ctx->x_registered_desc) (void)hipHostUnregister(ctx->x_host_desc);
     if (ctx->h_xcnt) (void)hipHostFree(ctx->h_xcnt);
     (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr);
+    (void)hipFree(ctx->d_gf_keys); (void)hipFree(ctx->d_gf_vals); (void)hipFree(ctx->d_gf_temp);
+    (void)hipFree(ctx->d_gf_scratch);
     (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off);
     (void)hipFree(ctx->d_extrema); (void)hipFree(ctx->d_features);
     (void)hipFree(ctx->d_desc); (void)hipFree(ctx->d_feat_to_ext); (void)hipFree(ctx->d_ext_nori);
@@ -486,6 +500,34 @@ int psx_build_pyramid(psx_ctx* ctx)
     return PSX_OK;
 }
 
+// Pyramid::extrema_filter_grid (s_filtergrid.cu:113-325), gated as in s_orientation.cu:378-383.
+// Like the reference, the host reads the per-octave counts once to decide and to size the sort.
+static int grid_filter(psx_ctx* ctx)
+{
+    PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    int total = 0;
+    for (int o = 0; o < ctx->hp.num_octaves; o++) total += imin(ctx->h_cnt->ext_ct[o], ctx->cfg.max_extrema);
+    const int fmax = ctx->cfg.filter_max_extrema;
+    if (!((int)(fmax * 1.1) < total)) return PSX_OK;
+
+    int rc;
+    size_t temp_bytes = 0;
+    PSX_HIP(psx_gridfilter_sort_bytes(total, &temp_bytes));
+    if ((rc = grow(ctx, &ctx->d_gf_keys, &ctx->gf_keys_cap, 2 * (size_t)total)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_gf_vals, &ctx->gf_vals_cap, 2 * (size_t)total)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_gf_temp, &ctx->gf_temp_cap, temp_bytes + 256)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_gf_scratch, &ctx->gf_scratch_cap,
+                   psx_gridfilter_scratch_ints(ctx->cfg.filter_grid_size))) != PSX_OK) return rc;
+    PSX_HIP(psx_launch_gridfilter(ctx->d_params, ctx->d_cnt, ctx->cfg.grid_filter_mode, total, fmax,
+                                  ctx->d_gf_keys, ctx->d_gf_keys + total, ctx->d_gf_vals,
+                                  ctx->d_gf_vals + total, ctx->d_gf_temp, temp_bytes, ctx->d_gf_scratch,
+                                  ctx->stream));
+    ctx->filtered = true;
+    ctx->counts_valid = false;
+    return PSX_OK;
+}
+
 int psx_find_extrema(psx_ctx* ctx)
 {
     if (!ctx) return PSX_ERR_INVALID;
@@ -493,6 +535,7 @@ int psx_find_extrema(psx_ctx* ctx)
     PSX_HIP(hipSetDevice(ctx->device));
     for (int o = 0; o < ctx->hp.num_octaves; o++)
         PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+    ctx->filtered = false;
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     return PSX_OK;
 }
@@ -502,6 +545,10 @@ int psx_orientation(psx_ctx* ctx)
     if (!ctx) return PSX_ERR_INVALID;
     if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_orientation: no pyramid");
     PSX_HIP(hipSetDevice(ctx->device));
+    if (ctx->cfg.filter_max_extrema > 0 && !ctx->filtered) {
+        int rc = grid_filter(ctx);
+        if (rc != PSX_OK) return rc;
+    }
     PSX_HIP(psx_launch_orientation(ctx->d_params, ctx->d_cnt, ctx->stream));
     PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, ctx->stream));
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -752,7 +799,7 @@ int psx_dump_iext(psx_ctx* ctx, int octave, psx_iext* host_out, int capacity, in
     if (ctx->counts_partial) { ctx->counts_valid = false; }
     int rc = fetch_counts_full(ctx);
     if (rc != PSX_OK) return rc;
-    int n = imin(ctx->h_cnt->ext_ct[octave], ctx->cfg.max_extrema);
+    int n = imin(ctx->filtered ? ctx->h_cnt->iext_ct[octave] : ctx->h_cnt->ext_ct[octave], ctx->cfg.max_extrema);
     if (count) *count = n;
     if (host_out) {
         n = imin(n, capacity);

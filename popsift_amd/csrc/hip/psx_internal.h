@@ -67,6 +67,7 @@ struct PsxCounters {
     int ext_total;
     int ori_total;
     int pad[2];
+    int iext_ct[PSX_MAX_OCTAVES];  // initial extrema per octave before the grid filter (set by k_gf_apply)
 };
 
 struct PsxTaps { float g[PSX_GAUSS_ALIGN]; };
@@ -89,6 +90,13 @@ hipError_t psx_launch_downscale(const float* src, int sw, int sh, int spitch,
 hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s);
 hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt,
                               int octave, hipStream_t s);
+// grid filter (gridfilter.hip)
+size_t     psx_gridfilter_scratch_ints(int grid_size);
+hipError_t psx_gridfilter_sort_bytes(int total, size_t* bytes);
+hipError_t psx_launch_gridfilter(const PsxParams* d_params, PsxCounters* d_cnt, int mode, int total,
+                                 int filter_max, unsigned long long* keys_in, unsigned long long* keys_out,
+                                 unsigned* vals_in, unsigned* vals_out, void* temp, size_t temp_bytes,
+                                 int* scratch, hipStream_t s);
 hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
 hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
 hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, hipStream_t s);

@@ -172,6 +172,73 @@ def test_empty_and_tiny_inputs(oracle, capi):
     ctx2.close()
 
 
+def _iext_all(res_iext, num_octaves):
+    """(octave, x, y, level, cell, ignore) rows of all initial extrema, canonically ordered."""
+    rows = []
+    for o in range(num_octaves):
+        a = res_iext(o)
+        for e in a:
+            # sigma goes through powf and may differ in the last ulp (tolerance 1e-3 elsewhere): not a key
+            rows.append((o, float(e["xpos"]), float(e["ypos"]), int(e["lpos"]), 0,
+                         int(e["cell"]), int(e["ignore"])))
+    rows.sort()
+    return rows
+
+
+@pytest.mark.parametrize("mode,grid,fmax", [(1, 2, 800), (2, 2, 800), (1, 3, 1500), (2, 4, 300), (0, 2, 800),
+                                            (0, 3, 500)])
+def test_grid_filter(oracle, capi, mode, grid, fmax):
+    """extrema_filter_grid (s_filtergrid.cu:113-325) on the device vs the oracle's restatement.
+
+    LargestScaleFirst / SmallestScaleFirst: the surviving set is defined by (cell, scale) order, so
+    the ignore flags must agree extremum by extremum.  RandomScale keeps the first extrema of each
+    cell in buffer order, which is atomicAdd arrival order on a GPU (also in the reference): only
+    the per-cell and per-octave survivor counts are defined, and those must agree.
+    """
+    img = synth(640, 480, 4242)
+    kw = dict(octaves=4, filter_max_extrema=fmax, filter_grid_size=grid, grid_filter_mode=mode)
+    ocfg, gcfg = _cfgs(oracle, capi, kw)
+    ref = oracle.run(ocfg, img)
+    unfiltered = oracle.run(oracle.default_config(octaves=4), img)
+    assert unfiltered.ext_total > int(fmax * 1.1), "test image must trigger the filter"
+    assert ref.ext_total < unfiltered.ext_total
+    ctx = capi.Context(gcfg)
+    ctx.upload(img)
+    ctx.extract()
+    f, d = ctx.download()
+    a = _iext_all(ref.iext, ref.num_octaves)
+    b = _iext_all(ctx.dump_iext, ref.num_octaves)
+    assert len(a) == len(b)
+    assert len(f) == ref.ext_total
+    if mode != 0:
+        # exact duplicates (same position, level and scale) are interchangeable: compare as sorted rows
+        assert a == b
+        m = match_features(ref.features(), ref.descriptors(), f, d)
+        assert m["kp_match"] >= 0.999 and m["ori_match"] >= 0.995 and m["desc_match"] >= 0.995, m
+    else:
+        def survivors(rows, key):
+            out = {}
+            for r in rows:
+                if r[6] == 0:
+                    out[r[key]] = out.get(r[key], 0) + 1
+            return out
+        assert survivors(a, 5) == survivors(b, 5)     # per grid cell
+        assert survivors(a, 0) == survivors(b, 0)     # per octave
+    ctx.close()
+
+
+def test_grid_filter_not_triggered(oracle, capi):
+    """Below 1.1 x FilterMaxExtrema nothing is filtered (s_orientation.cu:378-383)."""
+    img = synth(320, 240, 5)
+    ref = oracle.run(oracle.default_config(octaves=3), img)
+    ctx = capi.Context(capi.default_config(octaves=3, filter_max_extrema=int(ref.ext_total / 1.1) + 1))
+    ctx.upload(img)
+    ctx.extract()
+    f, _ = ctx.download()
+    assert len(f) == ref.ext_total
+    ctx.close()
+
+
 def test_context_reuse_and_resize(oracle, capi):
     """One context, frames of different sizes (Pyramid::resetDimensions, sift_pyramid.cu:165-177)."""
     ocfg, gcfg = _cfgs(oracle, capi, dict(octaves=3))
