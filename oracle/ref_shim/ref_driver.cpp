@@ -122,11 +122,13 @@ void* ref_run(const osift_config* c, const void* img, int w, int h, int is_float
             r->gauss.emplace_back(gd + (size_t)l * W * H, gd + (size_t)(l + 1) * W * H);
         for (int l = 0; l < r->L - 1; l++)
             r->dog.emplace_back(dd + (size_t)l * W * H, dd + (size_t)(l + 1) * W * H);
-        // initial extrema of this octave (hct / dobuf_shadow: sift_pyramid.cu:41-49)
+        // initial extrema of this octave that reach the orientation stage (hct / dobuf_shadow:
+        // sift_pyramid.cu:41-49), read through i_ext_off as ori_par does (s_orientation.cu:83): after
+        // extrema_filter_grid hct.ext_ct[o] counts the survivors and i_ext_off lists them
         std::vector<osift_iext> v;
         const int n = std::min(hct.ext_ct[o], h_consts.max_extrema);
         for (int i = 0; i < n; i++) {
-            const InitialExtremum& e = dobuf_shadow.i_ext_dat[o][i];
+            const InitialExtremum& e = dobuf_shadow.i_ext_dat[o][dobuf_shadow.i_ext_off[o][i]];
             osift_iext x;
             x.xpos = e.xpos; x.ypos = e.ypos; x.lpos = e.lpos; x.sigma = e.sigma; x.cell = e.cell; x.ignore = e.ignore;
             v.push_back(x);

@@ -1,0 +1,1 @@
+#include "../../thrust_shim.h"

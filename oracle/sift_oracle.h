@@ -28,6 +28,9 @@
  *   - live in tests/test_ref_shim_cpu.py (Gauss tables and every pyramid plane bit-identical,
  *     feature sets identical within 2e-5 px, descriptors within 2e-6), and
  *   - through the committed fixtures tests/golden/ref_*.npz (tests/golden/make_golden.py).
+ * The grid filter is pinned the same way: s_filtergrid.cu itself is compiled against a serial
+ * stand-in for the Thrust calls it makes (oracle/ref_shim/thrust_shim.h; sort_by_key = stable sort,
+ * which is what Thrust's radix / merge sorts are) -- all three sort modes, live and as fixtures.
  * See DESIGN.md "Oracle".
  */
 #ifndef SIFT_ORACLE_H

@@ -28,6 +28,12 @@ CASES = {
     "opencv_96x80": (96, 80, 103, False, dict(octaves=3, sift_mode=po.MODE_OPENCV, gauss_mode=po.GAUSS_OPENCV_COMPUTE)),
     "float_up0_classic_160x120": (160, 120, 104, True, dict(octaves=3, upscale_factor=0.0, norm_mode=po.NORM_CLASSIC, norm_multi=9)),
     "auto_octaves_75x61": (75, 61, 105, False, dict()),
+    # extrema_filter_grid (s_filtergrid.cu, compiled against oracle/ref_shim/thrust_shim.h); the
+    # RandomScale mode depends on buffer order and has no order-free golden answer beyond counts
+    "gridfilter_largest_160x120": (160, 120, 99, False, dict(octaves=3, filter_max_extrema=38, filter_grid_size=2,
+                                                             grid_filter_mode=po.FILTER_LARGEST_FIRST)),
+    "gridfilter_smallest_g3_160x120": (160, 120, 99, False, dict(octaves=3, filter_max_extrema=57, filter_grid_size=3,
+                                                                 grid_filter_mode=po.FILTER_SMALLEST_FIRST)),
 }
 
 
@@ -48,7 +54,7 @@ def main():
             features=r.features(), descriptors=r.descriptors(),
         )
         for o in range(r.num_octaves):
-            data["iext_%d" % o] = r.iext(o)
+            data["iext_%d" % o] = r.iext(o)      # the extrema that reach orientation (grid-filter survivors)
         # the public API path (PopSift::enqueue / SiftJob::get) must agree with the direct drive
         ra = pr.run(cfg, img, api=True)
         assert ra.ext_total == r.ext_total and ra.ori_total == r.ori_total

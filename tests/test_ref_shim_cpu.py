@@ -44,3 +44,21 @@ def test_pipeline_matches_reference(oracle, ref):
     # the public API (PopSift::enqueue -> SiftJob::get, worker threads) gives the same counts
     ra = ref.run(cfg, img, api=True)
     assert (ra.ext_total, ra.ori_total) == (r.ext_total, r.ori_total)
+
+
+@pytest.mark.parametrize("mode,grid,frac", [(0, 2, 3), (1, 3, 2), (2, 2, 5)])
+def test_grid_filter_matches_reference(oracle, ref, mode, grid, frac):
+    """extrema_filter_grid: the reference's own s_filtergrid.cu (on oracle/ref_shim/thrust_shim.h) vs the
+    oracle's grid_filter().  The emulated device fills the extrema buffers in a deterministic order, so
+    even RandomScale (buffer-order dependent) can be compared feature by feature here."""
+    img = synth(160, 120, 99)
+    total = oracle.run(oracle.default_config(octaves=3), img).ext_total
+    cfg = oracle.default_config(octaves=3, filter_max_extrema=total // frac, filter_grid_size=grid,
+                                grid_filter_mode=mode)
+    r, o = ref.run(cfg, img), oracle.run(cfg, img)
+    assert r.ext_total == o.ext_total < total and r.ori_total == o.ori_total
+    for oc in range(r.num_octaves):
+        kept = o.iext(oc)
+        assert len(r.iext(oc)) == int((kept["ignore"] == 0).sum())
+    m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors())
+    assert m["kp_match"] == 1.0 and m["ori_match"] == 1.0 and m["desc_match"] == 1.0, m
