@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpopsift_hip.so")
+LIB_PATH = os.environ.get("POPSIFT_HIP_LIB") or os.path.join(_HERE, "lib", "libpopsift_hip.so")
 
 MAX_OCTAVES = 20
 GAUSS_ALIGN = 32

@@ -13,8 +13,8 @@
 // strip and marches down a chunk of rows in steps of 32 rows.  Per step: 32 input rows (+halo
 // columns) are staged in LDS with row-coalesced float4 loads (the loads for step k+1 are issued
 // before the arithmetic of step k), the horizontal filter writes into an LDS ring of 64
-// H-filtered rows, the vertical filter reads 8+2R ring values per thread to produce 8 output
-// rows of one column.  Each plane is read once and written once (8 B/pixel algorithmic traffic);
+// H-filtered rows, the vertical filter reads 4+2R ring rows per thread to produce 4 output
+// rows of two adjacent columns (packed f32 math).  Each plane is read once and written once (8 B/pixel algorithmic traffic);
 // the intermediate plane of the reference ("intm", 16 B/pixel more) never exists.
 //
 // Arithmetic order is the reference's, written with explicit fmaf (the file is compiled with
@@ -102,6 +102,27 @@ __device__ __forceinline__ float vfilter(const float* v, int i, const PsxTaps& t
     return o;
 }
 
+// the same chain on two adjacent columns at once (v_pk_fma_f32): v[j] = (T[.][c], T[.][c+1])
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define LDS_AS __attribute__((address_space(3)))
+__device__ __forceinline__ v2f pk_fma(v2f a, float g, v2f c)
+{
+    return __builtin_elementwise_fma(a, (v2f){g, g}, c);
+}
+template <int R>
+__device__ __forceinline__ v2f vfilter2(const v2f* v, int i, const PsxTaps& tp)
+{
+    v2f o = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = R; k >= 1; k--) {
+        o = pk_fma(v[R + i - k], tp.g[k], o);
+        o = pk_fma(v[R + i + k], tp.g[k], o);
+    }
+    o = pk_fma(v[R + i], tp.g[0], o);
+    return o;
+}
+
 #ifdef PSX_PHASE_TIMING
 __device__ long long* g_blur_dbg = nullptr;
 extern "C" void psx_debug_set_blur_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blur_dbg), &d, sizeof(d)); }
@@ -109,16 +130,70 @@ extern "C" void psx_debug_set_blur_buffer(long long* d) { (void)hipMemcpyToSymbo
 #else
 #define BSTAMP(i)
 #endif
+// ---------------------------------------------------------------------------------------------
+// k_blur: marching strips, laid out so that the loop body is almost only the arithmetic (an earlier
+// version spent ~2/3 of its VALU instructions on addresses, swizzles and ring wrap-around):
+//   * staged rows have an ODD stride in 16-byte chunks and the horizontal pass maps its lanes to
+//     (row, segment) so that every ds_read_b128 lane group is {2 adjacent rows} x {8 segments}:
+//     conflict free with plain immediate offsets, no XOR swizzle;
+//   * the ring of H-filtered rows is stored unpermuted with a 68-float row stride (aligned, conflict-free
+//     b128 writes and b64 reads) and its first rows are mirrored behind its end, so a
+//     vertical window never wraps: every ds_read_b64 is base + immediate offset;
+//   * all per-thread staging geometry is computed once, outside the step loop;
+//   * vertical pass on two adjacent columns per lane (v_pk_fma_f32), horizontal pass packed by
+//     the compiler over adjacent outputs.
+// ---------------------------------------------------------------------------------------------
 template <int R>
-#ifndef PSX_BLUR_MINW
-#define PSX_BLUR_MINW 1
-#endif
-__global__ __launch_bounds__(NT, PSX_BLUR_MINW) void k_blur(BlurArgs a)
+struct Geom2 {
+    static constexpr int HALO = (R + 3) & ~3;
+    static constexpr int SW   = TW + 2 * HALO;          // staged row width (floats)
+    static constexpr int SW4  = SW / 4;
+    static constexpr int NLD  = (BR * SW4 + NT - 1) / NT;
+    static constexpr int SWA  = 4 * (SW4 | 1);          // odd number of chunks per row
+    static constexpr int RING = (BR + 2 * R <= 64) ? 64 : 128;
+    static constexpr int VWIN = 4 + 2 * R;              // ring rows read by one vertical thread
+    static constexpr int MIRROR = VWIN - 1;             // slots < MIRROR are duplicated at slot + RING
+    static constexpr int RS   = TW + 4;                 // ring row stride (floats): 16-byte aligned rows, == 4 (mod 8)
+};
+
+// k-major forms of the two filters: the per-output chains are the reference's, but the independent
+// chains advance together so that dependent v_pk_fma_f32 never issue back to back
+template <int R, int HALO>
+__device__ __forceinline__ void hfilter8_km(const float* win, const PsxTaps& tp, float* out)
 {
-    using G = Geom<R>;
-    constexpr int HALO = G::HALO, SW4 = G::SW4, NLD = G::NLD, RING = G::RING, SWA = G::SWA;
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = fmaf(win[HALO + i], tp.g[0], 0.0f);
+#pragma unroll
+    for (int k = R; k >= 1; k--) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[i] = fmaf(win[HALO + i - k] + win[HALO + i + k], tp.g[k], out[i]);
+    }
+}
+template <int R>
+__device__ __forceinline__ void vfilter2x4_km(const v2f* v, const PsxTaps& tp, v2f* o)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (v2f){0.0f, 0.0f};
+#pragma unroll
+    for (int k = R; k >= 1; k--) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i - k], tp.g[k], o[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i + k], tp.g[k], o[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i], tp.g[0], o[i]);
+}
+
+template <int R>
+__global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur(BlurArgs a)
+{
+    using G = Geom2<R>;
+    constexpr int HALO = G::HALO, SW4 = G::SW4, NLD = G::NLD, SWA = G::SWA, RING = G::RING;
+    constexpr int VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS;
+    constexpr bool LAST_PARTIAL = (BR * SW4) % NT != 0;     // only the last staging slot can be empty
     __shared__ __attribute__((aligned(16))) float s_stage[BR * SWA];
-    __shared__ __attribute__((aligned(16))) float s_ring[RING * TW];
+    __shared__ __attribute__((aligned(16))) float s_ring[(RING + MIRROR) * RS];
 
     const int t     = threadIdx.x;
     const int lid   = xcd_remap(blockIdx.x, gridDim.x);
@@ -128,99 +203,142 @@ __global__ __launch_bounds__(NT, PSX_BLUR_MINW) void k_blur(BlurArgs a)
     const int Y0    = chunk * a.chunk_rows;
     const int Y1    = min(Y0 + a.chunk_rows, a.H);
     const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
+    const bool interior = (x0 - HALO >= 0) && (x0 + TW + HALO <= a.W);     // workgroup uniform
 
-    float4 pre[NLD];
+    // ---- staging geometry of this thread (step invariant) ----
+    int st_row[NLD], st_x[NLD], st_lds[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; j++) {
+        const int idx = t + j * NT;
+        const int row = idx / SW4, c4 = idx - row * SW4;
+        st_row[j] = row;
+        st_x[j]   = x0 - HALO + c4 * 4;
+        st_lds[j] = row * SWA + c4 * 4;
+    }
+    const bool last_on = !LAST_PARTIAL || (t + (NLD - 1) * NT < BR * SW4);
 
-    auto issue = [&](int k) {
-#pragma unroll
-        for (int j = 0; j < NLD; j++) {
-            const int idx = t + j * NT;
-            if (idx < BR * SW4) {
-                const int row = idx / SW4, c4 = idx - row * SW4;
-                const int y = psx_clampi(Y0 - R + k * BR + row, 0, a.H - 1);
-                const int x = x0 - HALO + c4 * 4;
-                const float* rp = a.src + (size_t)y * a.pitch;
-                if (x >= 0 && x + 3 < a.W) {
-                    pre[j] = *reinterpret_cast<const float4*>(rp + x);
-                } else {
-                    pre[j].x = rp[psx_clampi(x + 0, 0, a.W - 1)];
-                    pre[j].y = rp[psx_clampi(x + 1, 0, a.W - 1)];
-                    pre[j].z = rp[psx_clampi(x + 2, 0, a.W - 1)];
-                    pre[j].w = rp[psx_clampi(x + 3, 0, a.W - 1)];
-                }
-            }
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < NLD; j++) {
-            const int idx = t + j * NT;
-            if (idx < BR * SW4) {
-                const int row = idx / SW4, c4 = idx - row * SW4;
-                *reinterpret_cast<float4*>(&s_stage[row * SWA + stage_chunk(row, c4) * 4]) = pre[j];
-            }
-        }
-    };
+    // ---- horizontal pass geometry: lane -> (row, 8-column segment).  Two constraints (MI355X_MICROARCH.md,
+    // LDS): the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} must each hold two rows
+    // an odd distance apart (rows {0,1} / {2,3}; the staged row stride is an odd number of chunks), and
+    // the ds_write_b128 groups (8 contiguous lanes) of the ring store must pair rows an odd distance
+    // apart as well (ring row stride == 4 mod 8 dwords): (0,3) (3,0) (2,1) (1,2). ----
+    int h_row, h_seg;
+    {
+        const int blk = (t & 31) >> 2;                    // 4-lane block within the 32-lane half
+        const int rq = (0x21120330 >> (4 * blk)) & 3;     // rows          0 3 3 0 2 1 1 2
+        const int sh = (0xCC >> blk) & 1;                 // segments 4-7? 0 0 1 1 0 0 1 1
+        h_row = (t >> 6) * 8 + ((t >> 5) & 1) * 4 + rq;
+        h_seg = sh * 4 + (t & 3);
+    }
+    const LDS_AS float* h_src = (const LDS_AS float*)&s_stage[h_row * SWA + h_seg * 8];
+    // ---- vertical pass geometry: thread = (2 adjacent columns, 4 output rows) ----
+    const int v_pp = t & 31, v_rg = t >> 5;
+    const int v_x  = x0 + 2 * v_pp;
+    // byte offsets relative to row (Y0 - 2R + k*BR) of the destination planes; the row part is uniform
+    const unsigned v_doff = (unsigned)((v_rg * 4) * a.pitch + v_x) * 4u;
+    const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
 
 #ifdef PSX_PHASE_TIMING
     long long tacc[5] = {0, 0, 0, 0, 0};
     long long tprev = clock64();
     const long long tstart = tprev;
 #endif
-    issue(0);
-    for (int k = 0; k < nsteps; k++) {
-        commit();
-        BSTAMP(0);
-        __syncthreads();
-        BSTAMP(1);
-        if (k + 1 < nsteps) issue(k + 1);
-
-        // ---- horizontal: thread = (row, 8-column segment) ----
-        {
-            const int row = t >> 3, seg = t & 7;
-            float win[8 + 2 * HALO];
-            const float4* sp = reinterpret_cast<const float4*>(&s_stage[row * SWA]);
+    auto run = [&](auto interior_c) {
+        constexpr bool INTERIOR = decltype(interior_c)::value;
+        v4f pre[NLD];
+        auto issue = [&](int k) {
+            const int ybase = Y0 - R + k * BR;
 #pragma unroll
-            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
-                const float4 v = sp[stage_chunk(row, seg * 2 + q)];
-                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
-            }
-            float out[8];
-            hfilter8<R, HALO, false>(win, a.taps, out);
-            const int slot = (k * BR + row) & (RING - 1);
-            float4* rp = reinterpret_cast<float4*>(&s_ring[slot * TW + seg * 4]);
-            rp[0] = make_float4(out[0], out[1], out[2], out[3]);
-            rp[8] = make_float4(out[4], out[5], out[6], out[7]);
-        }
-        BSTAMP(2);
-        __syncthreads();
-        BSTAMP(3);
-
-        // ---- vertical: thread = (column, group of 8 output rows) ----
-        {
-            const int pos = t & (TW - 1), rg = t >> 6;
-            const int col = ring_col_of_pos(pos);
-            const int rel0 = k * BR - 2 * R + rg * 8;     // ring-relative index of T[r_out0 - R]
-            const int r_out0 = Y0 + rel0;
-            if (r_out0 + 7 >= Y0 && r_out0 < Y1) {        // wave-uniform
-                float v[8 + 2 * R];
-#pragma unroll
-                for (int j = 0; j < 8 + 2 * R; j++) v[j] = s_ring[((rel0 + j) & (RING - 1)) * TW + pos];
-                const int x = x0 + col;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int r_out = r_out0 + i;
-                    const float o = vfilter<R>(v, i, a.taps);
-                    if (r_out >= Y0 && r_out < Y1 && x < a.W) {
-                        a.dst[(size_t)r_out * a.pitch + x] = o;
-                        if (a.half_dst != nullptr && ((r_out | x) & 1) == 0)
-                            a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (x >> 1)] = o;
+            for (int j = 0; j < NLD; j++) {
+                if (j < NLD - 1 || last_on) {
+                    const int y = psx_clampi(ybase + st_row[j], 0, a.H - 1);
+                    if (INTERIOR) {
+                        const unsigned off = (unsigned)(y * a.pitch + st_x[j]) * 4u;
+                        pre[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.src) + off);
+                    } else {
+                        const float* rp = a.src + (size_t)y * a.pitch;
+                        const int x = st_x[j];
+                        pre[j].x = rp[psx_clampi(x + 0, 0, a.W - 1)];
+                        pre[j].y = rp[psx_clampi(x + 1, 0, a.W - 1)];
+                        pre[j].z = rp[psx_clampi(x + 2, 0, a.W - 1)];
+                        pre[j].w = rp[psx_clampi(x + 3, 0, a.W - 1)];
                     }
                 }
             }
+        };
+        auto commit = [&]() {
+#pragma unroll
+            for (int j = 0; j < NLD; j++)
+                if (j < NLD - 1 || last_on) *reinterpret_cast<v4f*>(&s_stage[st_lds[j]]) = pre[j];
+        };
+
+        issue(0);
+        for (int k = 0; k < nsteps; k++) {
+            commit();
+            BSTAMP(0);
+            __syncthreads();
+            BSTAMP(1);
+            if (k + 1 < nsteps) issue(k + 1);
+
+            // ---- horizontal ----
+            {
+                float win[8 + 2 * HALO];
+#pragma unroll
+                for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
+                    // volatile: keep one ds_read_b128 per chunk (otherwise the vectoriser re-reads every
+                    // odd-aligned pair with ds_read2_b32, at a quarter of the b128 rate and with conflicts)
+                    const v4f v = ((const volatile LDS_AS v4f*)h_src)[q];
+                    win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+                }
+                float out[8];
+                hfilter8_km<R, HALO>(win, a.taps, out);
+                const int slot = (k * BR + h_row) & (RING - 1);
+                float* rp = &s_ring[slot * RS + h_seg * 8];
+                reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
+                reinterpret_cast<float4*>(rp)[1] = make_float4(out[4], out[5], out[6], out[7]);
+                if (slot < MIRROR) {
+                    reinterpret_cast<float4*>(rp + RING * RS)[0] = make_float4(out[0], out[1], out[2], out[3]);
+                    reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
+                }
+            }
+            BSTAMP(2);
+            __syncthreads();
+            BSTAMP(3);
+
+            // ---- vertical ----
+            {
+                const int rel0 = k * BR - 2 * R + v_rg * 4;       // ring-relative index of T[r_out0 - R]
+                const int r_out0 = Y0 + rel0;
+                if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
+                    const LDS_AS float* vp = (const LDS_AS float*)&s_ring[(rel0 & (RING - 1)) * RS + 2 * v_pp];
+                    v2f v[VWIN];
+#pragma unroll
+                    // volatile: plain ds_read_b64 (256 B/clk); merged ds_read2_b64 runs at half that rate
+                    for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
+                    v2f o[4];
+                    vfilter2x4_km<R>(v, a.taps, o);
+                    // pin the four results here: otherwise each chain is sunk into its own predicated
+                    // store block and runs alone, dependent v_pk_fma_f32 back to back
+                    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+                    // uniform row base of this step; thread offsets are step invariant
+                    char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + k * BR) * a.pitch);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int r_out = r_out0 + i;
+                        if (r_out >= Y0 && r_out < Y1 && v_xok) {
+                            char* di = drow + (size_t)i * a.pitch * 4 + v_doff;
+                            if (v_pair) *reinterpret_cast<v2f*>(di) = o[i]; else *reinterpret_cast<float*>(di) = o[i].x;
+                            // get_by_2_pick_every_second: rows and columns 0,2,4,.. (v_x is even)
+                            if (a.half_dst != nullptr && (r_out & 1) == 0)
+                                a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = o[i].x;
+                        }
+                    }
+                }
+            }
+            BSTAMP(4);
         }
-        BSTAMP(4);
-    }
+    };
+    if (interior) run(std::true_type{}); else run(std::false_type{});
 #ifdef PSX_PHASE_TIMING
     if (threadIdx.x == 0 && g_blur_dbg) {
         for (int q = 0; q < 5; q++) g_blur_dbg[blockIdx.x * 8 + q] = tacc[q];

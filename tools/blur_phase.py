@@ -7,7 +7,7 @@ L = capi.lib()
 img = synth(1920, 1080, 1000)
 ctx = capi.Context(capi.default_config(octaves=5)); ctx.upload(img); ctx.extract(); ctx.sync()
 buf = torch.zeros(1100 * 8, dtype=torch.int64, device="cuda")
-for lvl in (1, 5):
+for lvl in (1, 2, 3, 4, 5):
     L.psx_debug_set_blur_buffer(C.c_void_p(buf.data_ptr()))
     buf.zero_(); torch.cuda.synchronize()
     ms, _ = ctx.time_blur(0, lvl, 1)
