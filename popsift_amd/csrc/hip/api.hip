@@ -96,6 +96,8 @@ struct psx_ctx {
     const void* d_input = nullptr;     int input_is_float = 0;
 
     float* d_pyr = nullptr;            size_t pyr_cap = 0;      // floats
+    float* d_up = nullptr;             size_t up_cap = 0;       // resampled input of octave 0 (floats)
+    int up_pitch = 0;
     psx_iext* d_iext = nullptr;        size_t iext_cap = 0;
     int* d_iext_off = nullptr;         size_t iext_off_cap = 0;
     psx_extremum* d_extrema = nullptr; size_t extrema_cap = 0;
@@ -307,7 +309,7 @@ int psx_destroy(psx_ctx* ctx)
     if (ctx->x_registered_feat) (void)hipHostUnregister(ctx->x_host_feat);
     if (ctx->x_registered_desc) (void)hipHostUnregister(ctx->x_host_desc);
     if (ctx->h_xcnt) (void)hipHostFree(ctx->h_xcnt);
-    (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr);
+    (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr); (void)hipFree(ctx->d_up);
     (void)hipFree(ctx->d_gf_keys); (void)hipFree(ctx->d_gf_vals); (void)hipFree(ctx->d_gf_temp);
     (void)hipFree(ctx->d_gf_scratch);
     (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off);
@@ -376,6 +378,8 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     total += 64;   // slack: vector loads never run past the last plane
     int rc;
     if ((rc = grow(ctx, &ctx->d_pyr, &ctx->pyr_cap, total)) != PSX_OK) return rc;
+    ctx->up_pitch = ((P.oct[0].w + 63) / 64) * 64 + 2 * PSX_LEVEL0_PAD;
+    if ((rc = grow(ctx, &ctx->d_up, &ctx->up_cap, (size_t)ctx->up_pitch * P.oct[0].h)) != PSX_OK) return rc;
     for (int o = 0; o < P.num_octaves; o++) P.oct[o].data = ctx->d_pyr + offs[o];
 
     // buffers sized so that no counter read-back is needed before they are used
@@ -484,6 +488,7 @@ int psx_build_pyramid(psx_ctx* ctx)
     PsxLevel0Args a;
     a.img = ctx->d_input; a.w = ctx->in_w; a.h = ctx->in_h; a.is_float = ctx->input_is_float;
     a.dst = P.oct[0].data; a.W = P.oct[0].w; a.H = P.oct[0].h; a.pitch = P.oct[0].pitch;
+    a.tmp = ctx->d_up; a.tmp_pitch = ctx->up_pitch;
     a.shift = 0.5f;                                                    // s_pyramid_build.cu:109-114
     if (c.sift_mode == PSX_MODE_POPSIFT || c.sift_mode == PSX_MODE_VLFEAT)
         a.shift = 0.5f * powf(2.0f, c.upscale_factor - 0);

@@ -52,6 +52,17 @@ constexpr float FIX_SCALE = 8388608.0f;           // 2^23
 __device__ __forceinline__ fix64 to_fix(float w) { return (fix64)(unsigned)(w * FIX_SCALE); }
 __device__ __forceinline__ float from_fix(fix64 v) { return __ull2float_rn(v) * (1.0f / FIX_SCALE); }
 
+#define LDS_AS __attribute__((address_space(3)))
+// ds_add_u64 without return value on an LDS-address-space pointer (immediate offsets fold into the instruction)
+__device__ __forceinline__ void lds_add(fix64 LDS_AS* p, fix64 v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(unsigned LDS_AS* p, unsigned v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ float wave_max(float v)
 {
 #pragma unroll
@@ -341,7 +352,7 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
 {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float a = mn * __frcp_rn(fmaxf(mx, 1e-30f));
+    const float a = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f));     // v_rcp_f32, 1 ulp
     const float s = a * a;
     float r = 0.006811792496591806f;
     r = fmaf(r, s, -0.0336042195558548f);
@@ -356,21 +367,33 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
     return (y < 0.0f) ? -r : r;
 }
 
-__global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt)
+typedef const __attribute__((address_space(1))) float* gfloat_p;
+
+__global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt)
 {
-    // 4 private copies of the 128-bin histogram per wave (lane column & 3): neighbouring pixels of
-    // a row fall into the same tile and orientation bin, and same-address atomics serialise.
-    // Copy stride 129 entries puts equal bins of different copies on different LDS banks.
-    constexpr int DCOPIES = 4, DSTRIDE = 129;
-    __shared__ fix64 s_desc[WPB][DCOPIES * DSTRIDE];
+    // Histogram layout per copy: tiles (iy, ix), iy, ix in -1..4, at index (iy+1)*5 + (ix+1), 8 bins
+    // each.  Column 0 and rows 0 / 5 are never read: the trilinear scatter of a pixel near the window
+    // border lands there instead of being range-checked (the kernel is VALU bound; the checks cost
+    // more than the wasted atomics).  ix = 4 of row iy aliases ix = -1 of row iy+1: both are dump slots.
+    // 4 private copies per wave (lane & 3): neighbouring pixels of a row fall into the same tile and
+    // orientation bin, and same-address atomics serialise.
+    // Bins are 18.14 unsigned fixed point, accumulated with ds_add_u32 (round to nearest per contribution):
+    // a bin collects at most (2*SBP)^2 pixels x |gradient| <= 360.7; SBP = 3*sigma <= ~15 for any legal
+    // Config (sigma <= 2, sift_conf.h) gives < 3.3e5 in total, i.e. < 8.2e4 per copy (the 4 copies take
+    // every 4th column) against 2^18 = 2.6e5.
+    constexpr int DCOPIES = 4, DTILES = 31, DSTRIDE = DTILES * 8 + 1;
+    constexpr float DFIX = 16384.0f;
+    __shared__ unsigned s_desc[WPB][DCOPIES * DSTRIDE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    fix64* acc = s_desc[wave];
+    unsigned* acc = s_desc[wave];
     const int lx = lane & 15, ly = lane >> 4;
-    fix64* myacc = acc + (lane & (DCOPIES - 1)) * DSTRIDE;
+    // LDS byte address of tile (-1,-1) of this lane's copy
+    const unsigned myacc = (unsigned)(uintptr_t)(acc + (lane & (DCOPIES - 1)) * DSTRIDE);
 
     const int total = cnt->ori_total;
     const int nwaves = gridDim.x * WPB;
-    for (int j = blockIdx.x * WPB + wave; j < total; j += nwaves) {
+    for (int jv = blockIdx.x * WPB + wave; jv < total; jv += nwaves) {
+        const int j = __builtin_amdgcn_readfirstlane(jv);          // wave uniform: scalar loads below
         const int ext_idx = P->feat_to_ext[j];
         const psx_extremum ex = P->extrema[ext_idx];
         const int ori_num = psx_clampi(j - ex.idx_ori, 0, PSX_ORI_MAX - 1);
@@ -380,13 +403,14 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
 
         if (ori_num == 0 && lane == 0) write_feature(P, ext_idx, ex, ex.idx_ori);
 
-        for (int i = lane; i < DCOPIES * DSTRIDE; i += PSX_WAVE) acc[i] = 0ull;
+        for (int i = lane; i < DCOPIES * DSTRIDE; i += PSX_WAVE) acc[i] = 0u;
         wave_fence();
 
         const float x = ex.xpos, y = ex.ypos;
         const int   level = psx_clampi(ex.lpos, 0, P->L - 1);
         const float SBP = fabsf(DESC_MAGNIFY * ex.sigma);
-        const float* plane = oc.data + (size_t)level * oc.plane;
+        const char* plane = reinterpret_cast<const char*>(oc.data + (size_t)level * oc.plane);
+        const unsigned pitch4 = (unsigned)oc.pitch * 4u;
 
         if (SBP != 0.0f) {
             const float cos_t = cosf(ang);
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
                 const float dyk = ii - y;
                 const float ub = fmaf(srsbp, dyk, 1.5f);      // u = crsbp*dx + srsbp*dy + 1.5
                 const float vb = fmaf(crsbp, dyk, 1.5f);      // v = crsbp*dy - srsbp*dx + 1.5
-                const float* prow = plane + (size_t)ii * oc.pitch;
+                const unsigned rowoff = (unsigned)ii * pitch4;
                 for (int tx = xmin; tx <= xmax; tx += 16) {
                     const int jj = tx + lx;
                     const float dxk = jj - x;
@@ -428,10 +452,15 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
                                     (u > -1.0f) && (u < 4.0f) && (v > -1.0f) && (v < 4.0f);
                     if (__ballot(in) == 0ull) continue;
                     if (in) {
-                        const float* p = prow + jj;
-                        const float gdx = p[1] - p[-1];
-                        const float gdy = p[oc.pitch] - p[-oc.pitch];
-                        const float mod = __fsqrt_rn(fmaf(gdx, gdx, gdy * gdy));
+                        // uniform plane base + 32-bit byte offset: global_load with scalar base
+                        const unsigned off = rowoff + (unsigned)jj * 4u;
+                        const float gxp = *(gfloat_p)(plane + off + 4u);
+                        const float gxm = *(gfloat_p)(plane + off - 4u);
+                        const float gyp = *(gfloat_p)(plane + (off + pitch4));
+                        const float gym = *(gfloat_p)(plane + (off - pitch4));
+                        const float gdx = gxp - gxm;
+                        const float gdy = gyp - gym;
+                        const float mod = __builtin_amdgcn_sqrtf(fmaf(gdx, gdx, gdy * gdy));
                         float th = fast_atan2(gdy, gdx) - ang;
                         th += (th <  0.0f  ? PI2_F : 0.0f);
                         th -= (th >= PI2_F ? PI2_F : 0.0f);
@@ -440,30 +469,28 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
                         const int   fo0  = (int)ffo;
                         const float wgt2 = tth - ffo;
                         const float wgt1 = 1.0f - wgt2;
-                        const int   fo   = fo0 & 7;
-                        const int   fo1  = (fo0 + 1) & 7;
+                        const unsigned fo  = (unsigned)(fo0 & 7) * 4u;
+                        const unsigned fo1 = (unsigned)((fo0 + 1) & 7) * 4u;
 
+                        // Gaussian window exp(-d^2/8) as one exp2; the fixed-point scale is folded in here
+                        // (a power of two commutes exactly with the products below)
                         const float un = u - 1.5f, vn = v - 1.5f;
-                        const float ww = __expf(-0.125f * fmaf(un, un, vn * vn)) * mod;
+                        const float ww = __builtin_amdgcn_exp2f(fmaf(un, un, vn * vn) * (-0.125f * 1.4426950408889634f))
+                                         * (mod * DFIX);
                         const float fu = floorf(u), fv = floorf(v);
-                        const int   ix0 = (int)fu, iy0 = (int)fv;
-                        const float ax1 = u - fu, ay1 = v - fv;      // weight of tile ix0+1 / iy0+1
+                        const int   ix0 = (int)fu, iy0 = (int)fv;        // -1..3
+                        const float ax1 = u - fu, ay1 = v - fv;          // weight of tile ix0+1 / iy0+1
                         const float ax0 = 1.0f - ax1, ay0 = 1.0f - ay1;
-#pragma unroll
-                        for (int dy = 0; dy < 2; dy++) {
-                            const int iy = iy0 + dy;
-                            if (iy < 0 || iy > 3) continue;
-                            const float wy = (dy ? ay1 : ay0) * ww;
-#pragma unroll
-                            for (int dx = 0; dx < 2; dx++) {
-                                const int ix = ix0 + dx;
-                                if (ix < 0 || ix > 3) continue;
-                                const float wgt = wy * (dx ? ax1 : ax0);
-                                fix64* tb = myacc + ((iy << 2) + ix) * 8;
-                                atomicAdd(&tb[fo],  to_fix(wgt1 * wgt));
-                                atomicAdd(&tb[fo1], to_fix(wgt2 * wgt));
-                            }
-                        }
+                        const float wy0 = ay0 * ww, wy1 = ay1 * ww;
+                        const float w00 = wy0 * ax0, w01 = wy0 * ax1, w10 = wy1 * ax0, w11 = wy1 * ax1;
+                        const unsigned tb = myacc + (unsigned)((iy0 + 1) * 5 + (ix0 + 1)) * 32u;
+                        unsigned LDS_AS* t0 = (unsigned LDS_AS*)(tb + fo);
+                        unsigned LDS_AS* t1 = (unsigned LDS_AS*)(tb + fo1);
+                        // tile (iy0, ix0), (iy0, ix0+1), (iy0+1, ix0), (iy0+1, ix0+1): +0, +8, +40, +48 entries
+                        lds_add(t0, (unsigned)fmaf(wgt1, w00, 0.5f)); lds_add(t1, (unsigned)fmaf(wgt2, w00, 0.5f));
+                        lds_add(t0 + 8, (unsigned)fmaf(wgt1, w01, 0.5f)); lds_add(t1 + 8, (unsigned)fmaf(wgt2, w01, 0.5f));
+                        lds_add(t0 + 40, (unsigned)fmaf(wgt1, w10, 0.5f)); lds_add(t1 + 40, (unsigned)fmaf(wgt2, w10, 0.5f));
+                        lds_add(t0 + 48, (unsigned)fmaf(wgt1, w11, 0.5f)); lds_add(t1 + 48, (unsigned)fmaf(wgt2, w11, 0.5f));
                     }
                 }
             }
@@ -471,13 +498,14 @@ __global__ __launch_bounds__(NT) void k_descriptors(const PsxParams* __restrict_
         wave_fence();
 
         // normalize_histogram (s_desc_norm_rs.h:42-77 / s_desc_norm_l2.h:86-135); lane owns 2 bins
-        fix64 sa = 0ull, sb = 0ull;
+        unsigned sa = 0u, sb = 0u;
+        const int rbin = (((lane >> 4) + 1) * 5 + ((lane >> 2) & 3) + 1) * 8 + (lane & 3) * 2;   // bins 2*lane, 2*lane+1
 #pragma unroll
         for (int c = 0; c < DCOPIES; c++) {
-            sa += acc[c * DSTRIDE + 2 * lane];
-            sb += acc[c * DSTRIDE + 2 * lane + 1];
+            sa += acc[c * DSTRIDE + rbin];
+            sb += acc[c * DSTRIDE + rbin + 1];
         }
-        float a = from_fix(sa), b = from_fix(sb);
+        float a = (float)sa * (1.0f / DFIX), b = (float)sb * (1.0f / DFIX);
         if (P->norm_mode == PSX_NORM_ROOTSIFT) {
             const float sum = wave_sum(a + b);
             a = ldexpf(sqrtf(a / sum), P->norm_multi);

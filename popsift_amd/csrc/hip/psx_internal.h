@@ -73,9 +73,12 @@ struct PsxCounters {
 struct PsxTaps { float g[PSX_GAUSS_ALIGN]; };
 
 // ---- host-side launch helpers implemented in the .hip files ---------------------------------
+// columns of the resampled input kept on each side of the plane (>= the largest filter halo, 32)
+#define PSX_LEVEL0_PAD 32
 struct PsxLevel0Args {
     const void* img; int w, h, is_float;
     float* dst; int W, H, pitch;
+    float* tmp; int tmp_pitch;    // resampled input: H rows of roundup(W,64) + 2*PSX_LEVEL0_PAD floats
     float shift;
     PsxTaps taps_h; int span_h;   // dd table, octave 0
     PsxTaps taps_v; int span_v;   // inc table, level 0

@@ -2,7 +2,7 @@
 //
 // Replaces (behaviour, not code) the reference's default build_pyramid branch
 // (s_pyramid_build.cu:547-575):
-//   normalizedSource::horiz + absoluteSource::vert (level 0 of octave 0)   -> k_level0
+//   normalizedSource::horiz + absoluteSource::vert (level 0 of octave 0)   -> k_upscale + k_blur<R,true>
 //   absoluteSource::horiz + absoluteSource::vert   (levels 1..L-1)         -> k_blur
 //   get_by_2_pick_every_second                                             -> fused into k_blur
 //                                                                             (k_downscale standalone)
@@ -47,60 +47,12 @@ struct BlurArgs {
     float*       dst;
     float*       half_dst;      // next octave level 0 (pick every second), or nullptr
     int W, H, pitch, half_pitch;
+    int src_pitch;              // floats per source row
+    int src_xoff, src_width;    // source column of output column 0; number of valid source columns
     int nstrips, chunk_rows;
-    PsxTaps taps;
+    PsxTaps taps;               // horizontal taps (and vertical, unless LEVEL0)
+    PsxTaps taps_v;             // LEVEL0 only: vertical taps
 };
-
-template <int R>
-struct Geom {
-    static constexpr int HALO = (R + 3) & ~3;
-    static constexpr int SW   = TW + 2 * HALO;     // staged row width (floats)
-    static constexpr int SW4  = SW / 4;
-    static constexpr int NLD  = (BR * SW4 + NT - 1) / NT;
-    static constexpr int RING = (BR + 2 * R <= 64) ? 64 : 128;
-    // LDS row stride of the staged rows: 96 or 160 floats, i.e. == 128 B (mod 256 B).  Together
-    // with the XOR swizzle below this makes the horizontal pass's ds_read_b128 conflict-free
-    // (checked against the gfx950 b128 lane groups, MI355X_MICROARCH.md "LDS").
-    static constexpr int SWA  = ((SW + 63) / 64) * 64 + 32;
-};
-
-// Staged rows are stored in 16-byte chunks; chunk c of row r lives at chunk (c ^ (r & 1)).
-__device__ __forceinline__ int stage_chunk(int row, int c4) { return c4 ^ (row & 1); }
-
-// Ring rows (64 H-filtered values) are stored permuted so that the horizontal pass writes two
-// conflict-free 128-byte runs per row: value of column col sits at ring_pos(col).
-__device__ __forceinline__ int ring_col_of_pos(int p) { return ((p & 31) >> 2) * 8 + (p & 3) + ((p >> 5) << 2); }
-
-// horizontal filter of 8 adjacent outputs from a register window; win[HALO+i] is the centre
-// of output i.
-template <int R, int HALO, bool LEVEL0>
-__device__ __forceinline__ void hfilter8(const float* win, const PsxTaps& tp, float* out)
-{
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int c = HALO + i;
-        float o = 0.0f;
-        if (!LEVEL0) o = fmaf(win[c], tp.g[0], o);
-#pragma unroll
-        for (int k = R; k >= 1; k--) o = fmaf(win[c - k] + win[c + k], tp.g[k], o);
-        if (LEVEL0) { o = fmaf(win[c], tp.g[0], o); o = o * 255.0f; }
-        out[i] = o;
-    }
-}
-
-// vertical filter: v[j] = T[r_out0 - R + j]; output i is centred on v[R + i]
-template <int R>
-__device__ __forceinline__ float vfilter(const float* v, int i, const PsxTaps& tp)
-{
-    float o = 0.0f;
-#pragma unroll
-    for (int k = R; k >= 1; k--) {
-        o = fmaf(v[R + i - k], tp.g[k], o);
-        o = fmaf(v[R + i + k], tp.g[k], o);
-    }
-    o = fmaf(v[R + i], tp.g[0], o);
-    return o;
-}
 
 // the same chain on two adjacent columns at once (v_pk_fma_f32): v[j] = (T[.][c], T[.][c+1])
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -110,19 +62,6 @@ __device__ __forceinline__ v2f pk_fma(v2f a, float g, v2f c)
 {
     return __builtin_elementwise_fma(a, (v2f){g, g}, c);
 }
-template <int R>
-__device__ __forceinline__ v2f vfilter2(const v2f* v, int i, const PsxTaps& tp)
-{
-    v2f o = {0.0f, 0.0f};
-#pragma unroll
-    for (int k = R; k >= 1; k--) {
-        o = pk_fma(v[R + i - k], tp.g[k], o);
-        o = pk_fma(v[R + i + k], tp.g[k], o);
-    }
-    o = pk_fma(v[R + i], tp.g[0], o);
-    return o;
-}
-
 #ifdef PSX_PHASE_TIMING
 __device__ long long* g_blur_dbg = nullptr;
 extern "C" void psx_debug_set_blur_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blur_dbg), &d, sizeof(d)); }
@@ -158,15 +97,21 @@ struct Geom2 {
 
 // k-major forms of the two filters: the per-output chains are the reference's, but the independent
 // chains advance together so that dependent v_pk_fma_f32 never issue back to back
-template <int R, int HALO>
+//   levels >= 1 (s_pyramid_build_aa.cu:17-50): centre, then pairs (x-k)+(x+k) from k=span-1 down to 1
+//   level 0 of octave 0 (s_pyramid_build_ra.cu:17-55): pairs outermost-in, then centre, then *255
+template <int R, int HALO, bool LEVEL0>
 __device__ __forceinline__ void hfilter8_km(const float* win, const PsxTaps& tp, float* out)
 {
 #pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = fmaf(win[HALO + i], tp.g[0], 0.0f);
+    for (int i = 0; i < 8; i++) out[i] = LEVEL0 ? 0.0f : fmaf(win[HALO + i], tp.g[0], 0.0f);
 #pragma unroll
     for (int k = R; k >= 1; k--) {
 #pragma unroll
         for (int i = 0; i < 8; i++) out[i] = fmaf(win[HALO + i - k] + win[HALO + i + k], tp.g[k], out[i]);
+    }
+    if (LEVEL0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { out[i] = fmaf(win[HALO + i], tp.g[0], out[i]); out[i] = out[i] * 255.0f; }
     }
 }
 template <int R>
@@ -185,7 +130,7 @@ __device__ __forceinline__ void vfilter2x4_km(const v2f* v, const PsxTaps& tp, v
     for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i], tp.g[0], o[i]);
 }
 
-template <int R>
+template <int R, bool LEVEL0>
 __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur(BlurArgs a)
 {
     using G = Geom2<R>;
@@ -203,7 +148,8 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
     const int Y0    = chunk * a.chunk_rows;
     const int Y1    = min(Y0 + a.chunk_rows, a.H);
     const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
-    const bool interior = (x0 - HALO >= 0) && (x0 + TW + HALO <= a.W);     // workgroup uniform
+    // workgroup uniform: every staged column exists in the source row (no clamping needed)
+    const bool interior = (x0 - HALO + a.src_xoff >= 0) && (x0 + TW + HALO + a.src_xoff <= a.src_width);
 
     // ---- staging geometry of this thread (step invariant) ----
     int st_row[NLD], st_x[NLD], st_lds[NLD];
@@ -212,7 +158,7 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
         const int idx = t + j * NT;
         const int row = idx / SW4, c4 = idx - row * SW4;
         st_row[j] = row;
-        st_x[j]   = x0 - HALO + c4 * 4;
+        st_x[j]   = x0 - HALO + c4 * 4 + a.src_xoff;
         st_lds[j] = row * SWA + c4 * 4;
     }
     const bool last_on = !LAST_PARTIAL || (t + (NLD - 1) * NT < BR * SW4);
@@ -253,15 +199,15 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
                 if (j < NLD - 1 || last_on) {
                     const int y = psx_clampi(ybase + st_row[j], 0, a.H - 1);
                     if (INTERIOR) {
-                        const unsigned off = (unsigned)(y * a.pitch + st_x[j]) * 4u;
+                        const unsigned off = (unsigned)(y * a.src_pitch + st_x[j]) * 4u;
                         pre[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.src) + off);
                     } else {
-                        const float* rp = a.src + (size_t)y * a.pitch;
+                        const float* rp = a.src + (size_t)y * a.src_pitch;
                         const int x = st_x[j];
-                        pre[j].x = rp[psx_clampi(x + 0, 0, a.W - 1)];
-                        pre[j].y = rp[psx_clampi(x + 1, 0, a.W - 1)];
-                        pre[j].z = rp[psx_clampi(x + 2, 0, a.W - 1)];
-                        pre[j].w = rp[psx_clampi(x + 3, 0, a.W - 1)];
+                        pre[j].x = rp[psx_clampi(x + 0, 0, a.src_width - 1)];
+                        pre[j].y = rp[psx_clampi(x + 1, 0, a.src_width - 1)];
+                        pre[j].z = rp[psx_clampi(x + 2, 0, a.src_width - 1)];
+                        pre[j].w = rp[psx_clampi(x + 3, 0, a.src_width - 1)];
                     }
                 }
             }
@@ -291,7 +237,7 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
                     win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
                 }
                 float out[8];
-                hfilter8_km<R, HALO>(win, a.taps, out);
+                hfilter8_km<R, HALO, LEVEL0>(win, a.taps, out);
                 const int slot = (k * BR + h_row) & (RING - 1);
                 float* rp = &s_ring[slot * RS + h_seg * 8];
                 reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
@@ -316,7 +262,7 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
                     // volatile: plain ds_read_b64 (256 B/clk); merged ds_read2_b64 runs at half that rate
                     for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
                     v2f o[4];
-                    vfilter2x4_km<R>(v, a.taps, o);
+                    vfilter2x4_km<R>(v, LEVEL0 ? a.taps_v : a.taps, o);
                     // pin the four results here: otherwise each chain is sunk into its own predicated
                     // store block and runs alone, dependent v_pk_fma_f32 back to back
                     asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
@@ -348,26 +294,20 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
 }
 
 // ---------------------------------------------------------------------------------------------
-// Octave 0, level 0: resample the input image (software model of the reference's normalised,
-// clamped, bilinear texture, s_image.cu:138-167) + horizontal "dd" filter + x255 + vertical "inc"
-// filter.  U(X, y) = tex2D at the coordinate of output column X; tap k of output x reads U(x-k),
-// U(x+k)  (DESIGN.md "octave 0").
+// Octave 0, level 0: the reference filters a normalised, clamped, bilinear texture of the input image
+// (s_image.cu:138-167, s_pyramid_build_ra.cu).  Tap k of output (x, y) reads U(x-k, y) and U(x+k, y)
+// with U(X, y) = tex2D at the coordinates of output column X, row y (DESIGN.md "octave 0").  k_upscale
+// materialises U once (software model of the texture unit: unnormalise, -0.5, 1.8 fixed-point weight,
+// clamped texels, u8 -> v/255), with `pad` extra columns on both sides because U(X) for X outside
+// [0, W) is defined by clamping TEXELS, not columns; k_blur<R, true> then runs the "dd" horizontal /
+// "inc" vertical filters over it like over any other level.
 // ---------------------------------------------------------------------------------------------
-struct Level0Dev {
+struct UpArgs {
     const void* img; int w, h, is_float;
-    float* dst; int W, H, pitch;
+    float* dst; int W, H, pitch, pad, ncol4;
     float shift;
-    int nstrips, chunk_rows;
-    PsxTaps taps_h, taps_v;
 };
 
-__device__ __forceinline__ float l0_texel(const Level0Dev& a, int i, int j)
-{
-    i = psx_clampi(i, 0, a.w - 1);
-    j = psx_clampi(j, 0, a.h - 1);
-    if (a.is_float) return static_cast<const float*>(a.img)[(size_t)j * a.w + i];
-    return (float)static_cast<const uint8_t*>(a.img)[(size_t)j * a.w + i] / 255.0f;
-}
 __device__ __forceinline__ void l0_axis(float cn, int size, int& i0, float& al)
 {
     const float tcoord = cn * (float)size;
@@ -380,200 +320,76 @@ __device__ __forceinline__ void l0_axis(float cn, int size, int& i0, float& al)
 }
 __device__ __forceinline__ float l0_lerp(float p, float q, float a) { return fmaf(a, q, (1.0f - a) * p); }
 
-template <int R>
-__global__ __launch_bounds__(NT) void k_level0(Level0Dev a)
+// u8 texel -> v/255 (cudaReadModeNormalizedFloat), correctly rounded without a division: one
+// Newton correction of q * fl(1/255) reproduces fl(q / 255) for all 256 inputs (checked exhaustively
+// by tests/test_gpu_parity.py::test_u8_normalisation_exact through a ramp image).
+__device__ __forceinline__ float l0_unorm8(unsigned q)
 {
-    using G = Geom<R>;
-    constexpr int HALO = G::HALO, SW = G::SW, RING = G::RING, SWA = G::SWA;
-    __shared__ __attribute__((aligned(16))) float s_stage[BR * SWA];
-    __shared__ __attribute__((aligned(16))) float s_ring[RING * TW];
-    __shared__ float s_lut[256];      // u8 texel -> v/255 (cudaReadModeNormalizedFloat)
-    __shared__ int   s_ci[SW];        // per staged column: left texel index and 1.8 weight
-    __shared__ float s_ca[SW];
-    __shared__ int   s_rj[2 * BR];    // per staged row (double buffered)
-    __shared__ float s_rb[2 * BR];
-    constexpr int TEXW = 56, TEXH = 24;    // input-texel footprint of one step (covers upscale >= 1; else direct loads)
-    __shared__ float s_tex[TEXH * TEXW];
+    const float c = 1.0f / 255.0f;
+    const float f = (float)q;
+    const float r = f * c;
+    const float e = fmaf(-255.0f, r, f);
+    return fmaf(e, c, r);
+}
 
-    const int t     = threadIdx.x;
-    const int lid   = xcd_remap(blockIdx.x, gridDim.x);
-    const int strip = lid % a.nstrips;
-    const int chunk = lid / a.nstrips;
-    const int x0    = strip * TW;
-    const int Y0    = chunk * a.chunk_rows;
-    const int Y1    = min(Y0 + a.chunk_rows, a.H);
-    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
-
-    s_lut[t] = (float)t / 255.0f;
-    if (t < SW) {
-        int i0; float al;
-        l0_axis(((float)(x0 - HALO + t) + a.shift) / (float)a.W, a.w, i0, al);
-        s_ci[t] = i0; s_ca[t] = al;
+__global__ __launch_bounds__(256) void k_upscale(UpArgs a)
+{
+    const int t = threadIdx.x;
+    const int cq = blockIdx.x * 64 + (t & 63);
+    const int y  = blockIdx.y * 4 + (t >> 6);
+    if (cq >= a.ncol4 || y >= a.H) return;
+    int j0; float be;
+    l0_axis(((float)y + a.shift) / (float)a.H, a.h, j0, be);
+    const int ja = psx_clampi(j0, 0, a.h - 1), jb = psx_clampi(j0 + 1, 0, a.h - 1);
+    int ia[4], ib[4]; float al[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        int i0;
+        l0_axis(((float)(cq * 4 + e - a.pad) + a.shift) / (float)a.W, a.w, i0, al[e]);
+        ia[e] = psx_clampi(i0, 0, a.w - 1); ib[e] = psx_clampi(i0 + 1, 0, a.w - 1);
     }
-    // row tables are double buffered: the table of step k+1 is built during step k so that the
-    // texel loads of step k+1 can be issued a whole step ahead (software prefetch into registers)
-    auto build_rows = [&](int k) {
-        if (t < BR) {
-            const int y = psx_clampi(Y0 - R + k * BR + t, 0, a.H - 1);
-            int j0; float be;
-            l0_axis(((float)y + a.shift) / (float)a.H, a.h, j0, be);
-            s_rj[(k & 1) * BR + t] = j0; s_rb[(k & 1) * BR + t] = be;
-        }
-    };
-    constexpr int NTEX = (TEXH * 64 + NT - 1) / NT;          // texel loads per thread (64-wide rows)
-    float treg[NTEX];
-    int jlo = 0, ilo = 0, nrows = 0, ncols = 0;
-    bool via_lds = false;
-    auto footprint = [&](int k) {
-        const int* rj = &s_rj[(k & 1) * BR];
-        jlo = psx_clampi(rj[0], 0, a.h - 1);
-        const int jhi = psx_clampi(rj[BR - 1] + 1, 0, a.h - 1);
-        ilo = psx_clampi(s_ci[0], 0, a.w - 1);
-        const int ihi = psx_clampi(s_ci[SW - 1] + 1, 0, a.w - 1);
-        nrows = jhi - jlo + 1; ncols = ihi - ilo + 1;
-        via_lds = (nrows <= TEXH && ncols <= TEXW);             // uniform over the workgroup
-    };
-    auto issue_texels = [&]() {
-        if (!via_lds) return;
-        const int ic = t & 63;
+    float p00[4], p10[4], p01[4], p11[4];
+    if (a.is_float) {
+        const float* ra = static_cast<const float*>(a.img) + (size_t)ja * a.w;
+        const float* rb = static_cast<const float*>(a.img) + (size_t)jb * a.w;
 #pragma unroll
-        for (int q = 0; q < NTEX; q++) {
-            const int jr = (t >> 6) + q * (NT / 64);
-            treg[q] = 0.0f;
-            if (jr < nrows && ic < ncols) {
-                const size_t g = (size_t)(jlo + jr) * a.w + (ilo + ic);
-                treg[q] = a.is_float ? static_cast<const float*>(a.img)[g]
-                                     : (float)static_cast<const uint8_t*>(a.img)[g];    // LUT applied at commit
+        for (int e = 0; e < 4; e++) { p00[e] = ra[ia[e]]; p10[e] = ra[ib[e]]; p01[e] = rb[ia[e]]; p11[e] = rb[ib[e]]; }
+    } else {
+        const uint8_t* ra = static_cast<const uint8_t*>(a.img) + (size_t)ja * a.w;
+        const uint8_t* rb = static_cast<const uint8_t*>(a.img) + (size_t)jb * a.w;
+        // the 8 texel columns of 4 adjacent outputs normally lie within 4 consecutive texels (any
+        // upscale >= 1): fetch them as one unaligned dword per texel row instead of 16 byte loads
+        const int base = min(ia[0], max(a.w - 4, 0));
+        unsigned q00[4], q10[4], q01[4], q11[4];
+        if (a.w >= 4 && ib[3] - base <= 3) {
+            unsigned wa, wb;
+            __builtin_memcpy(&wa, ra + base, 4);
+            __builtin_memcpy(&wb, rb + base, 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int sa = (ia[e] - base) * 8, sb = (ib[e] - base) * 8;
+                q00[e] = (wa >> sa) & 0xffu; q10[e] = (wa >> sb) & 0xffu;
+                q01[e] = (wb >> sa) & 0xffu; q11[e] = (wb >> sb) & 0xffu;
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { q00[e] = ra[ia[e]]; q10[e] = ra[ib[e]]; q01[e] = rb[ia[e]]; q11[e] = rb[ib[e]]; }
         }
-    };
-
-#ifdef PSX_PHASE_TIMING
-    long long tacc[5] = {0, 0, 0, 0, 0};
-    long long tprev = clock64();
-    const long long tstart = tprev;
-#endif
-    build_rows(0);
-    __syncthreads();
-    footprint(0);
-    issue_texels();
-
-    for (int k = 0; k < nsteps; k++) {
-        // commit the prefetched texels of this step (previous U staging has passed two barriers)
-        if (via_lds) {
-            const int ic = t & 63;
 #pragma unroll
-            for (int q = 0; q < NTEX; q++) {
-                const int jr = (t >> 6) + q * (NT / 64);
-                if (jr < nrows && ic < ncols)
-                    s_tex[jr * TEXW + ic] = a.is_float ? treg[q] : s_lut[(int)treg[q]];
-            }
+        for (int e = 0; e < 4; e++) {
+            p00[e] = l0_unorm8(q00[e]); p10[e] = l0_unorm8(q10[e]);
+            p01[e] = l0_unorm8(q01[e]); p11[e] = l0_unorm8(q11[e]);
         }
-        const int cjlo = jlo, cilo = ilo;
-        const bool cvia = via_lds;
-        if (k + 1 < nsteps) build_rows(k + 1);
-        BSTAMP(0);
-        __syncthreads();   // texels + next row table visible; previous H pass finished reading s_stage
-        BSTAMP(1);
-        if (k + 1 < nsteps) { footprint(k + 1); issue_texels(); }
-        const int* rjk = &s_rj[(k & 1) * BR];
-        const float* rbk = &s_rb[(k & 1) * BR];
-        // U(X, y) = lerp_y( lerp_x(T[j0]), lerp_x(T[j0+1]) ): same operations, same order as the texture
-        // model of the oracle
-        // All LDS / global reads of a thread's elements are issued before the first lerp: the loops are
-        // fully unrolled with a static trip count, and the (workgroup-uniform) source selection is
-        // hoisted OUTSIDE them -- a per-element select makes hipcc branch and wait per element.
-        {
-            constexpr int NPT = (BR * SW + NT - 1) / NT;
-            auto stage_elems = [&](auto mode) {
-                constexpr int MODE = decltype(mode)::value;     // 0: LDS texels, 1: float image, 2: u8 image
-                float t00[NPT], t10[NPT], t01[NPT], t11[NPT], al[NPT], be[NPT];
-#pragma unroll
-                for (int q = 0; q < NPT; q++) {
-                    const int idx = min(t + q * NT, BR * SW - 1);
-                    const int row = idx / SW, c = idx - row * SW;
-                    const int i0 = s_ci[c], j0 = rjk[row];
-                    al[q] = s_ca[c]; be[q] = rbk[row];
-                    const int ia = psx_clampi(i0, 0, a.w - 1), ib = psx_clampi(i0 + 1, 0, a.w - 1);
-                    const int ja = psx_clampi(j0, 0, a.h - 1), jb = psx_clampi(j0 + 1, 0, a.h - 1);
-                    if (MODE == 0) {
-                        const float* ra = &s_tex[(ja - cjlo) * TEXW - cilo];
-                        const float* rb = &s_tex[(jb - cjlo) * TEXW - cilo];
-                        t00[q] = ra[ia]; t10[q] = ra[ib]; t01[q] = rb[ia]; t11[q] = rb[ib];
-                    } else if (MODE == 1) {
-                        const float* f = static_cast<const float*>(a.img);
-                        t00[q] = f[(size_t)ja * a.w + ia]; t10[q] = f[(size_t)ja * a.w + ib];
-                        t01[q] = f[(size_t)jb * a.w + ia]; t11[q] = f[(size_t)jb * a.w + ib];
-                    } else {
-                        const uint8_t* b = static_cast<const uint8_t*>(a.img);
-                        t00[q] = (float)b[(size_t)ja * a.w + ia]; t10[q] = (float)b[(size_t)ja * a.w + ib];
-                        t01[q] = (float)b[(size_t)jb * a.w + ia]; t11[q] = (float)b[(size_t)jb * a.w + ib];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < NPT; q++) {
-                    const int idx = t + q * NT;
-                    if (idx < BR * SW) {
-                        const int row = idx / SW, c = idx - row * SW;
-                        float p00 = t00[q], p10 = t10[q], p01 = t01[q], p11 = t11[q];
-                        if (MODE == 2) { p00 = s_lut[(int)p00]; p10 = s_lut[(int)p10]; p01 = s_lut[(int)p01]; p11 = s_lut[(int)p11]; }
-                        const float r0 = l0_lerp(p00, p10, al[q]);
-                        const float r1 = l0_lerp(p01, p11, al[q]);
-                        s_stage[row * SWA + stage_chunk(row, c >> 2) * 4 + (c & 3)] = l0_lerp(r0, r1, be[q]);
-                    }
-                }
-            };
-            if (cvia) stage_elems(std::integral_constant<int, 0>{});
-            else if (a.is_float) stage_elems(std::integral_constant<int, 1>{});
-            else stage_elems(std::integral_constant<int, 2>{});
-        }
-        BSTAMP(2);
-        __syncthreads();
-        {
-            const int row = t >> 3, seg = t & 7;
-            float win[8 + 2 * HALO];
-            const float4* sp = reinterpret_cast<const float4*>(&s_stage[row * SWA]);
-#pragma unroll
-            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
-                const float4 v = sp[stage_chunk(row, seg * 2 + q)];
-                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
-            }
-            float out[8];
-            hfilter8<R, HALO, true>(win, a.taps_h, out);
-            const int slot = (k * BR + row) & (RING - 1);
-            float4* rp = reinterpret_cast<float4*>(&s_ring[slot * TW + seg * 4]);
-            rp[0] = make_float4(out[0], out[1], out[2], out[3]);
-            rp[8] = make_float4(out[4], out[5], out[6], out[7]);
-        }
-        BSTAMP(3);
-        __syncthreads();
-        {
-            const int pos = t & (TW - 1), rg = t >> 6;
-            const int col = ring_col_of_pos(pos);
-            const int rel0 = k * BR - 2 * R + rg * 8;
-            const int r_out0 = Y0 + rel0;
-            if (r_out0 + 7 >= Y0 && r_out0 < Y1) {
-                float v[8 + 2 * R];
-#pragma unroll
-                for (int j = 0; j < 8 + 2 * R; j++) v[j] = s_ring[((rel0 + j) & (RING - 1)) * TW + pos];
-                const int x = x0 + col;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int r_out = r_out0 + i;
-                    const float o = vfilter<R>(v, i, a.taps_v);
-                    if (r_out >= Y0 && r_out < Y1 && x < a.W) a.dst[(size_t)r_out * a.pitch + x] = o;
-                }
-            }
-        }
-        BSTAMP(4);
     }
-#ifdef PSX_PHASE_TIMING
-    if (threadIdx.x == 0 && g_blur_dbg) {
-        long long* d_ = g_blur_dbg + 1100 * 8;     // level-0 region of the debug buffer
-        for (int q = 0; q < 5; q++) d_[blockIdx.x * 8 + q] = tacc[q];
-        d_[blockIdx.x * 8 + 5] = clock64() - tstart; d_[blockIdx.x * 8 + 6] = nsteps;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        // lerp_y( lerp_x(T[j0]), lerp_x(T[j0+1]) ): same operations, same order as the oracle's texture model
+        const float r0 = l0_lerp(p00[e], p10[e], al[e]);
+        const float r1 = l0_lerp(p01[e], p11[e], al[e]);
+        o[e] = l0_lerp(r0, r1, be);
     }
-#endif
+    *reinterpret_cast<float4*>(a.dst + (size_t)y * a.pitch + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // get_by_2_pick_every_second (s_pyramid_build.cu:50-71), used only when the fused path is off
@@ -622,26 +438,37 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
     BlurArgs a;
     a.src = src; a.dst = dst; a.half_dst = half_dst;
     a.W = W; a.H = H; a.pitch = pitch; a.half_pitch = half_pitch;
+    a.src_pitch = pitch; a.src_xoff = 0; a.src_width = W;
     a.nstrips = (W + TW - 1) / TW;
     int nchunks;
     chunking(W, H, R, a.chunk_rows, nchunks);
-    a.taps = taps;
-    hipLaunchKernelGGL(k_blur<R>, dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
+    a.taps = taps; a.taps_v = taps;
+    hipLaunchKernelGGL((k_blur<R, false>), dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
 
 template <int R>
 hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
 {
-    Level0Dev a;
-    a.img = h.img; a.w = h.w; a.h = h.h; a.is_float = h.is_float;
-    a.dst = h.dst; a.W = h.W; a.H = h.H; a.pitch = h.pitch;
-    a.shift = h.shift;
+    const int pad = PSX_LEVEL0_PAD;
+    const int wr = ((h.W + TW - 1) / TW) * TW;           // every strip reads full-width source rows
+    UpArgs u;
+    u.img = h.img; u.w = h.w; u.h = h.h; u.is_float = h.is_float;
+    u.dst = h.tmp; u.W = h.W; u.H = h.H; u.pitch = h.tmp_pitch; u.pad = pad; u.ncol4 = (wr + 2 * pad) / 4;
+    u.shift = h.shift;
+    hipLaunchKernelGGL(k_upscale, dim3((u.ncol4 + 63) / 64, (h.H + 3) / 4), dim3(256), 0, s, u);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+
+    BlurArgs a;
+    a.src = h.tmp; a.dst = h.dst; a.half_dst = nullptr;
+    a.W = h.W; a.H = h.H; a.pitch = h.pitch; a.half_pitch = 0;
+    a.src_pitch = h.tmp_pitch; a.src_xoff = pad; a.src_width = wr + 2 * pad;
     a.nstrips = (h.W + TW - 1) / TW;
     int nchunks;
     chunking(h.W, h.H, R, a.chunk_rows, nchunks);
-    a.taps_h = h.taps_h; a.taps_v = h.taps_v;
-    hipLaunchKernelGGL(k_level0<R>, dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
+    a.taps = h.taps_h; a.taps_v = h.taps_v;
+    hipLaunchKernelGGL((k_blur<R, true>), dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
 

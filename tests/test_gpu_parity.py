@@ -61,6 +61,23 @@ def test_pyramid_float_input(oracle, capi):
     ctx.close()
 
 
+def test_u8_normalisation_exact(oracle, capi):
+    """Every u8 value 0..255 goes through the device's division-free v/255 (pyramid.hip l0_unorm8); level 0
+    must stay bit-identical to the oracle, with and without upsampling."""
+    img = (np.arange(96 * 80, dtype=np.int64) * 37 % 256).astype(np.uint8).reshape(80, 96)
+    assert len(np.unique(img)) == 256
+    for up in (1.0, 0.0):
+        kw = dict(octaves=2, upscale_factor=up)
+        ocfg, gcfg = _cfgs(oracle, capi, kw)
+        ref = oracle.run_pyramid(ocfg, img)
+        ctx = capi.Context(gcfg)
+        ctx.upload(img)
+        ctx.build_pyramid()
+        for l in range(ref.num_levels):
+            assert np.array_equal(ctx.dump_plane(capi.PLANE_GAUSS, 0, l), ref.gauss(0, l)), (up, l)
+        ctx.close()
+
+
 @pytest.mark.parametrize("w,h,seed,kw", CASES)
 def test_extrema_sets(oracle, capi, w, h, seed, kw):
     img = synth(w, h, seed)
