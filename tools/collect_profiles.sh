@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- tools/collect_profiles.sh): regenerates the rocprofv3 evidence that is
+# copied into profiles/.  Counter passes are separate runs with --kernel-trace only (gpurun refuses --pmc
+# combined with the sys/hip/hsa trace domains).
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p1 /tmp/p2 /tmp/p3 /tmp/p4
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -o s -- python $R/tools/single_stream.py 20 > $OUT/single.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p3 -o f -- python $R/tools/single_stream.py 3 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p4 -o w -- python $R/tools/single_stream.py 3 > $OUT/pmc_write.log 2>&1
+cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+cp $(find /tmp/p2 -name "*kernel_stats.csv" | head -1) $OUT/single_stream_kernel_stats.csv
+python $R/tools/profiles_summarize.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) $(find /tmp/p2 -name "*kernel_trace.csv" | head -1) \
+       $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $(find /tmp/p4 -name "*counter_collection.csv" | head -1) $OUT
+ls -la $OUT
