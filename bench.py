@@ -176,21 +176,26 @@ def main():
             tot_bytes += by
             nl += 1
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9     # GB/s, algorithmic 8 B/pixel
-        # what the memory system delivers for "read a plane, write a plane" on this box: a device copy of
-        # one octave-0 plane (torch is only the memcpy + event timer here)
+        # what the memory system delivers on this box (torch is only the memcpy + event timer here):
+        #   measured_copy       a 1 GiB -> 1 GiB device copy (the "measured HBM roofline"; the
+        #                       working set is far beyond the 256 MB Infinity Cache)
+        #   measured_copy_plane a copy of one octave-0 plane (33 MB), i.e. what "read a plane, write a
+        #                       plane" costs with the plane sizes k_blur actually works on
+        def copy_rate(nfloats, reps):
+            src_t = torch.rand(nfloats, device=dev)
+            dst_t = torch.empty_like(src_t)
+            for _ in range(3):
+                dst_t.copy_(src_t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                dst_t.copy_(src_t)
+            e1.record()
+            torch.cuda.synchronize()
+            return 2.0 * nfloats * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
         pw, ph = c0.octave_dims(0)
-        src_t = torch.rand(ph, pw, device=dev)
-        dst_t = torch.empty_like(src_t)
-        for _ in range(5):
-            dst_t.copy_(src_t)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            dst_t.copy_(src_t)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2.0 * pw * ph * 4 * 50 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del src_t, dst_t
+        copy_gbs = copy_rate(1 << 28, 10)
+        copy_plane_gbs = copy_rate(pw * ph, 50)
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
         # and --pmc WRITE_SIZE in separate runs, 2x FETCH_SIZE correction); null when not collected
         traffic = None
@@ -203,7 +208,8 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "avg_launch_ms": round(tot_ms / nl, 5), "bytes_per_launch": tot_bytes / nl,
                     "traffic": traffic,
-                    "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
+                    "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+                    "measured_copy_plane": round(copy_plane_gbs, 1)}
 
         # per-stage device time of one frame (HIP events on the context's stream)
         c0.enable_timers(True)
