@@ -207,7 +207,19 @@ int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float
  * (features as psx_feature records, descriptors, descriptor->extremum map). */
 int psx_dev_alloc(int device, size_t bytes, void** out);
 int psx_dev_free(int device, void* ptr);
+/* synchronous device -> host copy of a buffer obtained from psx_dev_alloc / psx_clone_results */
+int psx_dev_read(int device, void* host_dst, const void* dev_src, size_t bytes);
 int psx_clone_results(psx_ctx* ctx, void* d_features, void* d_descriptors, int* d_reverse_map);
+
+/* FeaturesDev::match (features.cu:160-304, compute_distance / l2_in_t0): brute-force 2-nearest
+ * neighbours of every left descriptor among the right ones, squared L2 distance evaluated with the
+ * reference's operation tree, right side scanned in index order with strict '<' (ties keep the earlier
+ * index).  d_left / d_right: DEVICE pointers to l_len / r_len descriptors of 128 floats (e.g.
+ * psx_device_results / psx_clone_results).  host_match[3*i..3*i+2] = {best, second, accept} with
+ * accept = (d_best / d_second < 0.8f), the int3 match_matrix of the reference; host_dist (may be NULL)
+ * [2*i..2*i+1] = the two squared distances (what show_distance prints).  Synchronous. */
+int psx_match(int device, const float* d_left, int l_len, const float* d_right, int r_len,
+              int* host_match, float* host_dist);
 
 /* device_prop_t (common/device_prop.h:23-108): enumeration only; there are no texture limits. */
 int psx_device_count(int* count);

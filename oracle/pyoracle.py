@@ -101,6 +101,8 @@ def lib():
             f.argtypes = [C.c_void_p]
             f.restype = C.c_void_p
         L.osift_set_threads.argtypes = [C.c_int]
+        L.osift_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.osift_match.restype = None
         _LIB = L
     return _LIB
 
@@ -229,3 +231,15 @@ def run_pyramid(cfg, img, threads=0):
     img, w, h, is_float = _img_args(img)
     lib().osift_set_threads(threads if threads > 0 else default_threads())
     return Result(lib().osift_run_pyramid(C.byref(cfg), img.ctypes.data_as(C.c_void_p), w, h, is_float))
+
+
+def match(left, right, threads=0):
+    """osift_match: (n,3) int32 {best, second, accept} and (n,2) float32 squared distances."""
+    left = np.ascontiguousarray(left, dtype=np.float32).reshape(-1, 128)
+    right = np.ascontiguousarray(right, dtype=np.float32).reshape(-1, 128)
+    lib().osift_set_threads(threads if threads > 0 else default_threads())
+    mm = np.zeros((len(left), 3), np.int32)
+    dd = np.zeros((len(left), 2), np.float32)
+    lib().osift_match(left.ctypes.data_as(C.c_void_p), len(left), right.ctypes.data_as(C.c_void_p), len(right),
+                      mm.ctypes.data_as(C.c_void_p), dd.ctypes.data_as(C.c_void_p))
+    return mm, dd

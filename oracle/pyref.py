@@ -104,3 +104,19 @@ def run(cfg, img, api=False):
     img, w, h, is_float = po._img_args(img)
     f = lib().ref_run_api if api else lib().ref_run
     return Result(f(C.byref(cfg), img.ctypes.data_as(C.c_void_p), w, h, is_float))
+
+
+def match(left, right):
+    """The reference's FeaturesDev::match (its own features.cu on the CUDA emulation); results parsed
+    from what it prints.  Returns (n,3) int32 {best, second, accept} and (n,2) float32 printed distances."""
+    left = np.ascontiguousarray(left, dtype=np.float32).reshape(-1, 128)
+    right = np.ascontiguousarray(right, dtype=np.float32).reshape(-1, 128)
+    L = lib()
+    L.ref_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    mm = np.full((len(left), 3), -1, np.int32)
+    dd = np.zeros((len(left), 2), np.float32)
+    n = L.ref_match(left.ctypes.data_as(C.c_void_p), len(left), right.ctypes.data_as(C.c_void_p), len(right),
+                    mm.ctypes.data_as(C.c_void_p), dd.ctypes.data_as(C.c_void_p))
+    if n != len(left):
+        raise RuntimeError("ref_match parsed %d of %d lines" % (n, len(left)))
+    return mm, dd

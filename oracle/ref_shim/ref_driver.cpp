@@ -16,6 +16,9 @@
 #include "../sift_oracle.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
 #include <cstring>
 #include <vector>
 
@@ -190,5 +193,51 @@ int ref_ext_total(void* h) { return static_cast<RefResult*>(h)->ext_total; }
 int ref_ori_total(void* h) { return static_cast<RefResult*>(h)->ori_total; }
 const osift_feature* ref_features(void* h) { return static_cast<RefResult*>(h)->feat.data(); }
 const float* ref_descriptors(void* h) { return static_cast<RefResult*>(h)->desc.data(); }
+
+
+// FeaturesDev::match of the reference (features.cu:270-304).  It only PRINTS its result (device printf in
+// show_distance), so stdout is redirected into a temporary file around the call and the lines are parsed:
+//   "<accept|reject> feat %4d [%4d] matches feat %4d [%4d] ( 2nd feat %4d [%4d] ) dist %.3f vs %.3f"
+// out3[3i..] = {best, second, accept}; dist2[2i..] = the two printed distances (3 decimals).
+int ref_match(const float* l, int nl, const float* r, int nr, int* out3, float* dist2)
+{
+    FeaturesDev lf(nl, nl), rf(nr, nr);
+    cudaMemcpy(lf.getDescriptors(), l, (size_t)nl * 128 * sizeof(float), cudaMemcpyHostToDevice);
+    cudaMemcpy(rf.getDescriptors(), r, (size_t)nr * 128 * sizeof(float), cudaMemcpyHostToDevice);
+    std::vector<int> idl(nl), idr(nr);
+    for (int i = 0; i < nl; i++) idl[i] = i;
+    for (int i = 0; i < nr; i++) idr[i] = i;
+    cudaMemcpy(lf.getReverseMap(), idl.data(), (size_t)nl * sizeof(int), cudaMemcpyHostToDevice);
+    cudaMemcpy(rf.getReverseMap(), idr.data(), (size_t)nr * sizeof(int), cudaMemcpyHostToDevice);
+
+    char path[] = "/tmp/ref_match_XXXXXX";
+    const int fd = mkstemp(path);
+    if (fd < 0) return -1;
+    fflush(stdout);
+    const int saved = dup(1);
+    dup2(fd, 1);
+    lf.match(&rf);
+    fflush(stdout);
+    dup2(saved, 1);
+    close(saved);
+    close(fd);
+
+    FILE* f = fopen(path, "r");
+    if (!f) return -2;
+    char line[512];
+    int n = 0;
+    while (fgets(line, sizeof(line), f)) {
+        char verdict[16]; int lfeat, li, rfeat1, m1, rfeat2, m2; float d1, d2;
+        if (sscanf(line, "%15s feat %d [%d] matches feat %d [%d] ( 2nd feat %d [%d] ) dist %f vs %f",
+                   verdict, &lfeat, &li, &rfeat1, &m1, &rfeat2, &m2, &d1, &d2) == 9 && li >= 0 && li < nl) {
+            out3[3 * li + 0] = m1; out3[3 * li + 1] = m2; out3[3 * li + 2] = (strcmp(verdict, "accept") == 0);
+            if (dist2) { dist2[2 * li + 0] = d1; dist2[2 * li + 1] = d2; }
+            n++;
+        }
+    }
+    fclose(f);
+    remove(path);
+    return n;
+}
 
 } // extern "C"

@@ -1165,3 +1165,42 @@ osift_result* osift_run(const osift_config* c, const void* img, int w, int h, in
 { return run_impl(c, img, w, h, is_float, 1); }
 osift_result* osift_run_pyramid(const osift_config* c, const void* img, int w, int h, int is_float)
 { return run_impl(c, img, w, h, is_float, 0); }
+
+/* ------------------------------------------------------------------------- */
+/* 2-NN matcher (features.cu:160-225)                                         */
+/* ------------------------------------------------------------------------- */
+static float match_l2(const float* l, const float* r)
+{
+    float p[32];
+    for (int t = 0; t < 32; t++) {                 /* l2_in_t0, one CUDA thread each (:160-176) */
+        const float x = l[4 * t + 0] - r[4 * t + 0];
+        const float y = l[4 * t + 1] - r[4 * t + 1];
+        const float z = l[4 * t + 2] - r[4 * t + 2];
+        const float w = l[4 * t + 3] - r[4 * t + 3];
+        float s = y * y;
+        s = fmaf(x, x, s);
+        s = fmaf(z, z, s);
+        s = fmaf(w, w, s);
+        p[t] = s;
+    }
+    /* shuffle_down 16, 8, 4, 2, 1 (:177-181): value of lane 0 */
+    for (int off = 16; off >= 1; off >>= 1)
+        for (int t = 0; t < off; t++) p[t] = p[t] + p[t + off];
+    return p[0];
+}
+
+void osift_match(const float* l, int nl, const float* r, int nr, int* out3, float* dist2)
+{
+    #pragma omp parallel for schedule(static)
+    for (int i = 0; i < nl; i++) {
+        float v1 = INFINITY, v2 = INFINITY;        /* compute_distance, :183-223 */
+        int i1 = 0, i2 = 0;
+        for (int j = 0; j < nr; j++) {
+            const float res = match_l2(l + (size_t)i * 128, r + (size_t)j * 128);
+            if (res < v1) { v2 = v1; i2 = i1; v1 = res; i1 = j; }
+            else if (res < v2) { v2 = res; i2 = j; }
+        }
+        out3[3 * i + 0] = i1; out3[3 * i + 1] = i2; out3[3 * i + 2] = (v1 / v2 < 0.8f) ? 1 : 0;
+        if (dist2) { dist2[2 * i + 0] = v1; dist2[2 * i + 1] = v2; }
+    }
+}

@@ -19,6 +19,7 @@
  *   normalisation           s_desc_norm_rs.h:42-77, s_desc_norm_l2.h:86-135
  *   output mapping          sift_pyramid.cu:250-280
  *   grid filter             s_filtergrid.cu:36-325
+ *   2-NN matcher            features.cu:160-225 (osift_match)
  *
  * PARITY PIN STATUS: PINNED.  The reference ships no golden vectors of its own (its goldens are
  * an external reference.tgz fetched by wget, testScripts/downloadOxfordDataset.sh.in:4-9), so
@@ -145,6 +146,14 @@ const int*           osift_feat_to_ext(const osift_result* r);   /* ori_total */
 
 /* set number of OpenMP threads used by osift_run (0 = library default) */
 void  osift_set_threads(int n);
+
+/* FeaturesDev::match -> compute_distance (features.cu:160-225): for each of the nl left descriptors
+ * (128 floats) the two right descriptors with the smallest squared L2 distance, scanned in index order
+ * with strict '<'.  out3[3i..] = {best, second, accept = d1/d2 < 0.8f}; dist2[2i..] = {d1, d2} (may be NULL).
+ * The distance follows l2_in_t0's operation tree: per float4 t a partial
+ * fma(w,w, fma(z,z, fma(x,x, y*y))) (the left-to-right contraction of x*x + y*y + z*z + w*w), then the
+ * shuffle_down tree 16/8/4/2/1 as seen by lane 0. */
+void osift_match(const float* l, int nl, const float* r, int nr, int* out3, float* dist2);
 
 #ifdef __cplusplus
 }

@@ -729,6 +729,16 @@ int psx_dev_free(int device, void* ptr)
     return PSX_OK;
 }
 
+int psx_dev_read(int device, void* host_dst, const void* dev_src, size_t bytes)
+{
+    psx_ctx* ctx = nullptr;
+    if (bytes == 0) return PSX_OK;
+    if (!host_dst || !dev_src) return PSX_ERR_INVALID;
+    PSX_HIP(hipSetDevice(device));
+    PSX_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return PSX_OK;
+}
+
 int psx_clone_results(psx_ctx* ctx, void* d_features, void* d_descriptors, int* d_reverse_map)
 {
     if (!ctx) return PSX_ERR_INVALID;

@@ -2,8 +2,10 @@
 // popsift-demo needs Boost and DevIL, which are not part of this hot-path build).
 //
 // usage: popsift_demo <w> <h> <raw-u8-or-f32-file> <out.txt> [--float] [--vlfeat|--opencv]
-//                     [--octaves N] [--repeat N] [--norm-multi M] [--classic]
+//                     [--octaves N] [--repeat N] [--norm-multi M] [--classic] [--match <second-raw-file>]
 // writes: one line per descriptor:  x y sigma orientation d0..d127  (full float precision)
+// --match: MatchingMode as in the reference's popsift-match (src/application/match.cpp:257-275): both images
+//          are extracted into FeaturesDev objects and lFeatures->match(rFeatures) prints one line per descriptor
 #include <popsift/popsift.h>
 #include <popsift/features.h>
 #include <popsift/sift_conf.h>
@@ -23,6 +25,7 @@ int main( int argc, char** argv )
     const int w = atoi( argv[1] ), h = atoi( argv[2] );
     bool is_float = false;
     int repeat = 1;
+    const char* match_file = nullptr;
     popsift::Config config;
     for( int i = 5; i < argc; i++ ) {
         if( !strcmp( argv[i], "--float" ) ) is_float = true;
@@ -32,6 +35,7 @@ int main( int argc, char** argv )
         else if( !strcmp( argv[i], "--octaves" ) && i + 1 < argc ) config.setOctaves( atoi( argv[++i] ) );
         else if( !strcmp( argv[i], "--norm-multi" ) && i + 1 < argc ) config.setNormalizationMultiplier( atoi( argv[++i] ) );
         else if( !strcmp( argv[i], "--repeat" ) && i + 1 < argc ) repeat = atoi( argv[++i] );
+        else if( !strcmp( argv[i], "--match" ) && i + 1 < argc ) match_file = argv[++i];
     }
     std::vector<unsigned char> raw( (size_t)w * h * ( is_float ? 4 : 1 ) );
     {
@@ -39,6 +43,29 @@ int main( int argc, char** argv )
         if( !in.read( (char*)raw.data(), (std::streamsize)raw.size() ) ) { std::cerr << "short read" << std::endl; return 3; }
     }
     std::cout << "PopSift version: " << POPSIFT_VERSION_STRING << std::endl;
+
+    if( match_file != nullptr ) {
+        std::vector<unsigned char> raw2( raw.size() );
+        std::ifstream in2( match_file, std::ios::binary );
+        if( !in2.read( (char*)raw2.data(), (std::streamsize)raw2.size() ) ) { std::cerr << "short read" << std::endl; return 3; }
+        PopSift msift( config, popsift::Config::MatchingMode, is_float ? PopSift::FloatImages : PopSift::ByteImages );
+        SiftJob* lJob = is_float ? msift.enqueue( w, h, (const float*)raw.data() ) : msift.enqueue( w, h, raw.data() );
+        SiftJob* rJob = is_float ? msift.enqueue( w, h, (const float*)raw2.data() ) : msift.enqueue( w, h, raw2.data() );
+        if( !lJob || !rJob ) return 4;
+        popsift::FeaturesDev* lFeatures = lJob->getDev();
+        popsift::FeaturesDev* rFeatures = rJob->getDev();
+        if( !lFeatures || !rFeatures ) return 5;
+        std::cout << "Number of features:    " << lFeatures->getFeatureCount() << std::endl;
+        std::cout << "Number of descriptors: " << lFeatures->getDescriptorCount() << std::endl;
+        std::cout << "Number of features:    " << rFeatures->getFeatureCount() << std::endl;
+        std::cout << "Number of descriptors: " << rFeatures->getDescriptorCount() << std::endl;
+        std::cout.flush();
+        lFeatures->match( rFeatures );
+        fflush( stdout );
+        delete lFeatures; delete rFeatures; delete lJob; delete rJob;
+        msift.uninit();
+        return 0;
+    }
 
     PopSift sift( config, popsift::Config::ExtractingMode, is_float ? PopSift::FloatImages : PopSift::ByteImages );
 

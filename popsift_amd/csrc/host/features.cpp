@@ -1,5 +1,6 @@
 // features.cpp -- FeaturesHost / FeaturesDev / Feature::print
 // (reference behaviour: features.cu:27-128, 306-330)
+#include <cstdio>
 #include "popsift/features.h"
 #include "popsift/sift_extremum.h"
 
@@ -137,9 +138,32 @@ void FeaturesDev::reset( int num_ext, int num_ori )
     setDescriptorCount( num_ori );
 }
 
-void FeaturesDev::match( FeaturesDev* )
+// FeaturesDev::match (features.cu:270-304): the reference computes the match matrix on the device and
+// prints one line per left descriptor from a device printf (show_distance, features.cu:227-268); same
+// lines here, printed by the host from the arrays psx_match returns.
+void FeaturesDev::match( FeaturesDev* other )
 {
-    fatal( __FILE__, __LINE__, "not yet" );
+    if( other == nullptr ) fatal( __FILE__, __LINE__, "FeaturesDev::match: null argument" );
+    const int l_len = getDescriptorCount();
+    const int r_len = other->getDescriptorCount();
+    if( l_len <= 0 ) return;
+    std::vector<int>   mm( 3 * (size_t)l_len );
+    std::vector<float> dd( 2 * (size_t)l_len );
+    std::vector<int>   l_fem( l_len ), r_fem( r_len > 0 ? r_len : 1 );
+    if( psx_match( _device, (const float*)_ori, l_len, (const float*)other->_ori, r_len, mm.data(), dd.data() ) != PSX_OK ||
+        psx_dev_read( _device, l_fem.data(), _rev, (size_t)l_len * sizeof(int) ) != PSX_OK ||
+        ( r_len > 0 && psx_dev_read( other->_device, r_fem.data(), other->_rev, (size_t)r_len * sizeof(int) ) != PSX_OK ) )
+        fatal( __FILE__, __LINE__, "FeaturesDev::match failed" );
+    for( int i = 0; i < l_len; i++ )
+    {
+        const int m1 = mm[3*i], m2 = mm[3*i+1];
+        printf( "%s feat %4d [%4d] matches feat %4d [%4d] ( 2nd feat %4d [%4d] ) dist %.3f vs %.3f\n",
+                mm[3*i+2] ? "accept" : "reject",
+                l_fem[i], i,
+                r_len > 0 ? r_fem[m1] : 0, m1,
+                r_len > 0 ? r_fem[m2] : 0, m2,
+                dd[2*i], dd[2*i+1] );
+    }
 }
 
 } // namespace popsift

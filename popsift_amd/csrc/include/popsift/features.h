@@ -100,8 +100,8 @@ public:
 
     void reset( int num_ext, int num_ori );
 
-    /// brute-force matcher of the reference (features.cu:186-304): not part of the extraction
-    /// hot path; throws std::runtime_error("not yet")
+    /// brute-force 2-NN matcher of the reference (features.cu:160-304): prints one accept/reject line
+    /// per descriptor of *this, as the reference's show_distance does
     void match( FeaturesDev* other );
 
     inline Feature*    getFeatures()    { return _ext; }

@@ -371,3 +371,59 @@ def test_cpp_api_demo_matches_oracle(oracle, tmp_path):
     assert pos_ok.mean() >= 0.999
     dd = np.linalg.norm(ea[:, 4:] - eb[:, 4:], axis=1)
     assert (dd[pos_ok] <= 1e-3).mean() >= 0.99
+
+
+# ---- MatchingMode: FeaturesDev::match (features.cu:160-304) ---------------------------------------------
+@pytest.mark.parametrize("nl,nr,seed", [(300, 257, 1), (64, 1000, 2), (1, 1, 3), (5, 0, 4), (129, 1, 5), (2500, 2300, 6)])
+def test_match_bit_exact(oracle, capi, nl, nr, seed):
+    """psx_match vs the oracle's osift_match (pinned against the reference's own matcher in
+    tests/test_ref_shim_cpu.py): indices and accept flags are integer output -> equal; the squared
+    distances follow the same operation tree -> bit-identical."""
+    rng = np.random.default_rng(seed)
+    left = rng.random((nl, 128), dtype=np.float32)
+    right = rng.random((nr, 128), dtype=np.float32)
+    if nr > 10:
+        right[7] = left[0]; right[3] = left[0]          # exact duplicates: ties keep the earlier index
+        right[9] = left[min(2, nl - 1)] + np.float32(1e-3)
+    mo, do_ = oracle.match(left, right)
+    mg, dg = capi.match(left, right)
+    assert np.array_equal(mo, mg)
+    assert np.array_equal(do_.view(np.uint32), dg.view(np.uint32))
+
+
+def test_match_on_extracted_descriptors(oracle, capi):
+    """Two views of the same scene through the whole pipe, then the matcher on the real descriptors."""
+    a, b = synth(320, 240, 77), np.roll(synth(320, 240, 77), 3, axis=1)
+    da, db = [], []
+    for img, out in ((a, da), (b, db)):
+        ctx = capi.Context(capi.default_config(octaves=3))
+        ctx.upload(img)
+        ctx.extract()
+        out.append(ctx.download()[1])
+        ctx.close()
+    mo, do_ = oracle.match(da[0], db[0])
+    mg, dg = capi.match(da[0], db[0])
+    assert np.array_equal(mo, mg) and np.array_equal(do_.view(np.uint32), dg.view(np.uint32))
+    assert mo[:, 2].mean() > 0.3          # a 3-pixel shift keeps most keypoints matchable
+
+
+def test_cpp_matching_mode(tmp_path):
+    """PopSift(config, MatchingMode) -> SiftJob::getDev -> FeaturesDev::match, the flow of the reference's
+    popsift-match (match.cpp:257-275).  An image matched against itself: every line reports distance 0."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo = os.path.join(root, "popsift_amd", "lib", "popsift_demo")
+    w, h = 256, 192
+    img = synth(w, h, 91)
+    raw = tmp_path / "in.raw"
+    raw.write_bytes(img.tobytes())
+    p = subprocess.run([demo, str(w), str(h), str(raw), str(tmp_path / "unused.txt"), "--octaves", "3",
+                        "--match", str(raw)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    lines = [l for l in p.stdout.splitlines() if " matches feat " in l]
+    n_desc = [int(l.split(":")[1]) for l in p.stdout.splitlines() if l.startswith("Number of descriptors")]
+    assert len(n_desc) == 2 and n_desc[0] == n_desc[1] > 50
+    assert len(lines) == n_desc[0]
+    assert all(l.split("dist")[1].split()[0] == "0.000" for l in lines)
+    assert all(l.startswith(("accept", "reject")) for l in lines)

@@ -62,3 +62,20 @@ def test_grid_filter_matches_reference(oracle, ref, mode, grid, frac):
         assert len(r.iext(oc)) == int((kept["ignore"] == 0).sum())
     m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors())
     assert m["kp_match"] == 1.0 and m["ori_match"] == 1.0 and m["desc_match"] == 1.0, m
+
+
+@pytest.mark.parametrize("nl,nr,seed", [(40, 50, 1), (3, 1, 2), (33, 70, 3)])
+def test_matcher_matches_reference(oracle, ref, nl, nr, seed):
+    """osift_match vs the reference's own FeaturesDev::match (features.cu on the CUDA emulation; its
+    result is parsed from what show_distance prints): same indices, same accept flags, distances equal
+    to the 3 printed decimals."""
+    rng = np.random.default_rng(seed)
+    left = rng.random((nl, 128), dtype=np.float32)
+    right = rng.random((nr, 128), dtype=np.float32)
+    if nr > 10:
+        right[7] = left[3]; right[9] = left[3]           # duplicates: d1 == d2 == 0 -> NaN ratio -> reject
+    mr, dr = ref.match(left, right)
+    mo, do_ = oracle.match(left, right)
+    assert np.array_equal(mr, mo)
+    finite = np.isfinite(do_)
+    assert np.abs(dr[finite] - do_[finite]).max() <= 6e-4
