@@ -100,6 +100,8 @@ struct psx_ctx {
     int up_pitch = 0;
     psx_iext* d_iext = nullptr;        size_t iext_cap = 0;
     int* d_iext_off = nullptr;         size_t iext_off_cap = 0;
+    unsigned long long* d_cand = nullptr; size_t cand_cap = 0;
+    int* d_cand_ct = nullptr;          size_t cand_ct_cap = 0;
     psx_extremum* d_extrema = nullptr; size_t extrema_cap = 0;
     psx_feature* d_features = nullptr; size_t features_cap = 0;
     float* d_desc = nullptr;           size_t desc_cap = 0;       // floats
@@ -312,7 +314,7 @@ int psx_destroy(psx_ctx* ctx)
     (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr); (void)hipFree(ctx->d_up);
     (void)hipFree(ctx->d_gf_keys); (void)hipFree(ctx->d_gf_vals); (void)hipFree(ctx->d_gf_temp);
     (void)hipFree(ctx->d_gf_scratch);
-    (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off);
+    (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off); (void)hipFree(ctx->d_cand); (void)hipFree(ctx->d_cand_ct);
     (void)hipFree(ctx->d_extrema); (void)hipFree(ctx->d_features);
     (void)hipFree(ctx->d_desc); (void)hipFree(ctx->d_feat_to_ext); (void)hipFree(ctx->d_ext_nori);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -387,6 +389,12 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     const size_t ori_need = (size_t)imax(2 * (int)iext_need, c.max_extrema + c.max_extrema / 4);
     if ((rc = grow(ctx, &ctx->d_iext, &ctx->iext_cap, iext_need)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_iext_off, &ctx->iext_off_cap, iext_need)) != PSX_OK) return rc;
+    // candidates before refinement: ~1.3x the survivors on natural images; room for 4x the cap per octave,
+    // split over PSX_CAND_SUB sub-lists; a candidate that finds its sub-list full is refined in place
+    P.cand_capacity = (4 * c.max_extrema + PSX_CAND_SUB - 1) / PSX_CAND_SUB;
+    if ((rc = grow(ctx, &ctx->d_cand, &ctx->cand_cap, (size_t)P.num_octaves * PSX_CAND_SUB * P.cand_capacity)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_cand_ct, &ctx->cand_ct_cap, (size_t)P.num_octaves * PSX_CAND_SUB * 32)) != PSX_OK) return rc;
+    P.cand_ct = ctx->d_cand_ct;
     if ((rc = grow(ctx, &ctx->d_extrema, &ctx->extrema_cap, iext_need)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_features, &ctx->features_cap, iext_need)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_desc, &ctx->desc_cap, ori_need * 128)) != PSX_OK) return rc;
@@ -395,6 +403,7 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     for (int o = 0; o < P.num_octaves; o++) {
         P.iext[o] = ctx->d_iext + (size_t)o * c.max_extrema;
         P.iext_off[o] = ctx->d_iext_off + (size_t)o * c.max_extrema;
+        P.cand[o] = ctx->d_cand + (size_t)o * PSX_CAND_SUB * P.cand_capacity;
     }
     P.ext_capacity = (int)iext_need;
     P.ori_capacity = (int)ori_need;
@@ -484,6 +493,7 @@ int psx_build_pyramid(psx_ctx* ctx)
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     // Pyramid::reset_extrema_mgmt, sift_pyramid.cu:364-371
     PSX_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(PsxCounters), ctx->stream));
+    PSX_HIP(hipMemsetAsync(ctx->d_cand_ct, 0, sizeof(int) * (size_t)P.num_octaves * PSX_CAND_SUB * 32, ctx->stream));
 
     PsxLevel0Args a;
     a.img = ctx->d_input; a.w = ctx->in_w; a.h = ctx->in_h; a.is_float = ctx->input_is_float;
@@ -540,6 +550,7 @@ int psx_find_extrema(psx_ctx* ctx)
     PSX_HIP(hipSetDevice(ctx->device));
     for (int o = 0; o < ctx->hp.num_octaves; o++)
         PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+    PSX_HIP(psx_launch_refine(ctx->d_params, ctx->hp, ctx->d_cnt, ctx->stream));
     ctx->filtered = false;
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     return PSX_OK;

@@ -5,11 +5,11 @@
 // the DoG planes are never written to HBM.  A 256-thread workgroup stages a 64x16 tile (+1 px
 // halo) of all L-1 DoG levels in LDS, computed as G[l+1]-G[l] while loading the L Gaussian
 // planes once (24 B/pixel for L=6).  Candidates that pass the contrast pre-test and the strict
-// 26-neighbour test are queued in LDS; the refinement (<= 5 Newton steps, closed-form 3x3
-// solve) then runs one candidate per lane, reading DoG values on the fly from the Gaussian
-// planes (a single subtraction, bit-identical to a materialised DoG).  Survivors are compacted
-// with a 64-bit wave ballot and one atomicAdd per wave (wave64 re-design of extrema_count,
-// s_extrema.cu:22-44).
+// 26-neighbour test are appended to a per-octave candidate list; k_refine (one launch for all octaves)
+// runs the refinement (<= 5 Newton steps, closed-form 3x3 solve) one candidate per lane, reading DoG
+// values on the fly from the Gaussian planes (a single subtraction, bit-identical to a materialised
+// DoG).  Survivors are compacted with a 64-bit wave ballot and one atomicAdd per wave (wave64
+// re-design of extrema_count, s_extrema.cu:22-44).
 #include "psx_internal.h"
 
 namespace {
@@ -344,34 +344,40 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     __syncthreads();
     STAMP(3);
 
-    // ---- refine queued candidates, one per lane; wave64 ballot compaction ----
+    // ---- hand the candidates to k_refine: the refinement is a serial chain of up to 5 Newton steps per
+    // candidate and a tile has ~1 candidate, so refining here kept the whole workgroup (and its LDS)
+    // resident for one lane's latency.  Wave-aggregated append to the octave's candidate list; if the
+    // list is full the candidate is refined in place (same result, just slower). ----
     const int nq = sCount;
     const int lane = t & (PSX_WAVE - 1);
-    psx_iext* out = P->iext[octave];
-    int* out_off = P->iext_off[octave];
-    const DogView dv{oc, sD, NL, tx0, ty0};
     for (int base = 0; base < nq; base += NT) {
         const int q = base + t;
-        bool ok = false;
-        psx_iext ec;
-        if (q < nq) {
+        const bool have = q < nq;
+        int cx = 0, ly = 0, z = 0;
+        if (have) {
             const int code = sQ[q];
-            const int z = code >> 16, ly = (code >> 8) & 0xff, cx = code & 0xff;
-            const float v = sD[(z * THP + ly + 1) * TWP + cx + 1];
-            ok = refine<MODE>(P, dv, octave, tx0 + cx, ty0 + ly, z, v, ec);
+            z = code >> 16; ly = (code >> 8) & 0xff; cx = code & 0xff;
         }
-        const unsigned long long mask = __ballot(ok);
-        if (mask != 0ull) {
-            const int n = __popcll(mask);
-            const int leader = __ffsll((long long)mask) - 1;
-            int wbase = 0;
-            if (lane == leader) wbase = atomicAdd(&cnt->ext_ct[octave], n);
-            wbase = __shfl(wbase, leader);
-            if (ok) {
-                const int idx = wbase + __popcll(mask & ((1ull << lane) - 1ull));
-                if (idx < P->max_extrema) {
-                    out[idx] = ec;
-                    out_off[idx] = idx;
+        const unsigned long long mask = __ballot(have);
+        if (mask == 0ull) continue;
+        const int leader = __ffsll((long long)mask) - 1;
+        int wbase = 0;
+        const int sub = blockIdx.x & (PSX_CAND_SUB - 1);
+        if (lane == leader) wbase = atomicAdd(&P->cand_ct[(octave * PSX_CAND_SUB + sub) * 32], __popcll(mask));
+        wbase = __shfl(wbase, leader);
+        if (have) {
+            const int idx = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+            if (idx < P->cand_capacity) {
+                P->cand[octave][(size_t)sub * P->cand_capacity + idx] =
+                    ((unsigned long long)(unsigned)(ty0 + ly) << 32) | ((unsigned long long)(unsigned)z << 24) |
+                    (unsigned)(tx0 + cx);
+            } else {
+                const DogView dv{oc, sD, NL, tx0, ty0};
+                const float v = sD[(z * THP + ly + 1) * TWP + cx + 1];
+                psx_iext ec;
+                if (refine<MODE>(P, dv, octave, tx0 + cx, ty0 + ly, z, v, ec)) {
+                    const int o = atomicAdd(&cnt->ext_ct[octave], 1);
+                    if (o < P->max_extrema) { P->iext[octave][o] = ec; P->iext_off[octave][o] = o; }
                 }
             }
         }
@@ -380,6 +386,52 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
 #ifdef PSX_PHASE_TIMING
     if (threadIdx.x == 0 && g_dbg) g_dbg[blockIdx.x * 8 + 5] = nq;
 #endif
+}
+
+// Refinement of the queued candidates of ALL octaves in one launch: one wave per (octave, sub-list), one
+// candidate per lane, DoG values read from the Gaussian planes (L2 resident: the tile kernels have just
+// streamed them).  Survivors are compacted with a 64-bit wave ballot and one atomicAdd per wave
+// (wave64 re-design of extrema_count, s_extrema.cu:22-44).
+constexpr int REFINE_SPLIT = 4;
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_refine(const PsxParams* __restrict__ P, PsxCounters* cnt)
+{
+    // REFINE_SPLIT waves per (octave, sub-list); blockIdx.x = (octave * PSX_CAND_SUB + sub) * REFINE_SPLIT + part
+    const int lane = threadIdx.x;
+    const int list_id = blockIdx.x / REFINE_SPLIT, part = blockIdx.x % REFINE_SPLIT;
+    const int o = list_id / PSX_CAND_SUB, sub = list_id % PSX_CAND_SUB;
+    const int NL = P->L - 1;
+    const int n = min(P->cand_ct[list_id * 32], P->cand_capacity);
+    if (n <= part * PSX_WAVE) return;
+    const PsxOctave oc = P->oct[o];
+    const unsigned long long* list = P->cand[o] + (size_t)sub * P->cand_capacity;
+    const DogView dv{oc, nullptr, NL, -(1 << 30), -(1 << 30)};      // never "in tile": global reads
+    for (int e0 = part * PSX_WAVE; e0 < n; e0 += PSX_WAVE * REFINE_SPLIT) {
+        const int e = e0 + lane;
+        bool ok = false;
+        psx_iext ec;
+        if (e < n) {
+            const unsigned long long code = list[e];
+            const int x = (int)(code & 0xffffffu), z = (int)((code >> 24) & 0xffu), y = (int)(code >> 32);
+            const float v = rdog(oc, NL, x, y, z);
+            ok = refine<MODE>(P, dv, o, x, y, z, v, ec);
+        }
+        const unsigned long long mask = __ballot(ok);
+        if (mask != 0ull) {
+            const int leader = __ffsll((long long)mask) - 1;
+            int wbase = 0;
+            if (lane == leader) wbase = atomicAdd(&cnt->ext_ct[o], __popcll(mask));
+            wbase = __shfl(wbase, leader);
+            if (ok) {
+                const int idx = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+                if (idx < P->max_extrema) {
+                    P->iext[o][idx] = ec;
+                    P->iext_off[o][idx] = idx;
+                }
+            }
+        }
+    }
 }
 
 } // namespace
@@ -408,6 +460,18 @@ hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& hp, Ps
     default:
         hipLaunchKernelGGL(k_extrema<PSX_MODE_POPSIFT>, grid, block, smem, s, d_params, d_cnt, octave, tiles_x);
         break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t psx_launch_refine(const PsxParams* d_params, const PsxParams& hp, PsxCounters* d_cnt, hipStream_t s)
+{
+    if (hp.L - 3 < 1) return hipSuccess;
+    const dim3 grid(hp.num_octaves * PSX_CAND_SUB * REFINE_SPLIT), block(PSX_WAVE);
+    switch (hp.sift_mode) {
+    case PSX_MODE_VLFEAT: hipLaunchKernelGGL(k_refine<PSX_MODE_VLFEAT>, grid, block, 0, s, d_params, d_cnt); break;
+    case PSX_MODE_OPENCV: hipLaunchKernelGGL(k_refine<PSX_MODE_OPENCV>, grid, block, 0, s, d_params, d_cnt); break;
+    default:              hipLaunchKernelGGL(k_refine<PSX_MODE_POPSIFT>, grid, block, 0, s, d_params, d_cnt); break;
     }
     return hipGetLastError();
 }

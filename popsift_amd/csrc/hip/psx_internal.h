@@ -12,6 +12,7 @@
 #include "popsift_hip.h"
 
 #define PSX_WAVE 64
+#define PSX_CAND_SUB 64
 
 struct PsxOctave {
     float*   data;     // L planes, plane l at data + l*plane
@@ -45,6 +46,13 @@ struct PsxParams {
     float h_grid_div[PSX_MAX_OCTAVES];
     psx_iext* iext[PSX_MAX_OCTAVES];     // max_extrema entries each (dobuf.i_ext_dat)
     int*      iext_off[PSX_MAX_OCTAVES]; // dobuf.i_ext_off
+    // extremum candidates awaiting refinement (y<<32 | z<<24 | x): per octave PSX_CAND_SUB sub-lists of
+    // cand_capacity entries, each with its own counter on its own 128-byte line -- thousands of tiles
+    // appending through ONE counter serialise on that address in L2
+    unsigned long long* cand[PSX_MAX_OCTAVES];
+    int*      cand_ct;                   // [num_octaves][PSX_CAND_SUB][32]
+    int       cand_capacity;             // entries per sub-list
+    int       pad1;
     psx_extremum* extrema;               // dobuf.extrema
     psx_feature*  features;              // dobuf.features
     float*        desc;                  // dbuf.desc, 128 floats each
@@ -93,6 +101,7 @@ hipError_t psx_launch_downscale(const float* src, int sw, int sh, int spitch,
 hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s);
 hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt,
                               int octave, hipStream_t s);
+hipError_t psx_launch_refine(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt, hipStream_t s);
 // grid filter (gridfilter.hip)
 size_t     psx_gridfilter_scratch_ints(int grid_size);
 hipError_t psx_gridfilter_sort_bytes(int total, size_t* bytes);
