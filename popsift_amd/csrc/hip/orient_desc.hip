@@ -76,6 +76,28 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// atan2 on the gradient: degree-13 odd minimax polynomial for atan (max error 3.3e-7 rad), v_rcp_f32
+__device__ __forceinline__ float fast_atan2(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f));     // v_rcp_f32, 1 ulp
+    const float s = a * a;
+    float r = 0.006811792496591806f;
+    r = fmaf(r, s, -0.0336042195558548f);
+    r = fmaf(r, s, 0.07962366938591003f);
+    r = fmaf(r, s, -0.1323334127664566f);
+    r = fmaf(r, s, 0.19807815551757812f);
+    r = fmaf(r, s, -0.3331736922264099f);
+    r = fmaf(r, s, 0.9999961256980896f);
+    r = r * a;
+    if (ay > ax) r = 1.57079632679489662f - r;
+    if (x < 0.0f) r = PI_F - r;
+    return (y < 0.0f) ? -r : r;
+}
+
+typedef const __attribute__((address_space(1))) float* gfloat_p;
+
 // clamped per-octave extrema count (find_extrema_in_dog's atomicMin, s_extrema.cu:553)
 __device__ __forceinline__ int ext_count(const PsxParams* P, const PsxCounters* cnt, int o)
 {
@@ -87,16 +109,20 @@ __device__ __forceinline__ int ext_count(const PsxParams* P, const PsxCounters* 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict__ P, const PsxCounters* cnt)
 {
-    __shared__ fix64 s_hist[WPB][HCOPIES * ORI_NBINS];
+    // 18.14 fixed-point bins (ds_add_u32, round to nearest): a window holds at most (2*rad+1)^2 ~ 2200
+    // pixels x |gradient| <= 360.7 = 8e5 in total, the sum of all 8 copies; one copy stays far below 2^18
+    constexpr float OFIX = 16384.0f;
+    __shared__ unsigned s_hist[WPB][HCOPIES * ORI_NBINS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    fix64* hist = s_hist[wave];
+    unsigned* hist = s_hist[wave];
 
     int total = 0;
     for (int o = 0; o < P->num_octaves; o++) total += ext_count(P, cnt, o);
     if (total > P->ext_capacity) total = P->ext_capacity;
 
     const int nwaves = gridDim.x * WPB;
-    for (int e = blockIdx.x * WPB + wave; e < total; e += nwaves) {
+    for (int ev = blockIdx.x * WPB + wave; ev < total; ev += nwaves) {
+        const int e = __builtin_amdgcn_readfirstlane(ev);          // wave uniform: scalar loads below
         int o = 0, base = 0;
         for (;;) {
             const int c = ext_count(P, cnt, o);
@@ -107,17 +133,19 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         const int w = oc.w, h = oc.h;
         const psx_iext ie = P->iext[o][P->iext_off[o][e - base]];
 
-        for (int i = lane; i < HCOPIES * ORI_NBINS; i += PSX_WAVE) hist[i] = 0ull;
+        for (int i = lane; i < HCOPIES * ORI_NBINS; i += PSX_WAVE) hist[i] = 0u;
         wave_fence();
 
         const float x = ie.xpos, y = ie.ypos;
         const int   level = psx_clampi(ie.lpos, 0, P->L - 1);
         const float sig = ie.sigma;
-        const float* plane = oc.data + (size_t)level * oc.plane;
+        const char* plane = reinterpret_cast<const char*>(oc.data + (size_t)level * oc.plane);
+        const unsigned pitch4 = (unsigned)oc.pitch * 4u;
 
         const float sigw = ORI_WINFACTOR * sig;
         const int   rad  = (int)roundf((3.0f * sigw));
         const float factor = -0.5f / (sigw * sigw);
+        const float factor2 = factor * 1.4426950408889634f;        // exp(s*factor) = exp2(s*factor2)
         const int   sq_thres = rad * rad;
 
         const int xmin = max(1,     (int)roundf(x) - rad);
@@ -128,26 +156,29 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         const int hy = ymax - ymin + 1;
         const int loops = (wx > 0 && hy > 0) ? wx * hy : 0;
 
-        fix64* myhist = hist + (lane & (HCOPIES - 1)) * ORI_NBINS;
+        unsigned* myhist = hist + (lane & (HCOPIES - 1)) * ORI_NBINS;
         const float rcp_wx = 1.0f / (float)max(wx, 1);
         for (int i = lane; i < loops; i += PSX_WAVE) {
             // i / wx without integer division: (i+0.5)/wx is >= 0.5/wx away from an integer
             const int q = (int)(((float)i + 0.5f) * rcp_wx);
             const int yy = q + ymin;
             const int xx = i - q * wx + xmin;
-            const float* p = plane + (size_t)yy * oc.pitch + xx;
-            const float gdx = p[1] - p[-1];
-            const float gdy = p[oc.pitch] - p[-oc.pitch];
-            const float grad  = hypotf(gdx, gdy);
-            const float theta = atan2f(gdy, gdx);
+            // uniform plane base + 32-bit byte offset: global_load with scalar base
+            const unsigned off = (unsigned)yy * pitch4 + (unsigned)xx * 4u;
+            const float gdx = *(gfloat_p)(plane + off + 4u) - *(gfloat_p)(plane + off - 4u);
+            const float gdy = *(gfloat_p)(plane + (off + pitch4)) - *(gfloat_p)(plane + (off - pitch4));
+            // the reference uses hypotf / atan2f here (s_gradiant.h:56-69); v_sqrt_f32 and the 3.3e-7 rad
+            // polynomial move a sample across a bin boundary with probability ~1e-6
+            const float grad  = __builtin_amdgcn_sqrtf(fmaf(gdx, gdx, gdy * gdy));
+            const float theta = fast_atan2(gdy, gdx);
             const float dx = xx - x;
             const float dy = yy - y;
             const int sq_dist = (int)(dx * dx + dy * dy);
             if (sq_dist <= sq_thres) {
-                const float weight = grad * expf(sq_dist * factor);
-                int bidx = (int)roundf((float)ORI_NBINS * (theta + PI_F) / PI2_F);
+                const float weight = grad * __builtin_amdgcn_exp2f((float)sq_dist * factor2);
+                int bidx = (int)roundf((float)ORI_NBINS * (theta + PI_F) * (1.0f / PI2_F));
                 bidx = (bidx == ORI_NBINS) ? 0 : bidx;
-                atomicAdd(&myhist[bidx], to_fix(weight));
+                atomicAdd(&myhist[bidx], (unsigned)fmaf(weight, OFIX, 0.5f));
             }
         }
         wave_fence();
@@ -156,10 +187,10 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         const bool isbin = lane < ORI_NBINS;
         float hval = 0.0f;
         if (isbin) {
-            fix64 hsum = 0ull;
+            unsigned hsum = 0u;
 #pragma unroll
             for (int c = 0; c < HCOPIES; c++) hsum += hist[c * ORI_NBINS + lane];
-            hval = from_fix(hsum);
+            hval = (float)hsum * (1.0f / OFIX);
         }
         const int prev_l = isbin ? (lane == 0 ? ORI_NBINS - 1 : lane - 1) : lane;
         const int next_l = isbin ? (lane == ORI_NBINS - 1 ? 0 : lane + 1) : lane;
@@ -348,26 +379,6 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
 // __fdividef) are matched with gfx950 fast paths here: v_exp_f32, v_rcp_f32, v_sqrt_f32 and a
 // degree-13 odd minimax polynomial for atan (max error 3.3e-7 rad).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fast_atan2(float y, float x)
-{
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float a = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f));     // v_rcp_f32, 1 ulp
-    const float s = a * a;
-    float r = 0.006811792496591806f;
-    r = fmaf(r, s, -0.0336042195558548f);
-    r = fmaf(r, s, 0.07962366938591003f);
-    r = fmaf(r, s, -0.1323334127664566f);
-    r = fmaf(r, s, 0.19807815551757812f);
-    r = fmaf(r, s, -0.3331736922264099f);
-    r = fmaf(r, s, 0.9999961256980896f);
-    r = r * a;
-    if (ay > ax) r = 1.57079632679489662f - r;
-    if (x < 0.0f) r = PI_F - r;
-    return (y < 0.0f) ? -r : r;
-}
-
-typedef const __attribute__((address_space(1))) float* gfloat_p;
 
 __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt)
 {
