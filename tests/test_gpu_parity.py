@@ -256,6 +256,26 @@ def test_grid_filter_not_triggered(oracle, capi):
     ctx.close()
 
 
+def test_max_extrema_cap_and_candidate_overflow(oracle, capi):
+    """max_extrema caps the extrema per octave (s_extrema.cu:553, atomicMin); which ones survive is arrival
+    order, so only the counts and set membership are defined.  A tiny cap also makes the candidate
+    sub-lists of k_extrema overflow, which exercises the refine-in-place path."""
+    img = synth(640, 480, 808)
+    full = oracle.run(oracle.default_config(octaves=4), img)
+    cap = 40
+    n_oct = [len(full.iext(o)) for o in range(full.num_octaves)]
+    assert max(n_oct) > 20 * cap
+    ctx = capi.Context(capi.default_config(octaves=4, max_extrema=cap))
+    ctx.upload(img)
+    ctx.extract()
+    f, d = ctx.download()
+    assert len(f) == sum(min(n, cap) for n in n_oct)
+    assert len(d) == int(f["num_ori"].sum())
+    m = match_features(f, d, full.features(), full.descriptors())
+    assert m["kp_match"] >= 0.999 and m["ori_match"] >= 0.995 and m["desc_match"] >= 0.995, m
+    ctx.close()
+
+
 def test_context_reuse_and_resize(oracle, capi):
     """One context, frames of different sizes (Pyramid::resetDimensions, sift_pyramid.cu:165-177)."""
     ocfg, gcfg = _cfgs(oracle, capi, dict(octaves=3))
