@@ -332,15 +332,18 @@ __device__ __forceinline__ float l0_unorm8(unsigned q)
     return fmaf(e, c, r);
 }
 
+// One thread = 4 adjacent columns x UP_ROWS consecutive rows.  The column side (texel indices, 1.8 weights)
+// is computed once; the horizontal lerp of a texel row, r(j, X) = lerp(T[j][i0], T[j][i0+1], alpha_X), is
+// computed once per texel row and reused by the output rows that share it (at x2 upsampling two output
+// rows share each texel row); all lanes of a wave work on the same rows, so the reuse test is a scalar branch.
+constexpr int UP_ROWS = 4;
+
 __global__ __launch_bounds__(256) void k_upscale(UpArgs a)
 {
     const int t = threadIdx.x;
     const int cq = blockIdx.x * 64 + (t & 63);
-    const int y  = blockIdx.y * 4 + (t >> 6);
-    if (cq >= a.ncol4 || y >= a.H) return;
-    int j0; float be;
-    l0_axis(((float)y + a.shift) / (float)a.H, a.h, j0, be);
-    const int ja = psx_clampi(j0, 0, a.h - 1), jb = psx_clampi(j0 + 1, 0, a.h - 1);
+    const int y0 = (blockIdx.y * 4 + (t >> 6)) * UP_ROWS;
+    if (cq >= a.ncol4 || y0 >= a.H) return;
     int ia[4], ib[4]; float al[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -348,48 +351,63 @@ __global__ __launch_bounds__(256) void k_upscale(UpArgs a)
         l0_axis(((float)(cq * 4 + e - a.pad) + a.shift) / (float)a.W, a.w, i0, al[e]);
         ia[e] = psx_clampi(i0, 0, a.w - 1); ib[e] = psx_clampi(i0 + 1, 0, a.w - 1);
     }
-    float p00[4], p10[4], p01[4], p11[4];
-    if (a.is_float) {
-        const float* ra = static_cast<const float*>(a.img) + (size_t)ja * a.w;
-        const float* rb = static_cast<const float*>(a.img) + (size_t)jb * a.w;
+    // the 8 texel columns of 4 adjacent outputs normally lie within 4 consecutive texels (any upscale
+    // >= 1): they are fetched as one unaligned dword per texel row instead of 8 byte loads
+    const int base = min(ia[0], max(a.w - 4, 0));
+    const bool packed = !a.is_float && a.w >= 4 && ib[3] - base <= 3;
+    int sa[4], sb[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) { p00[e] = ra[ia[e]]; p10[e] = ra[ib[e]]; p01[e] = rb[ia[e]]; p11[e] = rb[ib[e]]; }
-    } else {
-        const uint8_t* ra = static_cast<const uint8_t*>(a.img) + (size_t)ja * a.w;
-        const uint8_t* rb = static_cast<const uint8_t*>(a.img) + (size_t)jb * a.w;
-        // the 8 texel columns of 4 adjacent outputs normally lie within 4 consecutive texels (any
-        // upscale >= 1): fetch them as one unaligned dword per texel row instead of 16 byte loads
-        const int base = min(ia[0], max(a.w - 4, 0));
-        unsigned q00[4], q10[4], q01[4], q11[4];
-        if (a.w >= 4 && ib[3] - base <= 3) {
-            unsigned wa, wb;
-            __builtin_memcpy(&wa, ra + base, 4);
-            __builtin_memcpy(&wb, rb + base, 4);
+    for (int e = 0; e < 4; e++) { sa[e] = (ia[e] - base) * 8; sb[e] = (ib[e] - base) * 8; }
+
+    auto lerp_row = [&](int j, float* r) {          // r[e] = lerp_x of texel row j at the 4 columns
+        float p[4], q[4];
+        if (a.is_float) {
+            const float* row = static_cast<const float*>(a.img) + (size_t)j * a.w;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int sa = (ia[e] - base) * 8, sb = (ib[e] - base) * 8;
-                q00[e] = (wa >> sa) & 0xffu; q10[e] = (wa >> sb) & 0xffu;
-                q01[e] = (wb >> sa) & 0xffu; q11[e] = (wb >> sb) & 0xffu;
-            }
+            for (int e = 0; e < 4; e++) { p[e] = row[ia[e]]; q[e] = row[ib[e]]; }
         } else {
+            const uint8_t* row = static_cast<const uint8_t*>(a.img) + (size_t)j * a.w;
+            if (packed) {
+                unsigned wv;
+                __builtin_memcpy(&wv, row + base, 4);
 #pragma unroll
-            for (int e = 0; e < 4; e++) { q00[e] = ra[ia[e]]; q10[e] = ra[ib[e]]; q01[e] = rb[ia[e]]; q11[e] = rb[ib[e]]; }
+                for (int e = 0; e < 4; e++) { p[e] = l0_unorm8((wv >> sa[e]) & 0xffu); q[e] = l0_unorm8((wv >> sb[e]) & 0xffu); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { p[e] = l0_unorm8(row[ia[e]]); q[e] = l0_unorm8(row[ib[e]]); }
+            }
         }
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            p00[e] = l0_unorm8(q00[e]); p10[e] = l0_unorm8(q10[e]);
-            p01[e] = l0_unorm8(q01[e]); p11[e] = l0_unorm8(q11[e]);
-        }
-    }
-    float o[4];
+        for (int e = 0; e < 4; e++) r[e] = l0_lerp(p[e], q[e], al[e]);
+    };
+
+    int cj0 = -1, cj1 = -1;                          // texel rows whose lerp_x is cached in r0 / r1
+    float r0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, r1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
+    for (int rr = 0; rr < UP_ROWS; rr++) {
+        const int y = y0 + rr;
+        if (y >= a.H) break;
+        int j0; float be;
+        l0_axis(((float)y + a.shift) / (float)a.H, a.h, j0, be);
+        // wave uniform (every lane of a wave has the same y): scalar compares and branches
+        const int ja = __builtin_amdgcn_readfirstlane(psx_clampi(j0, 0, a.h - 1));
+        const int jb = __builtin_amdgcn_readfirstlane(psx_clampi(j0 + 1, 0, a.h - 1));
+        float ra[4], rb[4];
+        if (ja == cj0)      { for (int e = 0; e < 4; e++) ra[e] = r0[e]; }
+        else if (ja == cj1) { for (int e = 0; e < 4; e++) ra[e] = r1[e]; }
+        else                lerp_row(ja, ra);
+        if (jb == ja)       { for (int e = 0; e < 4; e++) rb[e] = ra[e]; }
+        else if (jb == cj1) { for (int e = 0; e < 4; e++) rb[e] = r1[e]; }
+        else if (jb == cj0) { for (int e = 0; e < 4; e++) rb[e] = r0[e]; }
+        else                lerp_row(jb, rb);
+        cj0 = ja; cj1 = jb;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { r0[e] = ra[e]; r1[e] = rb[e]; }
         // lerp_y( lerp_x(T[j0]), lerp_x(T[j0+1]) ): same operations, same order as the oracle's texture model
-        const float r0 = l0_lerp(p00[e], p10[e], al[e]);
-        const float r1 = l0_lerp(p01[e], p11[e], al[e]);
-        o[e] = l0_lerp(r0, r1, be);
+        *reinterpret_cast<float4*>(a.dst + (size_t)y * a.pitch + cq * 4) =
+            make_float4(l0_lerp(ra[0], rb[0], be), l0_lerp(ra[1], rb[1], be),
+                        l0_lerp(ra[2], rb[2], be), l0_lerp(ra[3], rb[3], be));
     }
-    *reinterpret_cast<float4*>(a.dst + (size_t)y * a.pitch + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // get_by_2_pick_every_second (s_pyramid_build.cu:50-71), used only when the fused path is off
@@ -456,7 +474,7 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
     u.img = h.img; u.w = h.w; u.h = h.h; u.is_float = h.is_float;
     u.dst = h.tmp; u.W = h.W; u.H = h.H; u.pitch = h.tmp_pitch; u.pad = pad; u.ncol4 = (wr + 2 * pad) / 4;
     u.shift = h.shift;
-    hipLaunchKernelGGL(k_upscale, dim3((u.ncol4 + 63) / 64, (h.H + 3) / 4), dim3(256), 0, s, u);
+    hipLaunchKernelGGL(k_upscale, dim3((u.ncol4 + 63) / 64, (h.H + 4 * UP_ROWS - 1) / (4 * UP_ROWS)), dim3(256), 0, s, u);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
 
