@@ -114,6 +114,8 @@ struct psx_ctx {
     unsigned char* d_gf_temp = nullptr;      size_t gf_temp_cap = 0;
     int* d_gf_scratch = nullptr;             size_t gf_scratch_cap = 0;
     bool filtered = false;             // the grid filter ran on the current frame
+    bool interleave = false;           // psx_extract: launch an octave's extrema scan right behind its last blur level
+    bool ext_launched = false;         // ... which has happened for the current frame
 
     // zero-copy export
     psx_feature* x_host_feat = nullptr; float* x_host_desc = nullptr;
@@ -506,11 +508,16 @@ int psx_build_pyramid(psx_ctx* ctx)
     a.taps_v = taps_from(ctx->inc_filter); a.span_v = ctx->inc_span[0];
     PSX_HIP(psx_launch_level0(a, ctx->stream));
 
-    for (int o = 0; o < P.num_octaves; o++)
+    ctx->ext_launched = false;
+    for (int o = 0; o < P.num_octaves; o++) {
         for (int level = 1; level < P.L; level++) {
             int rc = launch_blur_level(ctx, o, level);
             if (rc != PSX_OK) return rc;
         }
+        // the six planes of this octave are as cache-resident now as they will ever be
+        if (ctx->interleave) PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+    }
+    ctx->ext_launched = ctx->interleave;
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     return PSX_OK;
 }
@@ -548,8 +555,10 @@ int psx_find_extrema(psx_ctx* ctx)
     if (!ctx) return PSX_ERR_INVALID;
     if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_find_extrema: no pyramid");
     PSX_HIP(hipSetDevice(ctx->device));
-    for (int o = 0; o < ctx->hp.num_octaves; o++)
-        PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+    if (!ctx->ext_launched)
+        for (int o = 0; o < ctx->hp.num_octaves; o++)
+            PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+    ctx->ext_launched = false;
     PSX_HIP(psx_launch_refine(ctx->d_params, ctx->hp, ctx->d_cnt, ctx->stream));
     ctx->filtered = false;
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -584,7 +593,11 @@ int psx_descriptors(psx_ctx* ctx)
 int psx_extract(psx_ctx* ctx)
 {
     int rc;
-    if ((rc = psx_build_pyramid(ctx)) != PSX_OK) return rc;
+    if (!ctx) return PSX_ERR_INVALID;
+    ctx->interleave = !ctx->timers;        // per-stage timers need the stages back to back
+    rc = psx_build_pyramid(ctx);
+    ctx->interleave = false;
+    if (rc != PSX_OK) return rc;
     if ((rc = psx_find_extrema(ctx)) != PSX_OK) return rc;
     if ((rc = psx_orientation(ctx)) != PSX_OK) return rc;
     return psx_descriptors(ctx);
