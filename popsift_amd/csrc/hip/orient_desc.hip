@@ -11,12 +11,18 @@
 //   * one launch covers all octaves: each wave looks its extremum up through the per-octave
 //     counters, so the host never reads a counter between stages (the reference does four blocking
 //     symbol copies and three device-wide syncs per image);
-//   * 36-bin histogram: 8 LDS copies per wave (lane & 7) absorb ds_add_f32 conflicts, reduced in
-//     fixed order; smoothing and the parabola fit run on lanes 0..35 with __shfl;
+//   * histograms are 18.14 unsigned fixed point accumulated with ds_add_u32 (ds_add_f32 is ~30x slower
+//     on gfx950, tools/ubench/lds_atomic.hip; integer sums do not depend on arrival order): 36 bins x 8
+//     copies per wave for the orientation, a padded 4x4x8 tile grid x 4 copies for the descriptor;
+//     smoothing and the parabola fit run on lanes 0..35 with __shfl;
 //   * the 64-candidate bitonic sort becomes four rounds of wave-max selection;
-//   * descriptor: every pixel of the rotated 5x5-SBP window is visited ONCE (gradient, hypot,
-//     atan2 once) and scattered into the <= 4 tiles whose |n| < 1 test passes, using the
-//     reference's per-tile arithmetic; the reference visits it from each of 16 tile scans.
+//   * descriptor: every pixel of the rotated 5x5-SBP window is visited ONCE (gradient, magnitude,
+//     angle once) and scattered trilinearly into 2x2 tiles x 2 bins; the reference visits it from each
+//     of its 16 tile scans;
+//   * both gather kernels are VALU-issue bound: per-wave state lives in SGPRs (readfirstlane), loads use
+//     a scalar plane base + one 32-bit offset, magnitude / angle / weights use v_sqrt_f32, v_rcp_f32,
+//     v_exp_f32 and a degree-13 atan polynomial (the reference: hypotf/atan2f for the orientation,
+//     __fdividef/__expf for the descriptor).
 #include "psx_internal.h"
 
 namespace {
