@@ -211,6 +211,17 @@ def main():
                     "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                     "measured_copy_plane": round(copy_plane_gbs, 1)}
 
+        # one frame at a time on one context (BASELINE config 2, "single frame"): wall-clock latency
+        c0.set_input_tensor(frames[0])
+        lat = []
+        for i in range(25):
+            t1 = time.perf_counter()
+            c0.extract()
+            c0.counts()
+            lat.append(time.perf_counter() - t1)
+        lat = sorted(lat[5:])
+        single_ms = lat[len(lat) // 2] * 1e3
+
         # per-stage device time of one frame (HIP events on the context's stream)
         c0.enable_timers(True)
         c0.set_input_tensor(frames[0])
@@ -248,6 +259,8 @@ def main():
             "keypoints_per_s": round(kps_total / dt, 1),
             "keypoints_per_frame": round(kps_total / n_frames, 1),
             "ms_per_frame": round(dt / (BATCH * args.steps) * 1e3, 4),
+            "single_frame": {"ms": round(single_ms, 4), "value": round(W * H / single_ms / 1e3, 1), "unit": "Mpix/s",
+                             "what": "median wall time of one frame at a time on one context (no overlap between frames)"},
             "stage_ms_single_frame": {"pyramid": round(stages[0], 4), "extrema": round(stages[1], 4),
                                       "orientation": round(stages[2], 4), "descriptors": round(stages[3], 4)},
             "host_export": {"value": round(n_frames * W * H / dt_x / 1e6, 1), "unit": "Mpix/s",
