@@ -276,6 +276,27 @@ def test_max_extrema_cap_and_candidate_overflow(oracle, capi):
     ctx.close()
 
 
+def test_hipgraph_replay_matches_stream_launches(capi, monkeypatch):
+    """POPSIFT_HIP_GRAPH=1: psx_extract captures its launch chain once and replays it; results must be
+    those of the plain stream launches, also after the input pointer / size changes (re-capture)."""
+    imgs = [synth(320, 240, 5), synth(320, 240, 6), synth(256, 200, 7)]
+    plain = []
+    ctx = capi.Context(capi.default_config(octaves=3))
+    for im in imgs:
+        ctx.upload(im); ctx.extract(); plain.append(ctx.download())
+    ctx.close()
+    monkeypatch.setenv("POPSIFT_HIP_GRAPH", "1")
+    ctx = capi.Context(capi.default_config(octaves=3))
+    for rep in range(2):
+        for im, (pf, pd) in zip(imgs, plain):
+            ctx.upload(im); ctx.extract()
+            f, d = ctx.download()
+            assert len(f) == len(pf) and len(d) == len(pd)
+            m = match_features(pf, pd, f, d)
+            assert m["kp_match"] == 1.0 and m["desc_match"] >= 0.999
+    ctx.close()
+
+
 def test_context_reuse_and_resize(oracle, capi):
     """One context, frames of different sizes (Pyramid::resetDimensions, sift_pyramid.cu:165-177)."""
     ocfg, gcfg = _cfgs(oracle, capi, dict(octaves=3))
