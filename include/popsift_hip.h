@@ -209,6 +209,8 @@ int psx_dev_alloc(int device, size_t bytes, void** out);
 int psx_dev_free(int device, void* ptr);
 /* synchronous device -> host copy of a buffer obtained from psx_dev_alloc / psx_clone_results */
 int psx_dev_read(int device, void* host_dst, const void* dev_src, size_t bytes);
+/* synchronous host -> device copy into such a buffer */
+int psx_dev_write(int device, void* dev_dst, const void* host_src, size_t bytes);
 int psx_clone_results(psx_ctx* ctx, void* d_features, void* d_descriptors, int* d_reverse_map);
 
 /* FeaturesDev::match (features.cu:160-304, compute_distance / l2_in_t0): brute-force 2-nearest

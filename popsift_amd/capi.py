@@ -56,7 +56,7 @@ SYMBOLS = [
     "psx_find_extrema", "psx_orientation", "psx_descriptors", "psx_extract", "psx_sync", "psx_counts",
     "psx_download", "psx_attach_export", "psx_device_results", "psx_dump_plane", "psx_dump_iext", "psx_dump_extrema",
     "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
-    "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_clone_results", "psx_match", "psx_device_count", "psx_device_info",
+    "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_dev_write", "psx_clone_results", "psx_match", "psx_device_count", "psx_device_info",
 ]
 
 _LIB = None
@@ -121,25 +121,38 @@ def default_config(**kw):
 
 
 def match(left, right, device=0):
-    """psx_match on host arrays: left (n,128) / right (m,128) float32 are copied to the device with
-    psx_dev_alloc + hipMemcpy-free plumbing (torch is only the allocator here).  Returns (match (n,3)
-    int32 = best, second, accept; dist (n,2) float32 squared distances)."""
-    import torch
+    """psx_match on host arrays: left (n,128) / right (m,128) float32 go to the device through
+    psx_dev_alloc / psx_dev_write.  Returns (match (n,3) int32 = best, second, accept; dist (n,2) float32
+    squared distances)."""
     L = lib()
     L.psx_match.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.psx_dev_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.psx_dev_free.argtypes = [C.c_int, C.c_void_p]
+    L.psx_dev_write.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     left = np.ascontiguousarray(left, dtype=np.float32).reshape(-1, 128)
     right = np.ascontiguousarray(right, dtype=np.float32).reshape(-1, 128)
-    dl = torch.from_numpy(left).to("cuda:%d" % device) if len(left) else None
-    dr = torch.from_numpy(right).to("cuda:%d" % device) if len(right) else None
-    torch.cuda.synchronize()
-    mm = np.zeros((len(left), 3), np.int32)
-    dd = np.zeros((len(left), 2), np.float32)
-    rc = L.psx_match(device, C.c_void_p(dl.data_ptr() if dl is not None else 0), len(left),
-                     C.c_void_p(dr.data_ptr() if dr is not None else 0), len(right),
-                     mm.ctypes.data_as(C.c_void_p), dd.ctypes.data_as(C.c_void_p))
-    if rc != 0:
-        raise PopSiftError("psx_match failed (%d)" % rc)
-    return mm, dd
+    bufs = []
+    try:
+        ptrs = []
+        for arr in (left, right):
+            p = C.c_void_p()
+            if len(arr):
+                if L.psx_dev_alloc(device, arr.nbytes, C.byref(p)) != 0:
+                    raise PopSiftError("psx_dev_alloc failed")
+                bufs.append(p)
+                if L.psx_dev_write(device, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes) != 0:
+                    raise PopSiftError("psx_dev_write failed")
+            ptrs.append(p)
+        mm = np.zeros((len(left), 3), np.int32)
+        dd = np.zeros((len(left), 2), np.float32)
+        rc = L.psx_match(device, ptrs[0], len(left), ptrs[1], len(right),
+                         mm.ctypes.data_as(C.c_void_p), dd.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise PopSiftError("psx_match failed (%d)" % rc)
+        return mm, dd
+    finally:
+        for p in bufs:
+            L.psx_dev_free(device, p)
 
 
 def gauss_tables(cfg):

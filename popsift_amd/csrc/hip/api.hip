@@ -815,6 +815,16 @@ int psx_dev_read(int device, void* host_dst, const void* dev_src, size_t bytes)
     return PSX_OK;
 }
 
+int psx_dev_write(int device, void* dev_dst, const void* host_src, size_t bytes)
+{
+    psx_ctx* ctx = nullptr;
+    if (bytes == 0) return PSX_OK;
+    if (!dev_dst || !host_src) return PSX_ERR_INVALID;
+    PSX_HIP(hipSetDevice(device));
+    PSX_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return PSX_OK;
+}
+
 int psx_clone_results(psx_ctx* ctx, void* d_features, void* d_descriptors, int* d_reverse_map)
 {
     if (!ctx) return PSX_ERR_INVALID;

@@ -468,3 +468,32 @@ def test_cpp_matching_mode(tmp_path):
     assert len(lines) == n_desc[0]
     assert all(l.split("dist")[1].split()[0] == "0.000" for l in lines)
     assert all(l.startswith(("accept", "reject")) for l in lines)
+
+
+def test_pipeline_plus_matcher_recovers_a_known_shift(capi):
+    """End-to-end sanity of extraction + MatchingMode matcher (BASELINE config 5 in miniature, OpenCV mode):
+    the second image is the first one shifted by (dx, dy) = (5, 3) pixels; accepted matches must pair keypoints
+    whose positions differ by that shift."""
+    base = synth(480 + 16, 360 + 16, 321)
+    a = np.ascontiguousarray(base[8:368, 8:488])
+    b = np.ascontiguousarray(base[8 - 3:368 - 3, 8 - 5:488 - 5])        # content moves by (+5, +3)
+    out = []
+    for img in (a, b):
+        ctx = capi.Context(capi.default_config(octaves=4, sift_mode=1, gauss_mode=3))
+        ctx.upload(img)
+        ctx.extract()
+        f, d = ctx.download()
+        # one (x, y) per descriptor
+        xy = np.zeros((len(d), 2), np.float32)
+        for k in f:
+            for o in range(k["num_ori"]):
+                xy[k["desc_idx"][o]] = (k["xpos"], k["ypos"])
+        out.append((xy, d))
+        ctx.close()
+    (xa, da), (xb, db) = out
+    mm, dd = capi.match(da, db)
+    acc = mm[:, 2] == 1
+    assert acc.sum() > 0.4 * len(da)
+    delta = xb[mm[acc, 0]] - xa[acc]
+    good = (np.abs(delta[:, 0] - 5.0) < 0.5) & (np.abs(delta[:, 1] - 3.0) < 0.5)
+    assert good.mean() > 0.97, (good.mean(), acc.sum())
