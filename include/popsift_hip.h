@@ -205,6 +205,10 @@ int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float
 /* FeaturesDev support (MatchingMode, popsift.cpp:346-383, sift_pyramid.cu:324-362): device
  * buffers owned by the caller and a device-to-device clone of the last results
  * (features as psx_feature records, descriptors, descriptor->extremum map). */
+/* pinned, GPU-mapped host memory (hipHostMalloc): cheap targets for psx_attach_export and sources for
+ * psx_upload_*.  Allocation is slow (pool the buffers). */
+int psx_host_alloc(size_t bytes, void** out);
+int psx_host_free(void* ptr);
 int psx_dev_alloc(int device, size_t bytes, void** out);
 int psx_dev_free(int device, void* ptr);
 /* synchronous device -> host copy of a buffer obtained from psx_dev_alloc / psx_clone_results */

@@ -87,12 +87,17 @@ struct psx_ctx {
     int octaves_resolved = -1;         // sticky auto-octave value (popsift.cpp:118-122)
     PsxParams    hp{};
     PsxParams*   d_params = nullptr;
+    PsxParams*   h_params_pin = nullptr;   // pinned mirror: source of the asynchronous parameter updates
     PsxCounters* d_cnt = nullptr;
     PsxCounters* h_cnt = nullptr;      // pinned
     bool counts_valid = false;
     bool counts_partial = false;       // only ext_total / ori_total valid (export fast path)
 
     void*       d_input_own = nullptr; size_t input_cap = 0;
+    // pageable caller memory is staged through a pinned buffer: hipMemcpyAsync from pageable memory took
+    // 4.9 ms for a 2 MB frame (measured), a host memcpy + DMA from pinned memory takes ~0.1 ms
+    void*       h_stage = nullptr;     size_t stage_cap = 0;
+    hipEvent_t  ev_upload = nullptr;   // the DMA out of h_stage has finished
     const void* d_input = nullptr;     int input_is_float = 0;
 
     float* d_pyr = nullptr;            size_t pyr_cap = 0;      // floats
@@ -298,6 +303,7 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     } while (0)
     PSX_HIPC(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_params), sizeof(PsxParams)));
+    PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_params_pin), sizeof(PsxParams), hipHostMallocDefault));
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), sizeof(PsxCounters)));
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_cnt), sizeof(PsxCounters), hipHostMallocDefault));
     PSX_HIPC(hipMemset(n->d_cnt, 0, sizeof(PsxCounters)));
@@ -317,6 +323,7 @@ int psx_destroy(psx_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->d_params); (void)hipFree(ctx->d_cnt);
+    if (ctx->h_params_pin) (void)hipHostFree(ctx->h_params_pin);
     if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
     if (ctx->x_registered_feat) (void)hipHostUnregister(ctx->x_host_feat);
     if (ctx->x_registered_desc) (void)hipHostUnregister(ctx->x_host_desc);
@@ -331,6 +338,8 @@ int psx_destroy(psx_ctx* ctx)
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
     if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
+    if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PSX_OK;
@@ -460,7 +469,23 @@ static int upload_common(psx_ctx* ctx, const void* host, int w, int h, int is_fl
         PSX_HIP(hipMalloc(&ctx->d_input_own, bytes + 64));
         ctx->input_cap = bytes;
     }
-    PSX_HIP(hipMemcpyAsync(ctx->d_input_own, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const void* src = host;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess || attr.type == hipMemoryTypeUnregistered) {
+        (void)hipGetLastError();
+        if (!ctx->ev_upload) PSX_HIP(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
+        else PSX_HIP(hipEventSynchronize(ctx->ev_upload));            // previous DMA out of the staging buffer
+        if (bytes > ctx->stage_cap) {
+            if (ctx->h_stage) PSX_HIP(hipHostFree(ctx->h_stage));
+            ctx->h_stage = nullptr; ctx->stage_cap = 0;
+            PSX_HIP(hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault));
+            ctx->stage_cap = bytes;
+        }
+        memcpy(ctx->h_stage, host, bytes);
+        src = ctx->h_stage;
+    }
+    PSX_HIP(hipMemcpyAsync(ctx->d_input_own, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (src == ctx->h_stage) PSX_HIP(hipEventRecord(ctx->ev_upload, ctx->stream));
     ctx->d_input = ctx->d_input_own;
     ctx->input_is_float = is_float;
     return PSX_OK;
@@ -773,7 +798,12 @@ int psx_attach_export(psx_ctx* ctx, psx_feature* host_features, int feature_capa
     P.x_counts = (ctx->x_dev_feat || ctx->x_dev_desc) ? ctx->h_xcnt : nullptr;
     P.x_feat_capacity = ctx->x_feat_cap;
     P.x_desc_capacity = ctx->x_desc_cap;
-    if (ctx->d_pyr) PSX_HIP(hipMemcpy(ctx->d_params, &P, sizeof(P), hipMemcpyHostToDevice));
+    if (ctx->d_pyr) {
+        // stream ordered, no host wait: the stream was drained above, so the pinned mirror is not in use,
+        // and the next frame's kernels are queued behind this copy
+        *ctx->h_params_pin = P;
+        PSX_HIP(hipMemcpyAsync(ctx->d_params, ctx->h_params_pin, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
+    }
     return PSX_OK;
 }
 
@@ -784,6 +814,22 @@ int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float
     if (d_features) *d_features = ctx->d_features;
     if (d_descriptors) *d_descriptors = ctx->d_desc;
     if (d_feat_to_ext) *d_feat_to_ext = ctx->d_feat_to_ext;
+    return PSX_OK;
+}
+
+int psx_host_alloc(size_t bytes, void** out)
+{
+    psx_ctx* ctx = nullptr;
+    if (!out) return PSX_ERR_INVALID;
+    PSX_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable));
+    return PSX_OK;
+}
+
+int psx_host_free(void* ptr)
+{
+    psx_ctx* ctx = nullptr;
+    if (!ptr) return PSX_OK;
+    PSX_HIP(hipHostFree(ptr));
     return PSX_OK;
 }
 

@@ -3,6 +3,8 @@
 //
 // usage: popsift_demo <w> <h> <raw-u8-or-f32-file> <out.txt> [--float] [--vlfeat|--opencv]
 //                     [--octaves N] [--repeat N] [--norm-multi M] [--classic] [--match <second-raw-file>]
+//                     [--bench N]   stream N frames through enqueue/get with at most 16 jobs outstanding and
+//                                   print the sustained rate (host images in, FeaturesHost out)
 // writes: one line per descriptor:  x y sigma orientation d0..d127  (full float precision)
 // --match: MatchingMode as in the reference's popsift-match (src/application/match.cpp:257-275): both images
 //          are extracted into FeaturesDev objects and lFeatures->match(rFeatures) prints one line per descriptor
@@ -11,6 +13,7 @@
 #include <popsift/sift_conf.h>
 #include <popsift/version.hpp>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +29,7 @@ int main( int argc, char** argv )
     bool is_float = false;
     int repeat = 1;
     const char* match_file = nullptr;
+    int bench = 0;
     popsift::Config config;
     for( int i = 5; i < argc; i++ ) {
         if( !strcmp( argv[i], "--float" ) ) is_float = true;
@@ -36,6 +40,7 @@ int main( int argc, char** argv )
         else if( !strcmp( argv[i], "--norm-multi" ) && i + 1 < argc ) config.setNormalizationMultiplier( atoi( argv[++i] ) );
         else if( !strcmp( argv[i], "--repeat" ) && i + 1 < argc ) repeat = atoi( argv[++i] );
         else if( !strcmp( argv[i], "--match" ) && i + 1 < argc ) match_file = argv[++i];
+        else if( !strcmp( argv[i], "--bench" ) && i + 1 < argc ) bench = atoi( argv[++i] );
     }
     std::vector<unsigned char> raw( (size_t)w * h * ( is_float ? 4 : 1 ) );
     {
@@ -64,6 +69,33 @@ int main( int argc, char** argv )
         fflush( stdout );
         delete lFeatures; delete rFeatures; delete lJob; delete rJob;
         msift.uninit();
+        return 0;
+    }
+
+    if( bench > 0 ) {
+        PopSift bsift( config, popsift::Config::ExtractingMode, is_float ? PopSift::FloatImages : PopSift::ByteImages );
+        std::queue<SiftJob*> q;
+        size_t kp = 0;
+        auto drain_one = [&]() {
+            SiftJob* j = q.front(); q.pop();
+            popsift::Features* fl = j->get();
+            if( fl ) { kp += fl->getFeatureCount(); delete fl; }
+            delete j;
+        };
+        auto submit = [&]() {
+            SiftJob* j = is_float ? bsift.enqueue( w, h, (const float*)raw.data() ) : bsift.enqueue( w, h, raw.data() );
+            if( j ) q.push( j );
+        };
+        for( int i = 0; i < 32; i++ ) { submit(); if( q.size() > 16 ) drain_one(); }       // warm-up
+        while( !q.empty() ) drain_one();
+        kp = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for( int i = 0; i < bench; i++ ) { submit(); if( q.size() > 16 ) drain_one(); }
+        while( !q.empty() ) drain_one();
+        const double dt = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+        printf( "bench: %d frames %dx%d in %.3f s: %.3f ms/frame, %.0f Mpix/s, %.0f keypoints/frame\n", bench, w, h, dt,
+                dt / bench * 1e3, (double)w * h * bench / dt / 1e6, (double)kp / bench );
+        bsift.uninit();
         return 0;
     }
 

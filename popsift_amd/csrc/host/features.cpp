@@ -2,11 +2,15 @@
 // (reference behaviour: features.cu:27-128, 306-330)
 #include <cstdio>
 #include "popsift/features.h"
+#include "host_pool.h"
 #include "popsift/sift_extremum.h"
 
 #include "popsift_hip.h"
 
 #include <cerrno>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <cmath>
 #include <cstdlib>
 #include <iomanip>
@@ -36,23 +40,89 @@ void* page_alloc( size_t bytes )
 FeaturesBase::FeaturesBase( ) : _num_ext( 0 ), _num_ori( 0 ) { }
 FeaturesBase::~FeaturesBase( ) = default;
 
-FeaturesHost::FeaturesHost( ) : _ext( nullptr ), _ori( nullptr ) { }
+// ---- buffer pools (host_pool.h) -------------------------------------------------------------------
+namespace pool {
+namespace {
+struct Pool
+{
+    std::mutex                            m;
+    std::vector<std::pair<void*, size_t>> free_list;
+    bool                                  pinned;
+    explicit Pool( bool p ) : pinned( p ) { }
 
-FeaturesHost::FeaturesHost( int num_ext, int num_ori ) : _ext( nullptr ), _ori( nullptr )
+    void* get( size_t bytes, size_t* cap )
+    {
+        if( bytes == 0 ) bytes = 1;
+        {
+            std::lock_guard<std::mutex> g( m );
+            int best = -1;
+            for( size_t i = 0; i < free_list.size(); i++ )
+                if( free_list[i].second >= bytes && free_list[i].second <= 4 * bytes + ( 4u << 20 ) &&
+                    ( best < 0 || free_list[i].second < free_list[best].second ) ) best = (int)i;
+            if( best >= 0 ) {
+                void* p = free_list[best].first; *cap = free_list[best].second;
+                free_list.erase( free_list.begin() + best );
+                return p;
+            }
+        }
+        const size_t mb = (size_t)1 << 20;
+        const size_t c = ( ( bytes + bytes / 4 + mb - 1 ) / mb ) * mb;       // 25 % slack, whole megabytes
+        void* p = nullptr;
+        if( pinned ) { if( psx_host_alloc( c, &p ) != PSX_OK ) return nullptr; }
+        else         { if( posix_memalign( &p, 4096, c ) != 0 ) return nullptr; }
+        *cap = c;
+        return p;
+    }
+    void put( void* p, size_t cap )
+    {
+        if( p == nullptr ) return;
+        {
+            std::lock_guard<std::mutex> g( m );
+            if( free_list.size() < 32 ) { free_list.emplace_back( p, cap ); return; }
+        }
+        if( pinned ) psx_host_free( p ); else free( p );
+    }
+};
+Pool& plain()  { static Pool* p = new Pool( false ); return *p; }     // never destroyed: objects may outlive main()
+Pool& pinned() { static Pool* p = new Pool( true );  return *p; }
+} // namespace
+void* get_plain( size_t bytes, size_t* cap )  { return plain().get( bytes, cap ); }
+void  put_plain( void* p, size_t cap )        { plain().put( p, cap ); }
+void* get_pinned( size_t bytes, size_t* cap ) { return pinned().get( bytes, cap ); }
+void  put_pinned( void* p, size_t cap )       { pinned().put( p, cap ); }
+} // namespace pool
+
+FeaturesHost::FeaturesHost( ) : _ext( nullptr ), _ori( nullptr ), _ext_cap( 0 ), _ori_cap( 0 ) { }
+
+FeaturesHost::FeaturesHost( int num_ext, int num_ori ) : _ext( nullptr ), _ori( nullptr ), _ext_cap( 0 ), _ori_cap( 0 )
 {
     reset( num_ext, num_ori );
 }
 
 FeaturesHost::~FeaturesHost( )
 {
-    free( _ext );
-    free( _ori );
+    release();
+}
+
+void FeaturesHost::release( )
+{
+    if( _ext_cap ) pool::put_plain( _ext, _ext_cap ); else free( _ext );
+    if( _ori_cap ) pool::put_pinned( _ori, _ori_cap ); else free( _ori );
+    _ext = nullptr; _ori = nullptr; _ext_cap = _ori_cap = 0;
+}
+
+void FeaturesHost::adopt( int num_ext, int num_ori, Feature* ext, size_t ext_cap, Descriptor* ori, size_t ori_cap )
+{
+    release();
+    _ext = ext; _ext_cap = ext_cap;
+    _ori = ori; _ori_cap = ori_cap;
+    setFeatureCount( num_ext );
+    setDescriptorCount( num_ori );
 }
 
 void FeaturesHost::reset( int num_ext, int num_ori )
 {
-    free( _ext ); _ext = nullptr;
-    free( _ori ); _ori = nullptr;
+    release();
 
     _ext = (Feature*)page_alloc( (size_t)num_ext * sizeof(Feature) );
     if( _ext == nullptr ) {

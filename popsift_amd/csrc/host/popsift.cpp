@@ -10,9 +10,16 @@
 //     fulfilled (the reference's extract loop has no try/catch and would std::terminate).
 #include "popsift/popsift.h"
 #include "popsift/features.h"
+#include "host_pool.h"
 
 #include "popsift_hip.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -59,7 +66,7 @@ void to_psx( const popsift::Config& c, psx_config& p )
 
 int pipe_depth()
 {
-    int d = 4;
+    int d = 8;
     if( const char* e = getenv( "POPSIFT_PIPE_DEPTH" ) ) d = atoi( e );
     return d < 1 ? 1 : ( d > 32 ? 32 : d );
 }
@@ -118,23 +125,34 @@ popsift::FeaturesDev*  SiftJob::getDev()  { return dynamic_cast<popsift::Feature
  *********************************************************************************/
 
 namespace {
-// one extraction context of the pipe: pyramid + stream + export window + the job it works on
+// one extraction context of the pipe: pyramid + stream + export targets + the job it works on
 struct Slot
 {
     psx_ctx*     ctx = nullptr;
-    SiftJob*     job = nullptr;
-    psx_feature* xfeat = nullptr;
-    float*       xdesc = nullptr;
+    SiftJob*     job = nullptr;        // non-null: reserved by the submit thread / frame in flight
+    psx_feature* xfeat = nullptr;      // pinned export window for the 52-byte feature records (per slot)
+    size_t       xfeat_cap = 0;        // bytes
+    float*       xdesc = nullptr;      // pinned descriptor buffer of the frame in flight (pool; handed to the result)
+    size_t       xdesc_cap = 0;        // bytes
+    int          desc_cap = 0;         // descriptors
 };
 } // namespace
 
 struct PopSift::Impl
 {
-
     popsift::SyncQueue<SiftJob*> queue;
-    std::unique_ptr<std::thread> worker;
+    std::unique_ptr<std::thread> worker;      // submit thread (upload + launch chain)
+    std::unique_ptr<std::thread> collector;   // result thread (wait, hand over buffers, fulfil jobs in FIFO order)
     std::vector<Slot>            slots;
     std::deque<int>              inflight;    // slot indices, oldest first
+    std::mutex                   m;           // guards inflight, Slot::job, submit_done
+    std::condition_variable      cv_inflight, cv_free;
+    bool                         submit_done = false;
+    std::atomic<int>             want_desc{ 32768 };   // descriptor capacity of the next export buffer
+    // POPSIFT_PROFILE=1: seconds spent per phase, printed by uninit()
+    bool   prof = false;
+    double t_slot = 0, t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0;
+    int    n_done = 0;
     std::mutex                   cfg_mutex;
     bool                         contexts_exist = false;
     bool                         stopped = false;
@@ -260,26 +278,40 @@ void check( psx_ctx* ctx, int rc, const char* what )
     throw std::runtime_error( msg );
 }
 
-popsift::FeaturesHost* collect_host( Slot& s )
+inline double pnow() { return std::chrono::duration<double>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
+
+popsift::FeaturesHost* collect_host( Slot& s, std::atomic<int>& want_desc, double* t_frame )
 {
     int ne = 0, no = 0;
-    check( s.ctx, psx_counts( s.ctx, &ne, &no ), "psx_counts" );
+    const double t0 = pnow();
+    check( s.ctx, psx_counts( s.ctx, &ne, &no ), "psx_counts" );       // waits for the frame
+    *t_frame += pnow() - t0;
     if( ne == 0 || no == 0 ) {
         if( no == 0 ) cerr << "Warning: no descriptors extracted" << endl;   // sift_desc.cu:88-92
     }
-    popsift::FeaturesHost* f = new popsift::FeaturesHost( ne, no );
+    want_desc = std::max( 32768, no + no / 2 );
+    popsift::FeaturesHost* f = new popsift::FeaturesHost();
+    size_t ext_cap = 0;
+    popsift::Feature* dst = (popsift::Feature*)popsift::pool::get_plain( (size_t)std::max( ne, 1 ) * sizeof(popsift::Feature), &ext_cap );
+    if( dst == nullptr ) { delete f; throw std::runtime_error( "out of host memory for features" ); }
     const psx_feature* src = s.xfeat;
     std::vector<psx_feature> tmp;
-    if( ne > EXPORT_FEATURES || no > EXPORT_DESCRIPTORS ) {
-        // result larger than the export window: ordinary download of the complete device copy
+    popsift::Descriptor* base = nullptr;
+    if( ne > EXPORT_FEATURES || no > s.desc_cap ) {
+        // result larger than the export targets: ordinary download of the complete device copy
+        size_t cap = 0;
+        base = (popsift::Descriptor*)popsift::pool::get_pinned( (size_t)std::max( no, 1 ) * sizeof(popsift::Descriptor), &cap );
+        if( base == nullptr ) { popsift::pool::put_plain( dst, ext_cap ); delete f; throw std::runtime_error( "out of host memory for descriptors" ); }
+        f->adopt( ne, no, dst, ext_cap, base, cap );
         tmp.resize( ne );
-        check( s.ctx, psx_download( s.ctx, tmp.data(), ne, (float*)f->getDescriptors(), no ), "psx_download" );
+        check( s.ctx, psx_download( s.ctx, tmp.data(), ne, (float*)base, no ), "psx_download" );
         src = tmp.data();
-    } else if( no > 0 ) {
-        memcpy( f->getDescriptors(), s.xdesc, (size_t)no * sizeof(popsift::Descriptor) );
+    } else {
+        // the GPU wrote the descriptors straight into s.xdesc: the result object takes the buffer over
+        base = (popsift::Descriptor*)s.xdesc;
+        f->adopt( ne, no, dst, ext_cap, base, s.xdesc_cap );
+        s.xdesc = nullptr; s.xdesc_cap = 0; s.desc_cap = 0;
     }
-    popsift::Feature*    dst  = f->getFeatures();
-    popsift::Descriptor* base = f->getDescriptors();
     for( int i = 0; i < ne; i++ ) {
         const psx_feature& a = src[i];
         popsift::Feature&  b = dst[i];
@@ -308,38 +340,59 @@ popsift::FeaturesDev* collect_dev( Slot& s, int device )
 
 } // namespace
 
-void PopSift::dispatchLoop( )
+// Two host threads per PopSift, like the reference's upload / extract-download pair (popsift.cpp:276-344):
+//   dispatchLoop (submit)  pulls jobs, reserves a free context, uploads the image (pinned staging inside
+//                          the C-ABI) and queues the whole kernel chain; never waits for a frame
+//   collectLoop            waits for the OLDEST frame in flight, wraps the buffers the GPU has written into
+//                          a FeaturesHost (no copy of the descriptors) and fulfils the job
+void PopSift::collectLoop( )
 {
     Impl& p = *_impl;
-    const int depth = pipe_depth();
-
-    auto finish_oldest = [&]() {
-        const int si = p.inflight.front();
-        p.inflight.pop_front();
+    for( ;; ) {
+        int si;
+        {
+            std::unique_lock<std::mutex> lk( p.m );
+            p.cv_inflight.wait( lk, [&]{ return !p.inflight.empty() || p.submit_done; } );
+            if( p.inflight.empty() ) break;
+            si = p.inflight.front();
+            p.inflight.pop_front();
+        }
         Slot& s = p.slots[si];
         SiftJob* job = s.job;
-        s.job = nullptr;
         popsift::FeaturesBase* f = nullptr;
+        const double tc0 = pnow();
+        double tf = 0;
         try {
-            if( _proc_mode == popsift::Config::ExtractingMode ) f = collect_host( s );
+            if( _proc_mode == popsift::Config::ExtractingMode ) f = collect_host( s, p.want_desc, &tf );
             else                                                f = collect_dev( s, _device );
         } catch( ... ) {
             job->setError( std::current_exception() );
             f = nullptr;
         }
+        p.t_frame += tf; p.t_wrap += pnow() - tc0 - tf; p.n_done++;
+        {
+            std::lock_guard<std::mutex> g( p.m );
+            s.job = nullptr;
+        }
+        p.cv_free.notify_one();
         job->setFeatures( f );
-    };
+    }
+}
+
+void PopSift::dispatchLoop( )
+{
+    Impl& p = *_impl;
+    const int depth = pipe_depth();
+    {
+        std::lock_guard<std::mutex> g( p.m );
+        p.submit_done = false;
+    }
+    p.collector.reset( new std::thread( &PopSift::collectLoop, this ) );
 
     for( ;; ) {
-        SiftJob* job = nullptr;
-        if( p.inflight.empty() ) {
-            job = p.queue.pull();
-        } else if( !p.queue.try_pull( job ) ) {
-            finish_oldest();            // nothing new to submit: deliver the oldest frame
-            continue;
-        }
+        SiftJob* job = p.queue.pull();
         if( job == nullptr ) break;     // shutdown sentinel
-
+        int si = -1;
         try {
             if( !p.contexts_exist ) {
                 std::lock_guard<std::mutex> g( p.cfg_mutex );
@@ -353,43 +406,72 @@ void PopSift::dispatchLoop( )
                         throw std::runtime_error( std::string( "psx_create failed:\n    " ) + ( m ? m : "" ) );
                     }
                     if( _proc_mode == popsift::Config::ExtractingMode ) {
-                        const size_t page = (size_t)sysconf( _SC_PAGESIZE );
-                        void *xf = nullptr, *xd = nullptr;
-                        if( posix_memalign( &xf, page, (size_t)EXPORT_FEATURES * sizeof(psx_feature) ) != 0 ||
-                            posix_memalign( &xd, page, (size_t)EXPORT_DESCRIPTORS * 128 * sizeof(float) ) != 0 )
-                            throw std::runtime_error( "out of host memory for export buffers" );
-                        s.xfeat = (psx_feature*)xf; s.xdesc = (float*)xd;
-                        check( s.ctx, psx_attach_export( s.ctx, s.xfeat, EXPORT_FEATURES, s.xdesc, EXPORT_DESCRIPTORS ),
-                               "psx_attach_export" );
+                        s.xfeat = (psx_feature*)popsift::pool::get_pinned( (size_t)EXPORT_FEATURES * sizeof(psx_feature), &s.xfeat_cap );
+                        if( s.xfeat == nullptr ) throw std::runtime_error( "out of host memory for export buffers" );
                     }
                 }
                 p.contexts_exist = true;
             }
-            if( (int)p.inflight.size() == depth ) finish_oldest();
-
-            // a free slot: any slot without a job
-            int si = -1;
-            for( int i = 0; i < depth; i++ ) if( p.slots[i].job == nullptr ) { si = i; break; }
+            const double ts0 = pnow();
+            {
+                // a free context: one without a job
+                std::unique_lock<std::mutex> lk( p.m );
+                p.cv_free.wait( lk, [&]{ for( int i = 0; i < depth; i++ ) if( p.slots[i].job == nullptr ) return true; return false; } );
+                for( int i = 0; i < depth; i++ ) if( p.slots[i].job == nullptr ) { si = i; break; }
+                p.slots[si].job = job;
+            }
             Slot& s = p.slots[si];
+            const double ts1 = pnow();
+            if( _proc_mode == popsift::Config::ExtractingMode && s.xdesc == nullptr ) {
+                // the previous result took this context's descriptor buffer with it: attach a fresh one
+                const int want = p.want_desc;
+                s.xdesc = (float*)popsift::pool::get_pinned( (size_t)want * sizeof(popsift::Descriptor), &s.xdesc_cap );
+                if( s.xdesc == nullptr ) throw std::runtime_error( "out of host memory for export buffers" );
+                s.desc_cap = (int)std::min<size_t>( s.xdesc_cap / sizeof(popsift::Descriptor), (size_t)1 << 30 );
+                check( s.ctx, psx_attach_export( s.ctx, s.xfeat, EXPORT_FEATURES, s.xdesc, s.desc_cap ), "psx_attach_export" );
+            }
+            const double ts2 = pnow();
             if( job->isFloat() )
                 check( s.ctx, psx_upload_f32( s.ctx, (const float*)job->getData(), job->getWidth(), job->getHeight() ), "psx_upload_f32" );
             else
                 check( s.ctx, psx_upload_u8( s.ctx, job->getData(), job->getWidth(), job->getHeight() ), "psx_upload_u8" );
+            const double ts3 = pnow();
             check( s.ctx, psx_extract( s.ctx ), "psx_extract" );
-            s.job = job;
-            p.inflight.push_back( si );
+            const double ts4 = pnow();
+            p.t_slot += ts1 - ts0; p.t_attach += ts2 - ts1; p.t_upload += ts3 - ts2; p.t_submit += ts4 - ts3;
+            {
+                std::lock_guard<std::mutex> g( p.m );
+                p.inflight.push_back( si );
+            }
+            p.cv_inflight.notify_one();
         } catch( ... ) {
+            if( si >= 0 ) {
+                { std::lock_guard<std::mutex> g( p.m ); p.slots[si].job = nullptr; }
+                p.cv_free.notify_one();
+            }
             job->setError( std::current_exception() );
             job->setFeatures( nullptr );
         }
     }
 
-    while( !p.inflight.empty() ) finish_oldest();
+    {
+        std::lock_guard<std::mutex> g( p.m );
+        p.submit_done = true;
+    }
+    p.cv_inflight.notify_all();
+    if( p.collector ) { p.collector->join(); p.collector.reset(); }
+    if( getenv( "POPSIFT_PROFILE" ) != nullptr && p.n_done > 0 ) {
+        const double k = 1e3 / p.n_done;
+        fprintf( stderr, "[popsift profile] %d frames, ms per frame: submit thread: wait-for-context %.3f attach %.3f upload %.3f launch %.3f | "
+                         "collect thread: wait-for-frame %.3f wrap %.3f\n",
+                 p.n_done, p.t_slot * k, p.t_attach * k, p.t_upload * k, p.t_submit * k, p.t_frame * k, p.t_wrap * k );
+    }
 
     // jobs enqueued after the sentinel are never processed; release the contexts
     for( auto& s : p.slots ) {
         if( s.ctx ) { psx_attach_export( s.ctx, nullptr, 0, nullptr, 0 ); psx_destroy( s.ctx ); }
-        free( s.xfeat ); free( s.xdesc );
+        popsift::pool::put_pinned( s.xfeat, s.xfeat_cap );
+        popsift::pool::put_pinned( s.xdesc, s.xdesc_cap );
         s = Slot();
     }
     p.contexts_exist = false;

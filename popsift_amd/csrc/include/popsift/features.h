@@ -48,11 +48,15 @@ public:
     inline void setDescriptorCount( int num_ori ) { _num_ori = num_ori; }
 };
 
-/// Host-resident result: page-aligned arrays owned by the object.
+/// Host-resident result: arrays owned by the object.  Objects produced by PopSift hold pooled buffers
+/// (the descriptor array is the pinned buffer the GPU wrote the descriptors into: no copy); they go back
+/// to a process-wide pool when the object is deleted.
 class FeaturesHost : public FeaturesBase
 {
     Feature*     _ext;
     Descriptor*  _ori;
+    size_t       _ext_cap;   // bytes; 0: _ext came from posix_memalign
+    size_t       _ori_cap;   // bytes; 0: _ori came from posix_memalign
 
 public:
     FeaturesHost( );
@@ -77,8 +81,12 @@ public:
 
     void print( std::ostream& ostr, bool write_as_uchar ) const;
 
+    /// internal (PopSift): take ownership of pooled buffers (see host_pool.h); caps in bytes
+    void adopt( int num_ext, int num_ori, Feature* ext, size_t ext_cap, Descriptor* ori, size_t ori_cap );
+
 protected:
     friend class Pyramid;
+    void release( );
 };
 
 using Features = FeaturesHost;

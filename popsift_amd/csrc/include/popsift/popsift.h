@@ -123,6 +123,7 @@ private:
     struct Impl;
     void start();
     void dispatchLoop();
+    void collectLoop();
 
     std::unique_ptr<Impl> _impl;
     popsift::Config _config;
