@@ -497,3 +497,29 @@ def test_pipeline_plus_matcher_recovers_a_known_shift(capi):
     delta = xb[mm[acc, 0]] - xa[acc]
     good = (np.abs(delta[:, 0] - 5.0) < 0.5) & (np.abs(delta[:, 1] - 3.0) < 0.5)
     assert good.mean() > 0.97, (good.mean(), acc.sum())
+
+
+def test_cpp_streaming_reuses_result_buffers(capi, tmp_path):
+    """PopSift::enqueue / SiftJob::get streaming (demo --bench): 60 frames through the two host threads with
+    pooled, GPU-written result buffers; every frame must deliver the same number of keypoints as the C-ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo = os.path.join(root, "popsift_amd", "lib", "popsift_demo")
+    w, h = 512, 384
+    img = synth(w, h, 404)
+    raw = tmp_path / "in.raw"
+    raw.write_bytes(img.tobytes())
+    ctx = capi.Context(capi.default_config(octaves=4))
+    ctx.upload(img)
+    ctx.extract()
+    ne, _ = ctx.counts()
+    ctx.close()
+    for depth in ("1", "3"):
+        env = dict(os.environ, POPSIFT_PIPE_DEPTH=depth)
+        p = subprocess.run([demo, str(w), str(h), str(raw), str(tmp_path / "unused.txt"), "--octaves", "4", "--bench", "60"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stdout
+        line = [l for l in p.stdout.splitlines() if l.startswith("bench:")]
+        assert len(line) == 1, p.stdout
+        assert int(float(line[0].split(",")[-1].split()[0])) == ne, line[0]
