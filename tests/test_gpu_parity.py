@@ -523,3 +523,28 @@ def test_cpp_streaming_reuses_result_buffers(capi, tmp_path):
         line = [l for l in p.stdout.splitlines() if l.startswith("bench:")]
         assert len(line) == 1, p.stdout
         assert int(float(line[0].split(",")[-1].split()[0])) == ne, line[0]
+
+
+@pytest.mark.parametrize("kw", [dict(octaves=3, levels=4), dict(octaves=3, levels=2, sigma=1.4),
+                                dict(octaves=4, levels=5, upscale_factor=0.0),
+                                dict(octaves=3, edge_limit=6.0, threshold=0.02, assume_initial_blur=0)])
+def test_non_default_levels_and_thresholds(oracle, capi, kw):
+    """Levels != 3 take the generic staging path of k_extrema and other blur radii; thresholds, edge limit and
+    the initial-blur switch change tables and tests.  Planes bit-exact, features within tolerance."""
+    img = synth(400, 300, 2024)
+    ocfg, gcfg = _cfgs(oracle, capi, kw)
+    ref = oracle.run(ocfg, img)
+    ctx = capi.Context(gcfg)
+    ctx.upload(img)
+    ctx.extract()
+    assert ctx.num_levels == ref.num_levels
+    for o in range(ref.num_octaves):
+        for l in range(ref.num_levels):
+            assert np.array_equal(ctx.dump_plane(capi.PLANE_GAUSS, o, l), ref.gauss(o, l)), (o, l)
+        a, b = sort_iext(ref.iext(o)), sort_iext(ctx.dump_iext(o))
+        assert len(a) == len(b)
+        assert np.array_equal(a["xpos"], b["xpos"]) and np.array_equal(a["lpos"], b["lpos"])
+    fb, db = ctx.download()
+    m = match_features(ref.features(), ref.descriptors(), fb, db)
+    assert len(fb) == ref.ext_total and m["kp_match"] >= 0.999 and m["ori_match"] >= 0.995 and m["desc_match"] >= 0.995, m
+    ctx.close()
