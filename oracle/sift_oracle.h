@@ -32,6 +32,8 @@
  * The grid filter is pinned the same way: s_filtergrid.cu itself is compiled against a serial
  * stand-in for the Thrust calls it makes (oracle/ref_shim/thrust_shim.h; sort_by_key = stable sort,
  * which is what Thrust's radix / merge sorts are) -- all three sort modes, live and as fixtures.
+ * The 2-NN matcher (osift_match) is pinned against FeaturesDev::match of the reference (features.cu on the
+ * shim; its printed result is parsed): indices and accept flags equal, distances to the printed precision.
  * See DESIGN.md "Oracle".
  */
 #ifndef SIFT_ORACLE_H
