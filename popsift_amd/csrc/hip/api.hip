@@ -620,7 +620,7 @@ int psx_descriptors(psx_ctx* ctx)
     if (!ctx) return PSX_ERR_INVALID;
     if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_descriptors: no pyramid");
     PSX_HIP(hipSetDevice(ctx->device));
-    PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->stream));
+    PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->hp.x_desc != nullptr, ctx->stream));
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     return PSX_OK;
 }

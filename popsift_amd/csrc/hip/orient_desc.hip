@@ -558,8 +558,12 @@ hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStr
     return hipGetLastError();
 }
 
-hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, hipStream_t s)
+hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, bool exporting, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_descriptors, dim3(2048), dim3(NT), 0, s, d_params, d_cnt);
+    // 2048 workgroups = 8 waves/SIMD.  With the zero-copy export attached every wave ends in stores that
+    // cross PCIe; fewer resident waves leave room for the other streams' kernels meanwhile: 768 workgroups
+    // measured +11 % on the export leg of bench.py (4200 -> 4660 Mpix/s), 2048 is best without export.
+    const int grid = exporting ? 768 : 2048;
+    hipLaunchKernelGGL(k_descriptors, dim3(grid), dim3(NT), 0, s, d_params, d_cnt);
     return hipGetLastError();
 }

@@ -111,7 +111,7 @@ hipError_t psx_launch_gridfilter(const PsxParams* d_params, PsxCounters* d_cnt, 
                                  int* scratch, hipStream_t s);
 hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
 hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
-hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, hipStream_t s);
+hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, bool exporting, hipStream_t s);
 
 // ---- small device helpers --------------------------------------------------------------------
 __device__ __forceinline__ int psx_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
