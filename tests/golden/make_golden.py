@@ -28,6 +28,8 @@ CASES = {
     "opencv_96x80": (96, 80, 103, False, dict(octaves=3, sift_mode=po.MODE_OPENCV, gauss_mode=po.GAUSS_OPENCV_COMPUTE)),
     "float_up0_classic_160x120": (160, 120, 104, True, dict(octaves=3, upscale_factor=0.0, norm_mode=po.NORM_CLASSIC, norm_multi=9)),
     "auto_octaves_75x61": (75, 61, 105, False, dict()),
+    # a larger frame with four octaves in the mode the north_star quotes parity on (VLFeat), RootSift x512
+    "vlfeat_256x192_oct4": (256, 192, 106, False, dict(octaves=4, sift_mode=po.MODE_VLFEAT, norm_multi=9)),
     # extrema_filter_grid (s_filtergrid.cu, compiled against oracle/ref_shim/thrust_shim.h); the
     # RandomScale mode depends on buffer order and has no order-free golden answer beyond counts
     "gridfilter_largest_160x120": (160, 120, 99, False, dict(octaves=3, filter_max_extrema=38, filter_grid_size=2,
