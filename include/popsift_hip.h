@@ -171,6 +171,11 @@ int psx_descriptors(psx_ctx* ctx);
 /* step1 + step2 in one call (popsift.cpp:321-324). */
 int psx_extract(psx_ctx* ctx);
 
+/* How psx_counts / psx_sync-like waits of this context wait for the GPU: 0 (default) = hipStreamSynchronize
+ * (lowest latency, the calling thread may spin), 1 = sleep on a blocking event (for hosts that run one
+ * thread per context). */
+int psx_set_wait_mode(psx_ctx* ctx, int blocking);
+
 /* Waits for everything queued on the context's stream. */
 int psx_sync(psx_ctx* ctx);
 

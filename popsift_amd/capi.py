@@ -55,7 +55,7 @@ SYMBOLS = [
     "psx_octave_dims", "psx_upload_u8", "psx_upload_f32", "psx_set_input_dev", "psx_build_pyramid",
     "psx_find_extrema", "psx_orientation", "psx_descriptors", "psx_extract", "psx_sync", "psx_counts",
     "psx_download", "psx_attach_export", "psx_device_results", "psx_dump_plane", "psx_dump_iext", "psx_dump_extrema",
-    "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
+    "psx_set_wait_mode", "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
     "psx_host_alloc", "psx_host_free", "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_dev_write", "psx_clone_results", "psx_match", "psx_device_count", "psx_device_info",
 ]
 

@@ -135,6 +135,8 @@ struct psx_ctx {
     int* h_xcnt = nullptr;             // pinned [2]
 
     bool timers = false;
+    bool blocking_wait = false;        // psx_set_wait_mode: sleep on an event instead of spinning in hipStreamSynchronize
+    hipEvent_t ev_wait = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
 };
@@ -338,6 +340,7 @@ int psx_destroy(psx_ctx* ctx)
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
     if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
+    if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -557,12 +560,24 @@ int psx_build_pyramid(psx_ctx* ctx)
     return PSX_OK;
 }
 
+static int wait_stream(psx_ctx* ctx)
+{
+    if (ctx->blocking_wait) {
+        if (!ctx->ev_wait) PSX_HIP(hipEventCreateWithFlags(&ctx->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
+        PSX_HIP(hipEventRecord(ctx->ev_wait, ctx->stream));
+        PSX_HIP(hipEventSynchronize(ctx->ev_wait));
+        return PSX_OK;
+    }
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    return PSX_OK;
+}
+
 // Pyramid::extrema_filter_grid (s_filtergrid.cu:113-325), gated as in s_orientation.cu:378-383.
 // Like the reference, the host reads the per-octave counts once to decide and to size the sort.
 static int grid_filter(psx_ctx* ctx)
 {
     PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
-    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
     int total = 0;
     for (int o = 0; o < ctx->hp.num_octaves; o++) total += imin(ctx->h_cnt->ext_ct[o], ctx->cfg.max_extrema);
     const int fmax = ctx->cfg.filter_max_extrema;
@@ -693,7 +708,7 @@ static int fetch_counts_full(psx_ctx* ctx)
     if (ctx->counts_valid && !ctx->counts_partial) return PSX_OK;
     PSX_HIP(hipSetDevice(ctx->device));
     PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
-    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
     ctx->counts_valid = true;
     ctx->counts_partial = false;
     return PSX_OK;
@@ -705,7 +720,7 @@ static int fetch_counts(psx_ctx* ctx)
     PSX_HIP(hipSetDevice(ctx->device));
     if (ctx->hp.x_counts != nullptr) {
         // export attached: the scan kernel already deposited the counters in pinned memory
-        PSX_HIP(hipStreamSynchronize(ctx->stream));
+        { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
         ctx->h_cnt->ext_total = ctx->h_xcnt[0];
         ctx->h_cnt->ori_total = ctx->h_xcnt[1];
         ctx->counts_valid = true;
@@ -713,7 +728,7 @@ static int fetch_counts(psx_ctx* ctx)
         return PSX_OK;
     }
     PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
-    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
     ctx->counts_valid = true;
     ctx->counts_partial = false;
     return PSX_OK;
@@ -966,6 +981,13 @@ int psx_dump_extrema(psx_ctx* ctx, psx_extremum* host_out, int capacity, int* co
         n = imin(n, capacity);
         if (n > 0) PSX_HIP(hipMemcpy(host_out, ctx->d_extrema, (size_t)n * sizeof(psx_extremum), hipMemcpyDeviceToHost));
     }
+    return PSX_OK;
+}
+
+int psx_set_wait_mode(psx_ctx* ctx, int blocking)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    ctx->blocking_wait = blocking != 0;
     return PSX_OK;
 }
 

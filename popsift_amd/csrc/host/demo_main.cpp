@@ -3,6 +3,7 @@
 //
 // usage: popsift_demo <w> <h> <raw-u8-or-f32-file> <out.txt> [--float] [--vlfeat|--opencv]
 //                     [--octaves N] [--repeat N] [--norm-multi M] [--classic] [--match <second-raw-file>]
+//                     [--filter-max N] grid filter as AliceVision configures it (LargestScaleFirst)
 //                     [--bench N]   stream N frames through enqueue/get with at most 16 jobs outstanding and
 //                                   print the sustained rate (host images in, FeaturesHost out)
 // writes: one line per descriptor:  x y sigma orientation d0..d127  (full float precision)
@@ -41,6 +42,10 @@ int main( int argc, char** argv )
         else if( !strcmp( argv[i], "--repeat" ) && i + 1 < argc ) repeat = atoi( argv[++i] );
         else if( !strcmp( argv[i], "--match" ) && i + 1 < argc ) match_file = argv[++i];
         else if( !strcmp( argv[i], "--bench" ) && i + 1 < argc ) bench = atoi( argv[++i] );
+        else if( !strcmp( argv[i], "--filter-max" ) && i + 1 < argc ) {     // AliceVision: setFilterMaxExtrema + LargestScaleFirst
+            config.setFilterMaxExtrema( atoi( argv[++i] ) );
+            config.setFilterSorting( popsift::Config::LargestScaleFirst );
+        }
     }
     std::vector<unsigned char> raw( (size_t)w * h * ( is_float ? 4 : 1 ) );
     {

@@ -125,12 +125,11 @@ popsift::FeaturesDev*  SiftJob::getDev()  { return dynamic_cast<popsift::Feature
  *********************************************************************************/
 
 namespace {
-// one extraction context of the pipe: pyramid + stream + export targets + the job it works on
+// one extraction context of the pipe: pyramid + stream + export targets, owned by one worker thread
 struct Slot
 {
     psx_ctx*     ctx = nullptr;
-    SiftJob*     job = nullptr;        // non-null: reserved by the submit thread / frame in flight
-    psx_feature* xfeat = nullptr;      // pinned export window for the 52-byte feature records (per slot)
+    psx_feature* xfeat = nullptr;      // pinned export window for the 52-byte feature records
     size_t       xfeat_cap = 0;        // bytes
     float*       xdesc = nullptr;      // pinned descriptor buffer of the frame in flight (pool; handed to the result)
     size_t       xdesc_cap = 0;        // bytes
@@ -140,22 +139,15 @@ struct Slot
 
 struct PopSift::Impl
 {
-    popsift::SyncQueue<SiftJob*> queue;
-    std::unique_ptr<std::thread> worker;      // submit thread (upload + launch chain)
-    std::unique_ptr<std::thread> collector;   // result thread (wait, hand over buffers, fulfil jobs in FIFO order)
-    std::vector<Slot>            slots;
-    std::deque<int>              inflight;    // slot indices, oldest first
-    std::mutex                   m;           // guards inflight, Slot::job, submit_done
-    std::condition_variable      cv_inflight, cv_free;
-    bool                         submit_done = false;
-    std::atomic<int>             want_desc{ 32768 };   // descriptor capacity of the next export buffer
-    // POPSIFT_PROFILE=1: seconds spent per phase, printed by uninit()
-    bool   prof = false;
-    double t_slot = 0, t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0;
-    int    n_done = 0;
+    popsift::SyncQueue<SiftJob*>             queue;
+    std::vector<std::unique_ptr<std::thread>> workers;   // one per context
+    std::atomic<int>             want_desc{ 32768 };     // descriptor capacity of the next export buffer
     std::mutex                   cfg_mutex;
-    bool                         contexts_exist = false;
-    bool                         stopped = false;
+    std::atomic<bool>            contexts_exist{ false };
+    // POPSIFT_PROFILE=1: seconds spent per phase (all workers), printed by uninit()
+    std::mutex                   prof_mutex;
+    double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0;
+    int    n_done = 0;
 };
 
 PopSift::PopSift( const popsift::Config& config, popsift::Config::ProcessingMode mode, ImageMode imode, int device )
@@ -178,7 +170,13 @@ PopSift::~PopSift()
 
 void PopSift::start()
 {
-    _impl->worker.reset( new std::thread( &PopSift::dispatchLoop, this ) );
+    // One worker thread per context (POPSIFT_PIPE_DEPTH, default 8).  A worker takes the next job, uploads,
+    // queues the whole kernel chain, sleeps until ITS frame is done and fulfils the job: a host-side wait
+    // inside the chain (the grid filter reads the extrema counts, as in the reference) stalls one worker,
+    // not the pipe -- the other contexts keep the GPU busy.
+    const int depth = pipe_depth();
+    for( int i = 0; i < depth; i++ )
+        _impl->workers.emplace_back( new std::thread( &PopSift::dispatchLoop, this ) );
 }
 
 bool PopSift::configure( const popsift::Config& config, bool /*force*/ )
@@ -196,8 +194,20 @@ void PopSift::uninit( )
         std::cerr << "[warning] Attempt to release resources from an uninitialized instance" << std::endl;
         return;
     }
-    _impl->queue.push( nullptr );                       // shutdown sentinel (popsift.cpp:486)
-    if( _impl->worker ) { _impl->worker->join(); _impl->worker.reset(); }
+    _impl->queue.push( nullptr );                       // shutdown sentinel (popsift.cpp:486), passed on by each worker
+    for( auto& w : _impl->workers ) if( w ) w->join();
+    _impl->workers.clear();
+    {
+        SiftJob* j = nullptr;                           // swallow the sentinel the last worker passed on
+        while( _impl->queue.try_pull( j ) ) { }
+    }
+    if( getenv( "POPSIFT_PROFILE" ) != nullptr && _impl->n_done > 0 ) {
+        const double k = 1e3 / _impl->n_done;
+        fprintf( stderr, "[popsift profile] %d frames, host ms per frame (per worker thread): attach %.3f upload %.3f launch %.3f "
+                         "wait-for-frame %.3f wrap %.3f\n", _impl->n_done, _impl->t_attach * k, _impl->t_upload * k,
+                 _impl->t_submit * k, _impl->t_frame * k, _impl->t_wrap * k );
+    }
+    _impl->contexts_exist = false;
     _isInit = false;
 }
 
@@ -340,88 +350,37 @@ popsift::FeaturesDev* collect_dev( Slot& s, int device )
 
 } // namespace
 
-// Two host threads per PopSift, like the reference's upload / extract-download pair (popsift.cpp:276-344):
-//   dispatchLoop (submit)  pulls jobs, reserves a free context, uploads the image (pinned staging inside
-//                          the C-ABI) and queues the whole kernel chain; never waits for a frame
-//   collectLoop            waits for the OLDEST frame in flight, wraps the buffers the GPU has written into
-//                          a FeaturesHost (no copy of the descriptors) and fulfils the job
-void PopSift::collectLoop( )
-{
-    Impl& p = *_impl;
-    for( ;; ) {
-        int si;
-        {
-            std::unique_lock<std::mutex> lk( p.m );
-            p.cv_inflight.wait( lk, [&]{ return !p.inflight.empty() || p.submit_done; } );
-            if( p.inflight.empty() ) break;
-            si = p.inflight.front();
-            p.inflight.pop_front();
-        }
-        Slot& s = p.slots[si];
-        SiftJob* job = s.job;
-        popsift::FeaturesBase* f = nullptr;
-        const double tc0 = pnow();
-        double tf = 0;
-        try {
-            if( _proc_mode == popsift::Config::ExtractingMode ) f = collect_host( s, p.want_desc, &tf );
-            else                                                f = collect_dev( s, _device );
-        } catch( ... ) {
-            job->setError( std::current_exception() );
-            f = nullptr;
-        }
-        p.t_frame += tf; p.t_wrap += pnow() - tc0 - tf; p.n_done++;
-        {
-            std::lock_guard<std::mutex> g( p.m );
-            s.job = nullptr;
-        }
-        p.cv_free.notify_one();
-        job->setFeatures( f );
-    }
-}
-
 void PopSift::dispatchLoop( )
 {
     Impl& p = *_impl;
-    const int depth = pipe_depth();
-    {
-        std::lock_guard<std::mutex> g( p.m );
-        p.submit_done = false;
-    }
-    p.collector.reset( new std::thread( &PopSift::collectLoop, this ) );
+    Slot s;
+    double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0; int n_done = 0;
 
     for( ;; ) {
         SiftJob* job = p.queue.pull();
-        if( job == nullptr ) break;     // shutdown sentinel
-        int si = -1;
+        if( job == nullptr ) { p.queue.push( nullptr ); break; }      // pass the shutdown sentinel on
+
+        popsift::FeaturesBase* f = nullptr;
         try {
-            if( !p.contexts_exist ) {
-                std::lock_guard<std::mutex> g( p.cfg_mutex );
+            if( s.ctx == nullptr ) {
                 psx_config pc;
-                to_psx( _config, pc );
-                p.slots.resize( depth );
-                for( int i = 0; i < depth; i++ ) {
-                    Slot& s = p.slots[i];
-                    if( psx_create( _device, &pc, &s.ctx ) != PSX_OK ) {
-                        const char* m = psx_last_error( nullptr );
-                        throw std::runtime_error( std::string( "psx_create failed:\n    " ) + ( m ? m : "" ) );
-                    }
-                    if( _proc_mode == popsift::Config::ExtractingMode ) {
-                        s.xfeat = (psx_feature*)popsift::pool::get_pinned( (size_t)EXPORT_FEATURES * sizeof(psx_feature), &s.xfeat_cap );
-                        if( s.xfeat == nullptr ) throw std::runtime_error( "out of host memory for export buffers" );
-                    }
+                {
+                    std::lock_guard<std::mutex> g( p.cfg_mutex );   // configure() is refused from now on (popsift.cpp:81-83)
+                    p.contexts_exist = true;
+                    to_psx( _config, pc );
                 }
-                p.contexts_exist = true;
+                if( psx_create( _device, &pc, &s.ctx ) != PSX_OK ) {
+                    const char* m = psx_last_error( nullptr );
+                    s.ctx = nullptr;
+                    throw std::runtime_error( std::string( "psx_create failed:\n    " ) + ( m ? m : "" ) );
+                }
+                psx_set_wait_mode( s.ctx, 1 );                       // sleep, do not spin: there are PIPE_DEPTH of us
+                if( _proc_mode == popsift::Config::ExtractingMode ) {
+                    s.xfeat = (psx_feature*)popsift::pool::get_pinned( (size_t)EXPORT_FEATURES * sizeof(psx_feature), &s.xfeat_cap );
+                    if( s.xfeat == nullptr ) throw std::runtime_error( "out of host memory for export buffers" );
+                }
             }
-            const double ts0 = pnow();
-            {
-                // a free context: one without a job
-                std::unique_lock<std::mutex> lk( p.m );
-                p.cv_free.wait( lk, [&]{ for( int i = 0; i < depth; i++ ) if( p.slots[i].job == nullptr ) return true; return false; } );
-                for( int i = 0; i < depth; i++ ) if( p.slots[i].job == nullptr ) { si = i; break; }
-                p.slots[si].job = job;
-            }
-            Slot& s = p.slots[si];
-            const double ts1 = pnow();
+            const double t0 = pnow();
             if( _proc_mode == popsift::Config::ExtractingMode && s.xdesc == nullptr ) {
                 // the previous result took this context's descriptor buffer with it: attach a fresh one
                 const int want = p.want_desc;
@@ -430,49 +389,32 @@ void PopSift::dispatchLoop( )
                 s.desc_cap = (int)std::min<size_t>( s.xdesc_cap / sizeof(popsift::Descriptor), (size_t)1 << 30 );
                 check( s.ctx, psx_attach_export( s.ctx, s.xfeat, EXPORT_FEATURES, s.xdesc, s.desc_cap ), "psx_attach_export" );
             }
-            const double ts2 = pnow();
+            const double t1 = pnow();
             if( job->isFloat() )
                 check( s.ctx, psx_upload_f32( s.ctx, (const float*)job->getData(), job->getWidth(), job->getHeight() ), "psx_upload_f32" );
             else
                 check( s.ctx, psx_upload_u8( s.ctx, job->getData(), job->getWidth(), job->getHeight() ), "psx_upload_u8" );
-            const double ts3 = pnow();
+            const double t2 = pnow();
             check( s.ctx, psx_extract( s.ctx ), "psx_extract" );
-            const double ts4 = pnow();
-            p.t_slot += ts1 - ts0; p.t_attach += ts2 - ts1; p.t_upload += ts3 - ts2; p.t_submit += ts4 - ts3;
-            {
-                std::lock_guard<std::mutex> g( p.m );
-                p.inflight.push_back( si );
-            }
-            p.cv_inflight.notify_one();
+            const double t3 = pnow();
+            double tf = 0;
+            if( _proc_mode == popsift::Config::ExtractingMode ) f = collect_host( s, p.want_desc, &tf );
+            else                                                f = collect_dev( s, _device );
+            const double t4 = pnow();
+            t_attach += t1 - t0; t_upload += t2 - t1; t_submit += t3 - t2; t_frame += tf; t_wrap += t4 - t3 - tf; n_done++;
         } catch( ... ) {
-            if( si >= 0 ) {
-                { std::lock_guard<std::mutex> g( p.m ); p.slots[si].job = nullptr; }
-                p.cv_free.notify_one();
-            }
             job->setError( std::current_exception() );
-            job->setFeatures( nullptr );
+            f = nullptr;
         }
+        job->setFeatures( f );
     }
 
+    if( s.ctx ) { psx_attach_export( s.ctx, nullptr, 0, nullptr, 0 ); psx_destroy( s.ctx ); }
+    popsift::pool::put_pinned( s.xfeat, s.xfeat_cap );
+    popsift::pool::put_pinned( s.xdesc, s.xdesc_cap );
     {
-        std::lock_guard<std::mutex> g( p.m );
-        p.submit_done = true;
+        std::lock_guard<std::mutex> g( p.prof_mutex );
+        p.t_attach += t_attach; p.t_upload += t_upload; p.t_submit += t_submit; p.t_frame += t_frame; p.t_wrap += t_wrap;
+        p.n_done += n_done;
     }
-    p.cv_inflight.notify_all();
-    if( p.collector ) { p.collector->join(); p.collector.reset(); }
-    if( getenv( "POPSIFT_PROFILE" ) != nullptr && p.n_done > 0 ) {
-        const double k = 1e3 / p.n_done;
-        fprintf( stderr, "[popsift profile] %d frames, ms per frame: submit thread: wait-for-context %.3f attach %.3f upload %.3f launch %.3f | "
-                         "collect thread: wait-for-frame %.3f wrap %.3f\n",
-                 p.n_done, p.t_slot * k, p.t_attach * k, p.t_upload * k, p.t_submit * k, p.t_frame * k, p.t_wrap * k );
-    }
-
-    // jobs enqueued after the sentinel are never processed; release the contexts
-    for( auto& s : p.slots ) {
-        if( s.ctx ) { psx_attach_export( s.ctx, nullptr, 0, nullptr, 0 ); psx_destroy( s.ctx ); }
-        popsift::pool::put_pinned( s.xfeat, s.xfeat_cap );
-        popsift::pool::put_pinned( s.xdesc, s.xdesc_cap );
-        s = Slot();
-    }
-    p.contexts_exist = false;
 }

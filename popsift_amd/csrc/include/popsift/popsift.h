@@ -123,7 +123,6 @@ private:
     struct Impl;
     void start();
     void dispatchLoop();
-    void collectLoop();
 
     std::unique_ptr<Impl> _impl;
     popsift::Config _config;
