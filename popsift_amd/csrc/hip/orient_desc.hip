@@ -286,14 +286,22 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
     __shared__ int s_total;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-    if (t == 0) {
-        int ps = 0;
-        for (int o = 0; o < PSX_MAX_OCTAVES; o++) {
-            cnt->ext_ps[o] = ps;
-            ps += (o < P->num_octaves) ? ext_count(P, cnt, o) : 0;
+    // per-octave prefix sums: lane o of the first wave owns octave o (a serial loop of dependent global
+    // loads in one thread cost ~10 us here and ~20 us in the epilogue)
+    if (wave == 0) {
+        const int c = (lane < P->num_octaves) ? ext_count(P, cnt, lane) : 0;
+        int v = c;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const int u = __shfl_up(v, off);
+            if (lane >= off) v += u;
         }
-        cnt->ext_ps[PSX_MAX_OCTAVES] = ps;
-        s_total = min(ps, P->ext_capacity);
+        if (lane < PSX_MAX_OCTAVES) cnt->ext_ps[lane] = v - c;
+        const int ps = __shfl(v, PSX_MAX_OCTAVES - 1);
+        if (lane == 0) {
+            cnt->ext_ps[PSX_MAX_OCTAVES] = ps;
+            s_total = min(ps, P->ext_capacity);
+        }
     }
     __syncthreads();
     const int total = s_total;
@@ -355,18 +363,25 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
     }
     const int grand = carry;
     __syncthreads();
-    if (t == 0) {
+    if (wave == 0) {
         const int ori_total = min(grand, cap);
-        cnt->ext_total = total;
-        cnt->ori_total = ori_total;
-        if (P->x_counts != nullptr) { P->x_counts[0] = total; P->x_counts[1] = ori_total; }
-        // per-octave orientation counts (dct.ori_ct / ori_ps, s_orientation.cu:340-360)
-        for (int o = 0; o < PSX_MAX_OCTAVES; o++) {
-            const int fe = cnt->ext_ps[o];
-            cnt->ori_ps[o] = (fe < total) ? min(P->extrema[fe].idx_ori, ori_total) : ori_total;
+        if (lane == 0) {
+            cnt->ext_total = total;
+            cnt->ori_total = ori_total;
+            if (P->x_counts != nullptr) { P->x_counts[0] = total; P->x_counts[1] = ori_total; }
         }
-        cnt->ori_ps[PSX_MAX_OCTAVES] = ori_total;
-        for (int o = 0; o < PSX_MAX_OCTAVES; o++) cnt->ori_ct[o] = cnt->ori_ps[o + 1] - cnt->ori_ps[o];
+        // per-octave orientation counts (dct.ori_ct / ori_ps, s_orientation.cu:340-360), lane o = octave o
+        int ps = ori_total;
+        if (lane < PSX_MAX_OCTAVES) {
+            const int fe = cnt->ext_ps[lane];          // written by this lane above
+            ps = (fe < total) ? min(P->extrema[fe].idx_ori, ori_total) : ori_total;
+        }
+        const int nxt = __shfl_down(ps, 1);
+        if (lane < PSX_MAX_OCTAVES) {
+            cnt->ori_ps[lane] = ps;
+            cnt->ori_ct[lane] = ((lane == PSX_MAX_OCTAVES - 1) ? ori_total : nxt) - ps;
+        }
+        if (lane == 0) cnt->ori_ps[PSX_MAX_OCTAVES] = ori_total;
     }
 }
 
