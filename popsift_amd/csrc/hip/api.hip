@@ -7,7 +7,7 @@
 // device; the batch dispatcher uses that to keep several frames in flight per GPU.
 //
 // Stream model: every context owns one HIP stream; a frame is one stream-ordered chain
-//   memset(counters) -> k_level0 -> k_blur x (L-1) per octave -> k_extrema per octave
+//   memset(counters) -> k_upscale -> k_blur<R,true> -> per octave { k_blur x (L-1) -> k_extrema } -> k_refine
 //   -> k_orientation -> k_scan -> k_descriptors
 // with no host synchronisation inside the chain (the reference has four blocking counter
 // round-trips and four device-wide syncs per image).
