@@ -576,3 +576,47 @@ def test_bench_workload_bit_exact_and_repeatable(oracle, capi):
     # descriptors are order dependent only through their position in the array: compare as sorted rows
     assert np.array_equal(np.sort(d1.view(np.uint32), axis=0).sum(0), np.sort(d2.view(np.uint32), axis=0).sum(0))
     ctx.close()
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        w, h = int(rng.integers(40, 260)), int(rng.integers(40, 200))
+        kw = dict(octaves=int(rng.integers(1, 5)), levels=int(rng.integers(2, 5)),
+                  sift_mode=int(rng.integers(0, 3)), gauss_mode=int(rng.choice([0, 3])),
+                  upscale_factor=float(rng.choice([-1.0, 0.0, 1.0])), norm_mode=int(rng.integers(0, 2)),
+                  norm_multi=int(rng.choice([0, 9])), sigma=float(rng.choice([1.2, 1.6, 2.0])),
+                  threshold=float(rng.choice([0.02, 0.04, 0.0667])), edge_limit=float(rng.choice([6.0, 10.0, 16.0])))
+        out.append((w, h, 9000 + i, bool(rng.integers(0, 2)), kw))
+    return out
+
+
+@pytest.mark.parametrize("w,h,seed,is_float,kw", _fuzz_cases(100, 12345))
+def test_fuzz_small_configs(oracle, capi, w, h, seed, is_float, kw):
+    """Seeded random sweep over sizes (odd, tiny, non-multiples of every tile size), all three SIFT modes, both
+    span rules, down / no / up sampling, 2-4 levels, both normalisations, byte and float input: planes
+    bit-exact, initial extrema identical, features and descriptors within tolerance."""
+    img = synth_float(w, h, seed) if is_float else synth(w, h, seed)
+    ocfg, gcfg = _cfgs(oracle, capi, kw)
+    ref = oracle.run(ocfg, img)
+    ctx = capi.Context(gcfg)
+    ctx.upload(img)
+    ctx.extract()
+    assert ctx.num_octaves == ref.num_octaves
+    for o in range(ref.num_octaves):
+        assert ctx.octave_dims(o) == ref.dims[o]
+        for l in range(ref.num_levels):
+            assert np.array_equal(ctx.dump_plane(capi.PLANE_GAUSS, o, l), ref.gauss(o, l)), (o, l)
+        a, b = sort_iext(ref.iext(o)), sort_iext(ctx.dump_iext(o))
+        assert len(a) == len(b)
+        assert np.array_equal(a["xpos"], b["xpos"]) and np.array_equal(a["ypos"], b["ypos"]) and np.array_equal(a["lpos"], b["lpos"])
+    fb, db = ctx.download()
+    fa, da = ref.features(), ref.descriptors()
+    assert len(fa) == len(fb)
+    if len(fa):
+        m = match_features(fa, da, fb, db, norm_scale=float(2 ** kw["norm_multi"]))
+        # small sets: allow one orientation / descriptor flip (a 1e-7 atan difference moving a sample across a bin)
+        slack = 1.0 / max(1, len(fa)) + 0.005
+        assert m["kp_match"] >= 1.0 - slack and m["ori_match"] >= 1.0 - 2 * slack and m["desc_match"] >= 1.0 - 2 * slack, m
+    ctx.close()
