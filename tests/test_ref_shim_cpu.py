@@ -79,3 +79,34 @@ def test_matcher_matches_reference(oracle, ref, nl, nr, seed):
     assert np.array_equal(mr, mo)
     finite = np.isfinite(do_)
     assert np.abs(dr[finite] - do_[finite]).max() <= 6e-4
+
+
+def _ref_fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        w, h = int(rng.integers(40, 110)), int(rng.integers(40, 90))
+        kw = dict(octaves=int(rng.integers(1, 4)), levels=int(rng.integers(2, 5)), sift_mode=int(rng.integers(0, 3)),
+                  gauss_mode=int(rng.choice([0, 3])), upscale_factor=float(rng.choice([-1.0, 0.0, 1.0])),
+                  norm_mode=int(rng.integers(0, 2)), norm_multi=int(rng.choice([0, 9])),
+                  sigma=float(rng.choice([1.2, 1.6, 2.0])), threshold=float(rng.choice([0.02, 0.04])))
+        out.append((w, h, 7000 + i, kw))
+    return out
+
+
+@pytest.mark.parametrize("w,h,seed,kw", _ref_fuzz_cases(16, 4321))
+def test_fuzz_oracle_vs_reference(oracle, ref, w, h, seed, kw):
+    """Seeded random configurations through the reference's own code and the oracle: planes bit-identical,
+    same initial extrema, identical feature sets."""
+    img = synth(w, h, seed)
+    cfg = oracle.default_config(**kw)
+    r, o = ref.run(cfg, img), oracle.run(cfg, img)
+    assert r.dims == o.dims and r.num_levels == o.num_levels
+    for oc in range(r.num_octaves):
+        for l in range(r.num_levels):
+            assert np.array_equal(r.gauss(oc, l), o.gauss(oc, l)), (oc, l)
+        assert len(r.iext(oc)) == len(o.iext(oc))
+    assert r.ext_total == o.ext_total and r.ori_total == o.ori_total
+    if r.ext_total:
+        m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors(), norm_scale=float(2 ** kw["norm_multi"]))
+        assert m["kp_match"] == 1.0 and m["ori_match"] == 1.0 and m["desc_match"] == 1.0, m
