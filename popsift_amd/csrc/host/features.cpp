@@ -7,6 +7,7 @@
 
 #include "popsift_hip.h"
 
+#include <algorithm>
 #include <cerrno>
 #include <mutex>
 #include <utility>
@@ -48,6 +49,7 @@ struct Pool
     std::mutex                            m;
     std::vector<std::pair<void*, size_t>> free_list;
     bool                                  pinned;
+    size_t                                in_use = 0;      // bytes handed out
     explicit Pool( bool p ) : pinned( p ) { }
 
     void* get( size_t bytes, size_t* cap )
@@ -62,6 +64,7 @@ struct Pool
             if( best >= 0 ) {
                 void* p = free_list[best].first; *cap = free_list[best].second;
                 free_list.erase( free_list.begin() + best );
+                in_use += *cap;
                 return p;
             }
         }
@@ -71,6 +74,7 @@ struct Pool
         if( pinned ) { if( psx_host_alloc( c, &p ) != PSX_OK ) return nullptr; }
         else         { if( posix_memalign( &p, 4096, c ) != 0 ) return nullptr; }
         *cap = c;
+        { std::lock_guard<std::mutex> g( m ); in_use += c; }
         return p;
     }
     void put( void* p, size_t cap )
@@ -78,6 +82,7 @@ struct Pool
         if( p == nullptr ) return;
         {
             std::lock_guard<std::mutex> g( m );
+            in_use -= std::min( in_use, cap );
             if( free_list.size() < 32 ) { free_list.emplace_back( p, cap ); return; }
         }
         if( pinned ) psx_host_free( p ); else free( p );
@@ -90,6 +95,7 @@ void* get_plain( size_t bytes, size_t* cap )  { return plain().get( bytes, cap )
 void  put_plain( void* p, size_t cap )        { plain().put( p, cap ); }
 void* get_pinned( size_t bytes, size_t* cap ) { return pinned().get( bytes, cap ); }
 void  put_pinned( void* p, size_t cap )       { pinned().put( p, cap ); }
+size_t pinned_in_use( )                       { std::lock_guard<std::mutex> g( pinned().m ); return pinned().in_use; }
 } // namespace pool
 
 FeaturesHost::FeaturesHost( ) : _ext( nullptr ), _ori( nullptr ), _ext_cap( 0 ), _ori_cap( 0 ) { }

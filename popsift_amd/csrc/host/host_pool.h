@@ -18,6 +18,8 @@ void* get_plain( size_t bytes, size_t* cap );
 void  put_plain( void* p, size_t cap );
 void* get_pinned( size_t bytes, size_t* cap );
 void  put_pinned( void* p, size_t cap );
+/// bytes of pinned buffers currently handed out (not sitting in the pool)
+size_t pinned_in_use( );
 
 } // namespace pool
 } // namespace popsift

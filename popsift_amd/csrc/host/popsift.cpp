@@ -288,6 +288,13 @@ void check( psx_ctx* ctx, int rc, const char* what )
     throw std::runtime_error( msg );
 }
 
+// pinned bytes that result objects may hold before results fall back to pageable copies (POPSIFT_PINNED_LIMIT_MB)
+size_t pinned_limit()
+{
+    static const size_t lim = []{ const char* e = getenv( "POPSIFT_PINNED_LIMIT_MB" ); return (size_t)( e ? atol( e ) : 2048 ) << 20; }();
+    return lim;
+}
+
 inline double pnow() { return std::chrono::duration<double>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 
 popsift::FeaturesHost* collect_host( Slot& s, std::atomic<int>& want_desc, double* t_frame )
@@ -316,6 +323,14 @@ popsift::FeaturesHost* collect_host( Slot& s, std::atomic<int>& want_desc, doubl
         tmp.resize( ne );
         check( s.ctx, psx_download( s.ctx, tmp.data(), ne, (float*)base, no ), "psx_download" );
         src = tmp.data();
+    } else if( popsift::pool::pinned_in_use() > pinned_limit() ) {
+        // a caller that hoards results must not exhaust pinned memory: beyond the limit the result gets an
+        // ordinary page-aligned copy (what the reference hands out) and the context keeps its pinned buffer
+        f->reset( ne, no );
+        memcpy( f->getDescriptors(), s.xdesc, (size_t)no * sizeof(popsift::Descriptor) );
+        popsift::pool::put_plain( dst, ext_cap );
+        dst = f->getFeatures();
+        base = f->getDescriptors();
     } else {
         // the GPU wrote the descriptors straight into s.xdesc: the result object takes the buffer over
         base = (popsift::Descriptor*)s.xdesc;

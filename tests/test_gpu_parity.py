@@ -515,8 +515,10 @@ def test_cpp_streaming_reuses_result_buffers(capi, tmp_path):
     ctx.extract()
     ne, _ = ctx.counts()
     ctx.close()
-    for depth in ("1", "3"):
+    for depth, limit in (("1", None), ("3", None), ("2", "0")):      # limit 0: results are pageable copies
         env = dict(os.environ, POPSIFT_PIPE_DEPTH=depth)
+        if limit is not None:
+            env["POPSIFT_PINNED_LIMIT_MB"] = limit
         p = subprocess.run([demo, str(w), str(h), str(raw), str(tmp_path / "unused.txt"), "--octaves", "4", "--bench", "60"],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
         assert p.returncode == 0, p.stdout
