@@ -244,6 +244,17 @@ def main():
             cdt = time.perf_counter() - t1
             cpu = {"value": round(n_s * W * H / cdt / 1e6, 2), "unit": "Mpix/s", "cores": ncores,
                    "kind": "port", "sample": "%d frames 1920x1080, oracle/liboracle.so with OpenMP" % n_s}
+            # OpenCV's CPU SIFT next to it when the box has cv2; this image does not ship it
+            try:
+                import cv2
+                cv2.setNumThreads(ncores)
+                sift = cv2.SIFT_create(nOctaveLayers=3, contrastThreshold=0.04, edgeThreshold=10, sigma=1.6)
+                t2 = time.perf_counter()
+                nk = len(sift.detectAndCompute(frames_np[0], None)[0])
+                cpu["opencv_sift"] = {"value": round(W * H / (time.perf_counter() - t2) / 1e6, 2), "unit": "Mpix/s",
+                                      "cores": ncores, "keypoints": nk, "sample": "1 frame 1920x1080"}
+            except Exception:
+                cpu["opencv_sift"] = "absent (cv2 is not installed in this image)"
 
         out = {
             "metric": "Mpixels/sec end-to-end SIFT (5 oct, 3 lvl/oct) + keypoints/sec",
