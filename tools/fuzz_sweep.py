@@ -1,5 +1,5 @@
 """dev tool (GPU box): wider version of tests/test_gpu_parity.py::test_fuzz_small_configs.
-usage: python tools/fuzz_sweep.py [n] [seed]"""
+usage: python tools/fuzz_sweep.py [n] [seed] [size-scale]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,9 +10,12 @@ from tests.parity import match_features, sort_iext
 from tests.test_gpu_parity import _fuzz_cases
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 bad = 0
 worst = 1.0
+nkp = 0
 for (w, h, s, is_float, kw) in _fuzz_cases(n, seed):
+    w, h = w * scale, h * scale
     img = synth_float(w, h, s) if is_float else synth(w, h, s)
     ref = oracle.run(oracle.default_config(**kw), img)
     ctx = capi.Context(capi.default_config(**kw)); ctx.upload(img); ctx.extract()
@@ -25,6 +28,7 @@ for (w, h, s, is_float, kw) in _fuzz_cases(n, seed):
     fb, db = ctx.download()
     fa, da = ref.features(), ref.descriptors()
     ok = ok and len(fa) == len(fb)
+    nkp += len(fa)
     if ok and len(fa):
         m = match_features(fa, da, fb, db, norm_scale=float(2 ** kw["norm_multi"]))
         worst = min(worst, m["ori_match"], m["desc_match"])
@@ -34,4 +38,4 @@ for (w, h, s, is_float, kw) in _fuzz_cases(n, seed):
         bad += 1
         print("MISMATCH", w, h, s, is_float, kw)
     ctx.close()
-print("cases", n, "hard mismatches", bad, "worst ori/desc match fraction", worst)
+print("cases", n, "keypoints", nkp, "hard mismatches", bad, "worst ori/desc match fraction", worst)
