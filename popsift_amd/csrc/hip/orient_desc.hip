@@ -175,8 +175,8 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
             const float gdx = *(gfloat_p)(plane + off + 4u) - *(gfloat_p)(plane + off - 4u);
             const float gdy = *(gfloat_p)(plane + (off + pitch4)) - *(gfloat_p)(plane + (off - pitch4));
             // the reference uses hypotf / atan2f here (s_gradiant.h:56-69).  The magnitude only scales a weight
-            // (v_sqrt_f32 is enough); the angle picks the histogram bin and must round exactly like the oracle's
-            // roundf(36 (atan2f + pi) / 2pi) -- see the bin computation below.
+            // (v_sqrt_f32 is enough); the angle picks the histogram bin and must round exactly like the CPU restatement's
+            // (oracle/sift_oracle.c) roundf(36 (atan2f + pi) / 2pi) -- see the bin computation below.
             const float grad  = __builtin_amdgcn_sqrtf(fmaf(gdx, gdx, gdy * gdy));
             const float dx = xx - x;
             const float dy = yy - y;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
             if (sq_dist <= sq_thres) {
                 const float weight = grad * __builtin_amdgcn_exp2f((float)sq_dist * factor2);
                 // Bin = roundf(36 (atan2f(gdy,gdx) + pi) / 2pi) with accurate atan2f and IEEE division, as in the
-                // oracle: gradients along exact bin boundaries (gdx == gdy gives 45 deg = bin 22.5) are common in
+                // CPU restatement: gradients along exact bin boundaries (gdx == gdy gives 45 deg = bin 22.5) are common in
                 // smooth images and one heavy sample in the wrong bin moves the interpolated peak by ~6e-3 rad.
                 // The 3.3e-7 rad polynomial (2e-6 bins) decides every sample that is not within 1e-3 bins of a
                 // boundary; only those (about 0.2 % of the samples) take the exact, ~50-instruction form.
