@@ -622,3 +622,26 @@ def test_fuzz_small_configs(oracle, capi, w, h, seed, is_float, kw):
         slack = 1.0 / max(1, len(fa)) + 0.005
         assert m["kp_match"] >= 1.0 - slack and m["ori_match"] >= 1.0 - 2 * slack and m["desc_match"] >= 1.0 - 2 * slack, m
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(3000, 9), (7, 2500), (65, 65), (63, 129), (4097, 33), (128, 1), (1, 128), (2, 2), (1920, 16)])
+def test_extreme_shapes(oracle, capi, w, h):
+    """Strips thinner than a filter radius, planes smaller than a tile, one pixel wide / high, widths just over
+    a strip multiple: every plane bit-exact, same extrema, same counts, in three configurations."""
+    img = synth(w, h, 77)
+    for kw in (dict(octaves=3), dict(octaves=2, upscale_factor=0.0, sift_mode=1), dict(upscale_factor=-1.0, sift_mode=2)):
+        ocfg, gcfg = _cfgs(oracle, capi, kw)
+        ref = oracle.run(ocfg, img)
+        ctx = capi.Context(gcfg)
+        ctx.upload(img)
+        ctx.extract()
+        assert ctx.num_octaves == ref.num_octaves
+        for o in range(ref.num_octaves):
+            assert ctx.octave_dims(o) == ref.dims[o]
+            for l in range(ref.num_levels):
+                assert np.array_equal(ctx.dump_plane(capi.PLANE_GAUSS, o, l), ref.gauss(o, l)), (kw, o, l)
+            a, b = sort_iext(ref.iext(o)), sort_iext(ctx.dump_iext(o))
+            assert len(a) == len(b) and np.array_equal(a["xpos"], b["xpos"]) and np.array_equal(a["ypos"], b["ypos"])
+        fb, db = ctx.download()
+        assert len(fb) == ref.ext_total and abs(len(db) - ref.ori_total) <= 1
+        ctx.close()
