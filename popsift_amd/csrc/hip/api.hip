@@ -370,6 +370,9 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     int ow = (int)ceilf(w * scaleFactor);
     int oh = (int)ceilf(h * scaleFactor);
     if (ow <= 0 || oh <= 0) return fail(ctx, PSX_ERR_INVALID, "psx_resize: scaled image is empty");
+    // kernels address a plane (and the padded resampled input) with 32-bit byte offsets from its base
+    if (((size_t)((ow + 63) & ~63) + 2 * PSX_LEVEL0_PAD) * (size_t)oh * sizeof(float) >= ((size_t)1 << 32))
+        return fail(ctx, PSX_ERR_INVALID, "psx_resize: octave 0 plane of 4 GiB or more is not supported");
 
     PsxParams& P = ctx->hp;
     memset(&P, 0, sizeof(P));

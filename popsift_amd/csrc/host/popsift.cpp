@@ -219,6 +219,7 @@ PopSift::AllocTest PopSift::testTextureFit( int width, int height )
     const float scale = 1.0f / powf( 2.0f, -_config.getUpscaleFactor() );
     const double px = ceil( (double)width * scale ) * ceil( (double)height * scale );
     if( px * ( _config.levels + 3 ) * 1.34 > 1.0e11 ) return AllocTest::ImageExceedsLayeredSurfaceLimit;
+    if( px * 4.0 >= 4.0e9 ) return AllocTest::ImageExceedsLayeredSurfaceLimit;    // 32-bit offsets inside a plane
     return AllocTest::Ok;
 }
 
