@@ -73,3 +73,25 @@ def synth(w, h, seed=1000):
 def synth_float(w, h, seed=1000):
     """Float-image variant, value range [0,1) as PopSift::FloatImages expects (popsift.h:68-73)."""
     return (synth(w, h, seed).astype(np.float32) / np.float32(256.0)).astype(np.float32)
+
+
+def warp_homography(img, Hm):
+    """Bilinear warp of a u8 frame: out(x, y) = img(H^-1 (x, y, 1)), border replicated.  Used for the
+    BASELINE config 5 stand-in (homography-warped synthetic pairs; the Oxford images are not in the repo).
+    Deterministic numpy float64 arithmetic, rounded to u8."""
+    h, w = img.shape
+    Hi = np.linalg.inv(np.asarray(Hm, dtype=np.float64))
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    den = Hi[2, 0] * xs + Hi[2, 1] * ys + Hi[2, 2]
+    sx = (Hi[0, 0] * xs + Hi[0, 1] * ys + Hi[0, 2]) / den
+    sy = (Hi[1, 0] * xs + Hi[1, 1] * ys + Hi[1, 2]) / den
+    sx = np.clip(sx, 0.0, w - 1.0)
+    sy = np.clip(sy, 0.0, h - 1.0)
+    x0 = np.floor(sx).astype(np.int64)
+    y0 = np.floor(sy).astype(np.int64)
+    x1 = np.minimum(x0 + 1, w - 1)
+    y1 = np.minimum(y0 + 1, h - 1)
+    fx, fy = sx - x0, sy - y0
+    f = img.astype(np.float64)
+    out = (1 - fy) * ((1 - fx) * f[y0, x0] + fx * f[y0, x1]) + fy * ((1 - fx) * f[y1, x0] + fx * f[y1, x1])
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)

@@ -2,6 +2,11 @@
 
 The reference's own notion of "correct" is sorted-set equality (testScripts/testOxfordDataset.sh.in:
 140-154): the order of features is the order of atomicAdd and is not a contract.
+
+match_features is vectorised (KD-tree + numpy, no per-keypoint Python loop) so that it runs on the
+15 k-keypoint 1080p bench frame and the 125 k-keypoint 4096x4096 frame in about a second.  Besides the
+match fractions it returns exact mismatch COUNTS and a printable list of the mismatches with their cause,
+so that tests can assert "<= k mismatches" instead of a loose fraction.
 """
 import numpy as np
 from scipy.spatial import cKDTree
@@ -18,86 +23,179 @@ def _ang_diff(a, b):
     return np.minimum(d, 2 * np.pi - d)
 
 
-def match_features(fa, da, fb, db, norm_scale=1.0):
+def _assign_keypoints(fa, fb, k=6):
+    """For every keypoint of A the index of its partner in B (-1: none): nearest unused candidate within
+    tolerance.  The reference algorithm can emit exact duplicates (two start pixels refined to the same
+    position), so assignment is one-to-one: rounds over the k nearest neighbours, ties resolved by index."""
+    na, nb = len(fa), len(fb)
+    ka = np.stack([fa["xpos"], fa["ypos"], fa["debug_octave"] * 1e4, np.log2(np.maximum(fa["sigma"], 1e-12)) * 50.0], 1)
+    kb = np.stack([fb["xpos"], fb["ypos"], fb["debug_octave"] * 1e4, np.log2(np.maximum(fb["sigma"], 1e-12)) * 50.0], 1)
+    kq = min(k, nb)
+    _, idx = cKDTree(kb).query(ka, k=kq)
+    idx = idx.reshape(na, kq)
+    tol = TOL_POS * np.maximum(1.0, fa["sigma"].astype(np.float64))
+    ok = np.zeros((na, kq), bool)
+    for c in range(kq):
+        j = idx[:, c]
+        ok[:, c] = ((np.abs(fa["xpos"].astype(np.float64) - fb["xpos"][j]) <= tol)
+                    & (np.abs(fa["ypos"].astype(np.float64) - fb["ypos"][j]) <= tol)
+                    & (np.abs(fa["sigma"].astype(np.float64) - fb["sigma"][j]) <= TOL_SIGMA_REL * fa["sigma"])
+                    & (fa["debug_octave"] == fb["debug_octave"][j]))
+    partner = np.full(na, -1, np.int64)
+    used = np.zeros(nb, bool)
+    ptr = np.zeros(na, np.int64)          # candidate column each keypoint tries next
+    while True:
+        active = np.flatnonzero((partner < 0) & (ptr < kq))
+        if len(active) == 0:
+            break
+        # advance every unmatched keypoint to its first acceptable, still unused candidate
+        cols = ptr[active]
+        while True:
+            alive = cols < kq
+            cc = np.minimum(cols, kq - 1)
+            bad = alive & (~ok[active, cc] | used[idx[active, cc]])
+            if not bad.any():
+                break
+            cols = cols + bad
+        ptr[active] = cols
+        act, cols = active[alive], cols[alive]
+        if len(act) == 0:
+            break
+        cand = idx[act, cols]
+        # several A keypoints may propose the same B keypoint: the lowest A index wins this round, the
+        # others find it used in the next round and move on
+        order = np.argsort(cand, kind="stable")
+        cs, as_ = cand[order], act[order]
+        first = np.ones(len(cs), bool)
+        first[1:] = cs[1:] != cs[:-1]
+        partner[as_[first]] = cs[first]
+        used[cs[first]] = True
+    return partner
+
+
+def match_features(fa, da, fb, db, norm_scale=1.0, max_report=25):
     """fa/fb: structured feature arrays (debug_octave,xpos,ypos,sigma,num_ori,orientation,desc_idx);
-    da/db: (n,128) descriptor arrays.  Returns a dict of parity fractions (of set A)."""
+    da/db: (n,128) descriptor arrays.  Returns parity fractions (of set A), exact mismatch counts
+    (kp_miss, ori_miss, desc_miss) and `misses`: printable records of the first mismatches."""
     res = {"n_a": len(fa), "n_b": len(fb)}
     if len(fa) == 0 or len(fb) == 0:
-        res.update(kp_match=float(len(fa) == len(fb)), ori_match=1.0, desc_match=1.0, max_desc_dist=0.0)
+        res.update(kp_match=float(len(fa) == len(fb)), ori_match=1.0, desc_match=1.0, max_desc_dist=0.0,
+                   kp_miss=len(fa), ori_miss=0, desc_miss=0, desc_compared=0, misses=[])
         return res
-    # nearest neighbour in (x, y, octave*1e4) -- different octaves never match
-    ka = np.stack([fa["xpos"], fa["ypos"], fa["debug_octave"] * 1e4, np.log2(fa["sigma"]) * 50.0], 1)
-    kb = np.stack([fb["xpos"], fb["ypos"], fb["debug_octave"] * 1e4, np.log2(fb["sigma"]) * 50.0], 1)
-    tree = cKDTree(kb)
-    kq = min(4, len(fb))
-    _, idx_all = tree.query(ka, k=kq)
-    idx_all = idx_all.reshape(len(fa), kq)
-    kp_ok = np.zeros(len(fa), bool)
-    ori_ok = np.zeros(len(fa), bool)
-    n_desc = 0
-    n_desc_ok = 0
-    max_dd = 0.0
-    used = set()
-    for i in range(len(fa)):
-        a = fa[i]
-        tol = TOL_POS * max(1.0, float(a["sigma"]))
-        j = -1
-        # the reference algorithm can emit exact duplicates (two start pixels refined to the same
-        # position), so take the nearest *unused* candidate within tolerance
-        for cand in idx_all[i]:
-            cand = int(cand)
-            b = fb[cand]
-            if cand in used:
-                continue
-            if (abs(a["xpos"] - b["xpos"]) <= tol and abs(a["ypos"] - b["ypos"]) <= tol
-                    and abs(a["sigma"] - b["sigma"]) <= TOL_SIGMA_REL * a["sigma"]):
-                j = cand
-                break
-        if j < 0:
-            continue
-        b = fb[j]
-        used.add(j)
-        kp_ok[i] = True
-        na, nb = int(a["num_ori"]), int(b["num_ori"])
-        if na != nb:
-            continue
-        oa = a["orientation"][:na]
-        ob = b["orientation"][:nb]
-        # match orientations by nearest angle
-        good = True
-        pairs = []
-        taken = set()
-        for p in range(na):
-            dd = _ang_diff(oa[p], ob)
-            for q in taken:
-                dd[q] = np.inf
-            q = int(np.argmin(dd))
-            if dd[q] > TOL_ORI:
-                good = False
-                break
-            taken.add(q)
-            pairs.append((p, q))
-        if not good:
-            continue
-        ori_ok[i] = True
-        for p, q in pairs:
-            ia, ib = int(a["desc_idx"][p]), int(b["desc_idx"][q])
-            if ia < 0 or ib < 0:
-                continue
-            n_desc += 1
-            d = float(np.linalg.norm(da[ia].astype(np.float64) - db[ib].astype(np.float64))) / norm_scale
-            max_dd = max(max_dd, d)
-            if d <= TOL_DESC:
-                n_desc_ok += 1
+    na = len(fa)
+    partner = _assign_keypoints(fa, fb)
+    kp_ok = partner >= 0
+    ia = np.flatnonzero(kp_ok)
+    ib = partner[ia]
+    misses = []
+    for i in np.flatnonzero(~kp_ok)[:max_report]:
+        misses.append("keypoint A[%d] oct %d (%.4f, %.4f) sigma %.4f: no partner within tolerance"
+                      % (i, fa["debug_octave"][i], fa["xpos"][i], fa["ypos"][i], fa["sigma"][i]))
+
+    # ---- orientations: same count, then greedy nearest-angle pairing (4 x 4 per keypoint) ----
+    noa = fa["num_ori"][ia].astype(np.int64)
+    nob = fb["num_ori"][ib].astype(np.int64)
+    same_n = noa == nob
+    oa = fa["orientation"][ia].astype(np.float64)           # (m, 4)
+    ob = fb["orientation"][ib].astype(np.float64)
+    m = len(ia)
+    dd = _ang_diff(oa[:, :, None], ob[:, None, :])           # (m, 4, 4)
+    ar = np.arange(4)
+    dd[:, :, :] = np.where((ar[None, :, None] < noa[:, None, None]) & (ar[None, None, :] < nob[:, None, None]), dd, np.inf)
+    pair_q = np.full((m, 4), -1, np.int64)
+    good = same_n.copy()
+    for p in range(4):
+        need = p < noa
+        q = np.argmin(dd[:, p, :], axis=1)
+        dmin = dd[np.arange(m), p, q]
+        okp = dmin <= TOL_ORI
+        good &= ~need | okp
+        sel = need & okp
+        pair_q[sel, p] = q[sel]
+        rows = np.flatnonzero(sel)
+        dd[rows, :, q[rows]] = np.inf                        # q is taken
+    ori_ok = np.zeros(na, bool)
+    ori_ok[ia[good]] = True
+    for r in np.flatnonzero(~good)[:max_report]:
+        i, j = ia[r], ib[r]
+        cause = "num_ori %d vs %d" % (noa[r], nob[r]) if noa[r] != nob[r] else \
+            "angles %s vs %s" % (np.round(oa[r, :noa[r]], 5).tolist(), np.round(ob[r, :nob[r]], 5).tolist())
+        misses.append("orientation A[%d]/B[%d] oct %d (%.3f, %.3f) sigma %.3f: %s"
+                      % (i, j, fa["debug_octave"][i], fa["xpos"][i], fa["ypos"][i], fa["sigma"][i], cause))
+
+    # ---- descriptors of the paired orientations ----
+    rr, pp = np.nonzero((pair_q >= 0) & good[:, None])
+    qq = pair_q[rr, pp]
+    da_idx = fa["desc_idx"][ia[rr], pp].astype(np.int64)
+    db_idx = fb["desc_idx"][ib[rr], qq].astype(np.int64)
+    have = (da_idx >= 0) & (db_idx >= 0) & (da_idx < len(da)) & (db_idx < len(db))
+    rr, da_idx, db_idx = rr[have], da_idx[have], db_idx[have]
+    n_desc = len(rr)
+    if n_desc:
+        dist = np.empty(n_desc)
+        for s in range(0, n_desc, 65536):                     # bounded temporaries
+            e = min(n_desc, s + 65536)
+            diff = da[da_idx[s:e]].astype(np.float64) - db[db_idx[s:e]].astype(np.float64)
+            dist[s:e] = np.sqrt((diff * diff).sum(1)) / norm_scale
+        bad = dist > TOL_DESC
+        n_desc_ok = int((~bad).sum())
+        max_dd = float(dist.max())
+        for s in np.flatnonzero(bad)[:max_report]:
+            i = ia[rr[s]]
+            misses.append("descriptor A[%d] oct %d (%.3f, %.3f) sigma %.3f: L2 distance %.3g"
+                          % (i, fa["debug_octave"][i], fa["xpos"][i], fa["ypos"][i], fa["sigma"][i], dist[s]))
+    else:
+        n_desc_ok, max_dd = 0, 0.0
     res["kp_match"] = float(kp_ok.mean())
     res["ori_match"] = float(ori_ok.mean())
     res["desc_match"] = float(n_desc_ok / n_desc) if n_desc else 1.0
     res["desc_compared"] = n_desc
     res["max_desc_dist"] = max_dd
+    res["kp_miss"] = int((~kp_ok).sum())
+    res["ori_miss"] = int(kp_ok.sum() - good.sum())          # matched keypoints whose orientations differ
+    res["desc_miss"] = int(n_desc - n_desc_ok)
+    res["misses"] = misses
     return res
+
+
+def assert_parity(m, kp=0, ori=0, desc=0, what=""):
+    """Exact mismatch budget: at most `kp` unmatched keypoints, `ori` orientation mismatches and `desc`
+    descriptors beyond 1e-3; every mismatch is printed with its cause when the budget is exceeded."""
+    msg = "%s kp_miss %d (<= %d), ori_miss %d (<= %d), desc_miss %d (<= %d) of %d keypoints / %d descriptors, " \
+          "max desc dist %.3g\n  %s" % (what, m["kp_miss"], kp, m["ori_miss"], ori, m["desc_miss"], desc, m["n_a"],
+                                        m.get("desc_compared", 0), m["max_desc_dist"], "\n  ".join(m["misses"]))
+    assert m["kp_miss"] <= kp and m["ori_miss"] <= ori and m["desc_miss"] <= desc, msg
 
 
 def sort_iext(a):
     """Canonical order for initial extrema: (lpos, ypos, xpos)."""
     order = np.lexsort((a["xpos"], a["ypos"], a["lpos"]))
     return a[order]
+
+
+def budget(n_keypoints):
+    """Mismatch budget of a HIP-vs-oracle comparison with n keypoints.  Positions are bit-exact (0 keypoint
+    misses).  Orientations / descriptors go through transcendentals (libm on the CPU, ocml and fast paths on
+    the GPU): measured on MI355X (tools/parity_counts.py, profiles/r02_parity_counts.json) about 4 orientation
+    flips per 100 000 keypoints (a gradient sample within an ulp of a histogram-bin boundary) and fewer
+    descriptor outliers; the budget is that rate with head-room: 1 + n/10000 each."""
+    return dict(kp=0, ori=1 + n_keypoints // 10000, desc=1 + n_keypoints // 10000)
+
+
+def repeatability(fa, fb, Hm, w, h, tol_px=1.5):
+    """Fraction of keypoints of image A whose position mapped through the homography Hm lands within tol_px
+    (and within a factor sqrt(2) in scale) of a keypoint of image B, over those that map inside B."""
+    if len(fa) == 0 or len(fb) == 0:
+        return 0.0, 0
+    p = np.stack([fa["xpos"], fa["ypos"], np.ones(len(fa))], 1).astype(np.float64) @ np.asarray(Hm, np.float64).T
+    q = p[:, :2] / p[:, 2:3]
+    inside = (q[:, 0] >= 8) & (q[:, 0] < w - 8) & (q[:, 1] >= 8) & (q[:, 1] < h - 8)
+    if not inside.any():
+        return 0.0, 0
+    tree = cKDTree(np.stack([fb["xpos"], fb["ypos"]], 1).astype(np.float64))
+    hit = np.zeros(len(fa), bool)
+    for i, nb in enumerate(tree.query_ball_point(q, tol_px)):
+        if inside[i] and nb:
+            r = fb["sigma"][nb] / fa["sigma"][i]
+            hit[i] = bool(((r > 0.70) & (r < 1.42)).any())
+    return float(hit[inside].mean()), int(inside.sum())

@@ -1,0 +1,160 @@
+"""GPU parity at the sizes BASELINE.json names (configs 2, 3 and 5) and at the level counts that change
+the kernels' LDS footprint.  Everything goes through the C-ABI; the oracle is the checker.
+
+Bars: Gaussian planes and initial extrema bit-exact; features / orientations / descriptors within the
+north_star tolerances with an exact mismatch budget (tests/parity.py::budget), every mismatch printed.
+"""
+import numpy as np
+import pytest
+
+from popsift_amd.synth import synth, warp_homography
+from tests.parity import assert_parity, budget, match_features, repeatability, sort_iext
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes_and_extrema_equal(ctx, capi, ref):
+    assert ctx.num_octaves == ref.num_octaves and ctx.num_levels == ref.num_levels
+    for o in range(ref.num_octaves):
+        assert ctx.octave_dims(o) == ref.dims[o]
+        for l in range(ref.num_levels):
+            g = ctx.dump_plane(capi.PLANE_GAUSS, o, l)
+            assert np.array_equal(g.view(np.uint32), ref.gauss(o, l).view(np.uint32)), "plane (%d,%d) differs" % (o, l)
+            del g
+        a, b = sort_iext(ref.iext(o)), sort_iext(ctx.dump_iext(o))
+        assert len(a) == len(b), "octave %d: %d vs %d initial extrema" % (o, len(a), len(b))
+        for f in ("xpos", "ypos", "lpos", "cell"):
+            assert np.array_equal(a[f], b[f]), "octave %d field %s differs" % (o, f)
+
+
+def _features_within_budget(ref, fb, db, what, norm_scale=1.0):
+    fa, da = ref.features(), ref.descriptors()
+    assert len(fa) == len(fb), "%s: %d vs %d keypoints" % (what, len(fa), len(fb))
+    m = match_features(fa, da, fb, db, norm_scale=norm_scale)
+    print(what, {k: v for k, v in m.items() if k != "misses"})
+    assert_parity(m, what=what + " (oracle -> HIP)", **budget(len(fa)))
+    m2 = match_features(fb, db, fa, da, norm_scale=norm_scale)
+    assert_parity(m2, what=what + " (HIP -> oracle)", **budget(len(fa)))
+    assert abs(len(da) - len(db)) <= budget(len(fa))["ori"], (len(da), len(db))
+    return m
+
+
+def test_config2_1080p_full_feature_parity(oracle, capi):
+    """BASELINE config 2, the frame bench.py times (1920x1080 u8, 5 octaves, x2 upsample, ~15 k keypoints /
+    18 k descriptors): planes bit-exact, extrema identical, and the full feature set matched one to one."""
+    img = synth(1920, 1080, 1000)
+    ref = oracle.run(oracle.default_config(octaves=5), img)
+    ctx = capi.Context(capi.default_config(octaves=5))
+    ctx.upload(img)
+    ctx.extract()
+    _planes_and_extrema_equal(ctx, capi, ref)
+    fb, db = ctx.download()
+    assert len(fb) > 10000
+    _features_within_budget(ref, fb, db, "config 2 (1080p)")
+    ctx.close()
+
+
+def test_config3_4096sq_6_octaves(oracle, capi):
+    """BASELINE config 3: 4096x4096, 6 octaves, x2 upsample (octave 0 = 8192x8192, 268 MB per plane, 32-bit
+    in-plane offsets up to 2^28 floats, ~125 k keypoints, candidate lists ~1 M): planes bit-exact (compared
+    plane by plane), extrema identical, features within the budget."""
+    img = synth(4096, 4096, 3000)
+    ref = oracle.run(oracle.default_config(octaves=6), img)
+    ctx = capi.Context(capi.default_config(octaves=6))
+    ctx.upload(img)
+    ctx.extract()
+    assert ctx.octave_dims(0) == (8192, 8192)
+    _planes_and_extrema_equal(ctx, capi, ref)
+    fb, db = ctx.download()
+    assert len(fb) > 50000
+    _features_within_budget(ref, fb, db, "config 3 (4096^2, 6 octaves)")
+    ctx.close()
+
+
+# a mild perspective warp: rotation ~8 degrees, scale 0.9, shear and a small projective term
+_H5 = np.array([[0.891, -0.125, 60.0],
+                [0.125, 0.891, -20.0],
+                [4.0e-5, -2.0e-5, 1.0]])
+
+
+def test_config5_warped_pair_opencv_mode(oracle, capi):
+    """BASELINE config 5 stand-in (the Oxford boat/graffiti images are not in the repo):
+    a synthetic frame and its homography-warped copy, setMode(OpenCV) + setGaussMode("opencv").
+    (i) each image: HIP features/descriptors == oracle within the budget; (ii) repeatability of the HIP
+    keypoints under the known homography equals the oracle's and is high; (iii) the brute-force matcher
+    (psx_match, MatchingMode) pairs descriptors consistently with the homography."""
+    w, h = 800, 600
+    a = synth(w, h, 515)
+    b = warp_homography(a, _H5)
+    kw = dict(octaves=5, sift_mode=1, gauss_mode=3)
+    out = []
+    for name, img in (("A", a), ("B", b)):
+        ref = oracle.run(oracle.default_config(**kw), img)
+        ctx = capi.Context(capi.default_config(**kw))
+        ctx.upload(img)
+        ctx.extract()
+        _planes_and_extrema_equal(ctx, capi, ref)
+        fb, db = ctx.download()
+        _features_within_budget(ref, fb, db, "config 5 image " + name)
+        out.append((ref.features(), fb, db))
+        ctx.close()
+    (ra, fa, da), (rb, fb, db) = out
+    rep_hip, n_in = repeatability(fa, fb, _H5, w, h)
+    rep_ref, _ = repeatability(ra, rb, _H5, w, h)
+    print("config 5 repeatability: HIP %.4f oracle %.4f over %d keypoints" % (rep_hip, rep_ref, n_in))
+    assert n_in > 500
+    assert abs(rep_hip - rep_ref) < 2e-3
+    assert rep_hip > 0.55
+    # descriptor matching across the pair: accepted matches follow the homography
+    xa = np.zeros((len(da), 2)); xb = np.zeros((len(db), 2))
+    for f, x in ((fa, xa), (fb, xb)):
+        for k in range(4):
+            sel = f["num_ori"] > k
+            x[f["desc_idx"][sel, k]] = np.stack([f["xpos"][sel], f["ypos"][sel]], 1)
+    mm, _ = capi.match(da, db)
+    acc = mm[:, 2] == 1
+    assert acc.sum() > 300
+    p = np.concatenate([xa[acc], np.ones((acc.sum(), 1))], 1) @ _H5.T
+    err = np.linalg.norm(p[:, :2] / p[:, 2:3] - xb[mm[acc, 0]], axis=1)
+    print("config 5 matcher: %d accepted, %.3f within 2 px" % (acc.sum(), (err < 2.0).mean()))
+    assert (err < 2.0).mean() > 0.9
+
+
+@pytest.mark.parametrize("levels", [6, 7, 8, 9])
+def test_many_levels_lds_footprint(oracle, capi, levels):
+    """levels = 6..9 => 9..12 Gaussian planes per octave: k_extrema's DoG tile needs 72..107 KB of dynamic LDS
+    (above the 64 KB default limit), the last blur levels reach radius 30.  Planes bit-exact, extrema identical,
+    features within the budget."""
+    img = synth(320, 240, 900 + levels)
+    kw = dict(octaves=3, levels=levels)
+    ref = oracle.run(oracle.default_config(**kw), img)
+    ctx = capi.Context(capi.default_config(**kw))
+    ctx.upload(img)
+    ctx.extract()
+    _planes_and_extrema_equal(ctx, capi, ref)
+    fb, db = ctx.download()
+    _features_within_budget(ref, fb, db, "levels=%d" % levels)
+    ctx.close()
+
+
+def test_descriptor_bins_do_not_overflow_at_large_sigma(oracle, capi):
+    """The largest descriptor windows a legal Config can produce: levels=2 (the minimum, popsift.cpp:86) with
+    sigma=2.0 (the maximum, gauss_filter.cu:131) searches DoG levels 1..2 and refines up to sn = 3.5, i.e.
+    sigma <= 2*2^(3.5/2) = 6.7 and SBP = 3 sigma <= 20.2 octave pixels.  High-contrast blobs: the 18.14
+    fixed-point descriptor bins (orient_desc.hip) must hold the sums."""
+    img = np.zeros((300, 400), np.float64)
+    ys, xs = np.mgrid[0:300, 0:400]
+    rng = np.random.default_rng(3)
+    for _ in range(14):
+        cx, cy, s = rng.uniform(40, 360), rng.uniform(40, 260), rng.uniform(6, 14)
+        img += rng.choice([-1.0, 1.0]) * 120.0 * np.exp(-0.5 * ((xs - cx) ** 2 + (ys - cy) ** 2) / s ** 2)
+    img = np.clip(np.rint(img + 128.0 + synth(400, 300, 5).astype(np.float64) * 0.1 - 12.8), 0, 255).astype(np.uint8)
+    kw = dict(octaves=3, levels=2, sigma=2.0, upscale_factor=1.0)
+    ref = oracle.run(oracle.default_config(**kw), img)
+    ctx = capi.Context(capi.default_config(**kw))
+    ctx.upload(img)
+    ctx.extract()
+    fb, db = ctx.download()
+    assert len(fb) > 5
+    _features_within_budget(ref, fb, db, "large sigma")
+    ctx.close()
