@@ -4,39 +4,43 @@
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): 1920x1080 grayscale u8 frames, default Config with
-octaves=5, levels=3 (x2 upsample => octave 0 is 3840x2160).  A "step" is one batch of
-BATCH distinct synthetic frames, already resident in HBM, pushed through the full hot path
-(pyramid -> extrema -> orientation -> descriptors).  Frames are independent, so ranks share
-nothing: each rank processes its own BATCH frames per step (weak scaling, no collective on the
-data path); value = total pixels of all ranks / max-over-ranks time.
+Workload (BASELINE.json configs[1] / BASELINE.md workload 2): 1920x1080 grayscale u8 frames, default
+Config with octaves=5, levels=3 (x2 upsample => octave 0 is 3840x2160), distinct frames streamed
+through the product's public API: host image -> PopSift::enqueue -> SiftJob::get -> FeaturesHost
+(the C++14 library popsift_amd/lib/libpopsift.so, bound through include/popsift_c.h).  A "step" is
+BATCH = 8 frames per GPU.  Frames are independent: frame i of the global sequence goes to GPU i mod N
+(BASELINE config 4), ranks share nothing, no collective on the data path (weak scaling);
+value = total pixels of all ranks / max-over-ranks time, results of every timed frame collected inside the
+timed region.
 
-Two timed legs of K steps each, same frames, same kernels:
-  value        : inputs AND results resident in HBM (Feature records + descriptors stay in the
-                 context's device buffers, the reference's FeaturesDev / MatchingMode end state;
-                 only the two counters are read back per frame).  No PCIe inside the timed region.
-  host_export  : as above, plus every frame's Feature records and descriptors delivered into pinned
-                 host memory inside the timed region (psx_attach_export: the kernels stream them over
-                 PCIe; the reference's FeaturesHost / ExtractingMode end state, Pyramid::get_descriptors).
-
+Legs (same frames, same kernels, K steps each):
+  value / end_to_end : host frames in, FeaturesHost out (upload + full pipe + results in host memory)
+  device_resident    : C-ABI, inputs AND results resident in HBM (no PCIe in the timed region)
+  host_export        : C-ABI, inputs resident, Feature records + descriptors streamed to pinned host memory
 The JSON line also carries
-  roofline     : the separable-Gaussian kernel (k_blur, octave 0): algorithmic bytes (8 B/pixel)
-                 / average launch duration measured with HIP events on the kernel's stream
-  cpu_baseline : the CPU oracle (port of the reference arithmetic, OpenMP over all host cores)
-                 timed on a bounded sample of the same frames (rank 0, N=1 only)
+  roofline     : the separable-Gaussian kernel (k_blur, octave 0, levels 1..5): algorithmic bytes (8 B/pixel)
+                 / average duration of those launches measured IN the pipeline (begin/end events of each
+                 dispatch inside real psx_extract calls), next to the measured HBM copy rate of a hand-written
+                 16 B/lane copy kernel over 1 GiB
+  config3      : BASELINE config 3 (4096x4096, 6 octaves, 8192x8192 octave 0), device resident, one context
+  cpu_baseline : the CPU oracle (port of the reference arithmetic, OpenMP over the host cores) timed on a
+                 bounded sample of the same frames (rank 0, N=1 only)
 """
 import argparse
 import json
 import os
 import sys
 import time
+from collections import deque
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
 BATCH = 8          # frames per step per rank
-NCTX = int(os.environ.get("POPSIFT_BENCH_CTX", "16"))   # extraction contexts (pyramids + streams) in flight per GPU
+NDISTINCT = 64     # distinct frames per rank that the steps cycle through
+NCTX = int(os.environ.get("POPSIFT_BENCH_CTX", "16"))       # C-ABI legs: extraction contexts in flight per GPU
+MAX_OUT = int(os.environ.get("POPSIFT_BENCH_OUTSTANDING", "24"))   # end-to-end leg: jobs outstanding per PopSift
 HBM_PEAK_GBS = 8000.0
 
 
@@ -52,19 +56,103 @@ def usable_cores():
     return max(1, n)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def frame_seed(j, rank, world):
+    """Seed of this rank's j-th base frame: global frame i = j * world + rank goes to GPU i mod world."""
+    return 1000 + j * world + rank
 
+
+def make_frames(rank, world, synth):
+    """NDISTINCT distinct frames for this rank: BATCH synthetic base frames (popsift_amd/synth.py; base 0 of
+    rank 0 is the frame the parity tests check) and cheap distinct variants of them (cyclic shift + flip)."""
     import numpy as np
-    import torch
-    from popsift_amd import capi
-    from popsift_amd.synth import synth
+    base = [synth(W, H, frame_seed(j, rank, world)) for j in range(BATCH)]
+    frames = []
+    for v in range(NDISTINCT // BATCH):
+        for b in base:
+            f = b if v == 0 else np.roll(b, (53 * v, 97 * v), axis=(0, 1))
+            if v & 1:
+                f = f[:, ::-1]
+            frames.append(np.ascontiguousarray(f))
+    return frames
 
+
+class GpuBackend:
+    """Everything of the bench that touches the GPU (tests/test_distributed_cpu.py swaps in a stub with the same
+    interface to run the rank / seed / step / reduce control flow under gloo on CPU)."""
+    dist_backend = "nccl"
+
+    def __init__(self, rank, local_rank, world):
+        import numpy as np
+        import torch
+        from popsift_amd import capi
+        from popsift_amd.synth import synth
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+        torch.cuda.set_device(local_rank)
+        self.np, self.torch, self.capi = np, torch, capi
+        self.device = local_rank
+        self.dev = torch.device("cuda", local_rank)
+        self.frames_np = make_frames(rank, world, synth)
+        self.cfg = capi.default_config(octaves=5)
+        self.ps = None
+        self.ctxs = []
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def reduce_tensor(self, v):
+        return self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+
+    # ---- leg 1: the public C++ API, host frames in, FeaturesHost out ----
+    def e2e_open(self):
+        self.ps = self.capi.PopSift(self.cfg, device=self.device)
+
+    def e2e_enqueue(self, i):
+        return self.ps.enqueue(self.frames_np[i % NDISTINCT])      # PopSift::enqueue (deep copy of the image)
+
+    def e2e_get(self, job):
+        return self.ps.get_counts(job)[0]                          # SiftJob::get (blocks); FeaturesHost deleted
+
+    def e2e_close(self):
+        self.ps.close()
+        self.ps = None
+
+    # ---- legs 2, 3: C-ABI, inputs already resident in HBM ----
+    def abi_open(self):
+        torch, capi = self.torch, self.capi
+        self.frames = [torch.from_numpy(f).to(self.dev) for f in self.frames_np[:BATCH]]
+        torch.cuda.synchronize()
+        self.ctxs = [capi.Context(self.cfg, device=self.device) for _ in range(NCTX)]
+        cap_f, cap_d = 100000, 200000
+        self.pin_f = [torch.empty(cap_f * capi.FEATURE_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in range(NCTX)]
+        self.pin_d = [torch.empty(cap_d * 128, dtype=torch.float32).pin_memory() for _ in range(NCTX)]
+
+    def abi_export(self, on):
+        for c in range(NCTX):
+            if on:
+                self.ctxs[c].attach_export(self.pin_f[c], self.pin_d[c])
+            else:
+                self.ctxs[c].attach_export(None, None)
+
+    def abi_submit(self, c, i):
+        self.ctxs[c].set_input_tensor(self.frames[i])
+        self.ctxs[c].extract()
+
+    def abi_collect(self, c):
+        return self.ctxs[c].counts()[0]
+
+    def abi_close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+
+    def extras(self, args, world):
+        return extras(args, self.capi, self.torch, self.np, self.ctxs, self.frames, self.frames_np, world, self.device)
+
+
+def run(args, backend_cls=GpuBackend, out=sys.stdout):
+    """The bench proper: rank / world from the environment, one process per GPU, three timed legs, rank 0
+    prints ONE JSON line.  Returns the dict (rank 0) or None."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,71 +160,28 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend_cls.dist_backend, rank=rank, world_size=world)
     else:
         dist = None
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    # synthetic frames, resident in HBM before the timed region
-    frames_np = [synth(W, H, 1000 + rank * BATCH + i) for i in range(BATCH)]
-    frames = [torch.from_numpy(f).to(dev) for f in frames_np]
-    torch.cuda.synchronize()
-
-    cfg = capi.default_config(octaves=5)
-    ctxs = [capi.Context(cfg, device=local_rank) for _ in range(NCTX)]
-    # pinned host destinations, one per context (Pyramid::get_descriptors downloads into pinned memory)
-    cap_f, cap_d = 100000, 200000
-    pin_f = [torch.empty(cap_f * capi.FEATURE_DTYPE.itemsize, dtype=torch.uint8).pin_memory() for _ in range(NCTX)]
-    pin_d = [torch.empty(cap_d * 128, dtype=torch.float32).pin_memory() for _ in range(NCTX)]
-
-    def set_export(on):
-        # zero-copy export: the kernels stream features / descriptors into the pinned buffers over PCIe
-        for c in range(NCTX):
-            if on:
-                ctxs[c].attach_export(pin_f[c], pin_d[c])
-            else:
-                ctxs[c].attach_export(None, None)
-
-    def submit(c, i):
-        ctxs[c].set_input_tensor(frames[i])
-        ctxs[c].extract()
-
-    def collect(c):
-        # waits for the frame of context c; afterwards its results are in pin_f[c] / pin_d[c]
-        return ctxs[c].counts()
-
-    inflight = []          # contexts with a frame in flight, oldest first (persists across steps)
-    state = {"next": 0}
-
-    def step():
-        """One step = BATCH frames submitted; results of older frames are collected as the ring of
-        contexts fills up, so the pipeline stays full across step boundaries."""
-        kp = 0
-        for i in range(BATCH):
-            if len(inflight) == NCTX:
-                kp += collect(inflight.pop(0))[0]
-            c = state["next"]
-            state["next"] = (c + 1) % NCTX
-            submit(c, i)
-            inflight.append(c)
-        return kp
-
-    def drain():
-        kp = 0
-        while inflight:
-            kp += collect(inflight.pop(0))[0]
-        return kp
+    be = backend_cls(rank, local_rank, world)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        be.sync()
 
-    def timed_leg(export):
-        set_export(export)
+    def reduce_max_sum(dt, kps):
+        if dist is None:
+            return dt, float(kps)
+        tt = be.reduce_tensor(dt)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        kk = be.reduce_tensor(kps)
+        dist.all_reduce(kk, op=dist.ReduceOp.SUM)
+        return float(tt.item()), float(kk.item())
+
+    def timed(step, drain):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; every frame of the K steps
+        is complete (and collected) inside the timed region."""
         for _ in range(args.warmup):
             step()
         drain()
@@ -145,148 +190,228 @@ def main():
         kps = 0
         for _ in range(args.steps):
             kps += step()
-        kps += drain()          # every frame of the K steps is complete (and collected) inside the timed region
+        kps += drain()
         barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-            kk = torch.tensor([kps], dtype=torch.float64, device=dev)
-            dist.all_reduce(kk, op=dist.ReduceOp.SUM)
-            kps = float(kk.item())
-        return dt, float(kps)
+        return reduce_max_sum(time.perf_counter() - t0, kps)
 
-    dt, kps_total = timed_leg(False)        # the headline leg: everything stays in HBM
-    dt_x, _ = timed_leg(True)               # same work + delivery to pinned host memory
-    set_export(False)
+    # ---- leg 1 (headline): the public C++ API, host frames in, FeaturesHost out ----
+    be.e2e_open()
+    jobs = deque()
+    e2e = {"i": 0}
+
+    def e2e_step():
+        kp = 0
+        for _ in range(BATCH):
+            if len(jobs) >= MAX_OUT:
+                kp += be.e2e_get(jobs.popleft())
+            jobs.append(be.e2e_enqueue(e2e["i"]))
+            e2e["i"] += 1
+        return kp
+
+    def e2e_drain():
+        kp = 0
+        while jobs:
+            kp += be.e2e_get(jobs.popleft())
+        return kp
+
+    dt_e2e, kps_e2e = timed(e2e_step, e2e_drain)
+    be.e2e_close()
+
+    # ---- legs 2 and 3: C-ABI, inputs already resident in HBM ----
+    be.abi_open()
+    inflight = deque()
+    state = {"next": 0}
+
+    def abi_step():
+        kp = 0
+        for i in range(BATCH):
+            if len(inflight) == NCTX:
+                kp += be.abi_collect(inflight.popleft())
+            c = state["next"]
+            state["next"] = (c + 1) % NCTX
+            be.abi_submit(c, i)
+            inflight.append(c)
+        return kp
+
+    def abi_drain():
+        kp = 0
+        while inflight:
+            kp += be.abi_collect(inflight.popleft())
+        return kp
+
+    be.abi_export(False)
+    dt_dev, kps_dev = timed(abi_step, abi_drain)
+    be.abi_export(True)
+    dt_x, _ = timed(abi_step, abi_drain)
+    be.abi_export(False)
 
     n_frames = world * BATCH * args.steps
-    mpix_s = n_frames * W * H / dt / 1e6
+    rate = lambda dt: round(n_frames * W * H / dt / 1e6, 1)
 
+    result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: separable Gaussian, octave 0, levels 1..L-1 ----
-        c0 = ctxs[0]
-        c0.sync()
-        tot_ms, tot_bytes, nl = 0.0, 0.0, 0
-        for lvl in range(1, c0.num_levels):
-            c0.time_blur(0, lvl, 5)                     # warm
-            ms, by = c0.time_blur(0, lvl, 50)
-            tot_ms += ms
-            tot_bytes += by
-            nl += 1
-        achieved = tot_bytes / (tot_ms * 1e-3) / 1e9     # GB/s, algorithmic 8 B/pixel
-        # what the memory system delivers on this box (torch is only the memcpy + event timer here):
-        #   measured_copy       a 1 GiB -> 1 GiB device copy (the "measured HBM roofline"; the
-        #                       working set is far beyond the 256 MB Infinity Cache)
-        #   measured_copy_plane a copy of one octave-0 plane (33 MB), i.e. what "read a plane, write a
-        #                       plane" costs with the plane sizes k_blur actually works on
-        def copy_rate(nfloats, reps):
-            src_t = torch.rand(nfloats, device=dev)
-            dst_t = torch.empty_like(src_t)
-            for _ in range(3):
-                dst_t.copy_(src_t)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                dst_t.copy_(src_t)
-            e1.record()
-            torch.cuda.synchronize()
-            return 2.0 * nfloats * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        pw, ph = c0.octave_dims(0)
-        copy_gbs = copy_rate(1 << 28, 10)
-        copy_plane_gbs = copy_rate(pw * ph, 50)
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
-        # and --pmc WRITE_SIZE in separate runs, 2x FETCH_SIZE correction); null when not collected
-        traffic = None
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["k_blur_octave0_hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        roofline = {"bound": "hbm", "kernel": "k_blur (octave 0, 3840x2160, levels 1..5)",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "avg_launch_ms": round(tot_ms / nl, 5), "bytes_per_launch": tot_bytes / nl,
-                    "traffic": traffic,
-                    "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
-                    "measured_copy_plane": round(copy_plane_gbs, 1)}
-
-        # one frame at a time on one context (BASELINE config 2, "single frame"): wall-clock latency
-        c0.set_input_tensor(frames[0])
-        lat = []
-        for i in range(25):
-            t1 = time.perf_counter()
-            c0.extract()
-            c0.counts()
-            lat.append(time.perf_counter() - t1)
-        lat = sorted(lat[5:])
-        single_ms = lat[len(lat) // 2] * 1e3
-
-        # per-stage device time of one frame (HIP events on the context's stream)
-        c0.enable_timers(True)
-        c0.set_input_tensor(frames[0])
-        c0.extract()
-        stages = c0.stage_times()
-        c0.enable_timers(False)
-
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import pyoracle as po
-            ocfg = po.default_config(octaves=5)
-            ncores = usable_cores()
-            po.run(ocfg, frames_np[0], threads=ncores).close()     # warm
-            n_s = 0
-            t1 = time.perf_counter()
-            while n_s < BATCH and (n_s < 2 or time.perf_counter() - t1 < 12.0):
-                r = po.run(ocfg, frames_np[n_s], threads=ncores)
-                r.close()
-                n_s += 1
-            cdt = time.perf_counter() - t1
-            cpu = {"value": round(n_s * W * H / cdt / 1e6, 2), "unit": "Mpix/s", "cores": ncores,
-                   "kind": "port", "sample": "%d frames 1920x1080, oracle/liboracle.so with OpenMP" % n_s}
-            # OpenCV's CPU SIFT next to it when the box has cv2; this image does not ship it
-            try:
-                import cv2
-                cv2.setNumThreads(ncores)
-                sift = cv2.SIFT_create(nOctaveLayers=3, contrastThreshold=0.04, edgeThreshold=10, sigma=1.6)
-                t2 = time.perf_counter()
-                nk = len(sift.detectAndCompute(frames_np[0], None)[0])
-                cpu["opencv_sift"] = {"value": round(W * H / (time.perf_counter() - t2) / 1e6, 2), "unit": "Mpix/s",
-                                      "cores": ncores, "keypoints": nk, "sample": "1 frame 1920x1080"}
-            except Exception:
-                cpu["opencv_sift"] = "absent (cv2 is not installed in this image)"
-
-        out = {
+        result = {
             "metric": "Mpixels/sec end-to-end SIFT (5 oct, 3 lvl/oct) + keypoints/sec",
-            "value": round(mpix_s, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "value": rate(dt_e2e), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt_e2e / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "1920x1080 u8 frames, default Config, octaves=5, levels=3, "
-                                   "upscale x2 (octave 0 = 3840x2160), full pipe (pyramid, extrema, orientation, "
-                                   "descriptors), inputs and results resident in HBM",
-                       "frames_per_step_per_gpu": BATCH, "contexts_per_gpu": NCTX,
-                       "parallelism": "replicas x%d (one image per GPU, no collective)" % world},
-            "keypoints_per_s": round(kps_total / dt, 1),
-            "keypoints_per_frame": round(kps_total / n_frames, 1),
-            "ms_per_frame": round(dt / (BATCH * args.steps) * 1e3, 4),
-            "single_frame": {"ms": round(single_ms, 4), "value": round(W * H / single_ms / 1e3, 1), "unit": "Mpix/s",
-                             "what": "median wall time of one frame at a time on one context (no overlap between frames)"},
-            "stage_ms_single_frame": {"pyramid": round(stages[0], 4), "extrema": round(stages[1], 4),
-                                      "orientation": round(stages[2], 4), "descriptors": round(stages[3], 4)},
-            "host_export": {"value": round(n_frames * W * H / dt_x / 1e6, 1), "unit": "Mpix/s",
-                            "ms_per_step": round(dt_x / args.steps * 1e3, 4),
-                            "what": "same steps with Feature records + descriptors streamed into pinned host memory"},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
+            "config": {"workload": "1920x1080 u8 host frames (%d distinct per GPU) -> PopSift::enqueue -> SiftJob::get -> "
+                                   "FeaturesHost (C++ API of libpopsift.so, upload and result delivery inside the timed "
+                                   "region); default Config, octaves=5, levels=3, upscale x2 (octave 0 = 3840x2160), full "
+                                   "pipe (pyramid, extrema, orientation, descriptors)" % NDISTINCT,
+                       "frames_per_step_per_gpu": BATCH, "frames_timed": n_frames,
+                       "jobs_outstanding_per_gpu": MAX_OUT,
+                       "pipe_depth": int(os.environ.get("POPSIFT_PIPE_DEPTH", "8")),
+                       "parallelism": "replicas x%d (frame i -> GPU i mod N, no collective)" % world},
+            "keypoints_per_s": round(kps_e2e / dt_e2e, 1),
+            "keypoints_per_frame": round(kps_e2e / n_frames, 1),
+            "ms_per_frame": round(dt_e2e / (BATCH * args.steps) * 1e3, 4),
+            "device_resident": {"value": rate(dt_dev), "unit": "Mpix/s", "ms_per_step": round(dt_dev / args.steps * 1e3, 4),
+                                "keypoints_per_s": round(kps_dev / dt_dev, 1), "contexts_per_gpu": NCTX,
+                                "what": "C-ABI psx_extract, inputs and results resident in HBM (no PCIe in the timed region)"},
+            "host_export": {"value": rate(dt_x), "unit": "Mpix/s", "ms_per_step": round(dt_x / args.steps * 1e3, 4),
+                            "what": "C-ABI, inputs resident in HBM, Feature records + descriptors streamed into pinned host memory"},
         }
-        print(json.dumps(out), flush=True)
+        if not args.no_extras:
+            result.update(be.extras(args, world))
+        print(json.dumps(result), file=out, flush=True)
 
-    for c in ctxs:
-        c.close()
+    be.abi_close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return result
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the three timed legs")
+    return ap.parse_args(argv)
+
+
+def main():
+    run(parse_args())
+
+
+def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
+    """Rank-0 measurements outside the timed legs: roofline of the dominant kernel, single-frame latency and
+    stage times, BASELINE config 3, CPU baseline."""
+    ex = {}
+    c0 = ctxs[0]
+    c0.sync()
+
+    # ---- roofline of the dominant kernel, measured in the pipeline ----
+    c0.enable_blur_probe(True)
+    c0.set_input_tensor(frames[0])
+    per_level = None
+    nrep = 0
+    for it in range(24):
+        c0.extract()
+        ms, by = c0.blur_probe_times()
+        if it >= 4:                                         # first frames warm caches / clocks
+            per_level = ms if per_level is None else [a + b for a, b in zip(per_level, ms)]
+            nrep += 1
+    c0.enable_blur_probe(False)
+    per_level = [m / nrep for m in per_level]
+    avg_ms = sum(per_level) / len(per_level)
+    achieved = by / (avg_ms * 1e-3) / 1e9                   # GB/s, algorithmic 8 B/pixel
+    # isolated replay of each level (round-1 method), for comparison only
+    iso = []
+    for lvl in range(1, c0.num_levels):
+        c0.time_blur(0, lvl, 3)
+        iso.append(c0.time_blur(0, lvl, 30)[0])
+    copy_gbs, copy_ms = capi.copy_bench(device, 1 << 30, 10)
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["k_blur_octave0_hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    ex["roofline"] = {
+        "bound": "hbm", "kernel": "k_blur (octave 0, 3840x2160, levels 1..5), timed inside psx_extract",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "avg_launch_ms": round(avg_ms, 5), "per_level_ms": [round(m, 5) for m in per_level],
+        "bytes_per_launch": by, "traffic": traffic,
+        "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+        "measured_copy_what": "hand-written 16 B/lane copy kernel, 1 GiB read + 1 GiB written (psx_copy_bench)",
+        "isolated_replay_avg_ms": round(sum(iso) / len(iso), 5),
+    }
+
+    # ---- one frame at a time on one context (BASELINE config 2, "single frame") ----
+    lat = []
+    for i in range(25):
+        t1 = time.perf_counter()
+        c0.extract()
+        c0.counts()
+        lat.append(time.perf_counter() - t1)
+    lat = sorted(lat[5:])
+    single_ms = lat[len(lat) // 2] * 1e3
+    c0.enable_timers(True)
+    c0.extract()
+    stages = c0.stage_times()
+    c0.enable_timers(False)
+    ex["single_frame"] = {"ms": round(single_ms, 4), "value": round(W * H / single_ms / 1e3, 1), "unit": "Mpix/s",
+                          "what": "median wall time of one frame at a time on one context (no overlap between frames)"}
+    ex["stage_ms_single_frame"] = {"pyramid": round(stages[0], 4), "extrema": round(stages[1], 4),
+                                   "orientation": round(stages[2], 4), "descriptors": round(stages[3], 4)}
+
+    # ---- BASELINE config 3: 4096x4096, 6 octaves (octave 0 = 8192x8192), one context, device resident ----
+    try:
+        from popsift_amd.synth import synth
+        big = torch.from_numpy(np.ascontiguousarray(np.tile(frames_np[0], (4, 3))[:4096, :4096])).to(frames[0].device)
+        c3 = capi.Context(capi.default_config(octaves=6), device=device)
+        c3.set_input_tensor(big)
+        for _ in range(3):
+            c3.extract()
+        n3 = c3.counts()
+        t1 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            c3.extract()
+        n3 = c3.counts()
+        d3 = (time.perf_counter() - t1) / reps
+        ex["config3"] = {"value": round(4096 * 4096 / d3 / 1e6, 1), "unit": "Mpix/s", "ms_per_frame": round(d3 * 1e3, 3),
+                         "keypoints": n3[0], "descriptors": n3[1],
+                         "what": "4096x4096 u8 (tiled synthetic frame), octaves=6, upscale x2 (octave 0 = 8192x8192), "
+                                 "one context, frames back to back, device resident"}
+        c3.close()
+        del big
+    except Exception as e:                                   # never lose the headline to an extra
+        ex["config3"] = "failed: %s" % e
+
+    # ---- CPU baseline (bounded sample) ----
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        ocfg = po.default_config(octaves=5)
+        ncores = usable_cores()
+        po.run(ocfg, frames_np[0], threads=ncores).close()     # warm
+        n_s = 0
+        t1 = time.perf_counter()
+        while n_s < BATCH and (n_s < 2 or time.perf_counter() - t1 < 12.0):
+            po.run(ocfg, frames_np[n_s], threads=ncores).close()
+            n_s += 1
+        cdt = time.perf_counter() - t1
+        cpu = {"value": round(n_s * W * H / cdt / 1e6, 2), "unit": "Mpix/s", "cores": ncores,
+               "kind": "port", "sample": "%d frames 1920x1080, oracle/liboracle.so with OpenMP" % n_s}
+        try:
+            import cv2
+            cv2.setNumThreads(ncores)
+            sift = cv2.SIFT_create(nOctaveLayers=3, contrastThreshold=0.04, edgeThreshold=10, sigma=1.6)
+            t2 = time.perf_counter()
+            nk = len(sift.detectAndCompute(frames_np[0], None)[0])
+            cpu["opencv_sift"] = {"value": round(W * H / (time.perf_counter() - t2) / 1e6, 2), "unit": "Mpix/s",
+                                  "cores": ncores, "keypoints": nk, "sample": "1 frame 1920x1080"}
+        except Exception:
+            cpu["opencv_sift"] = "absent (cv2 is not installed in this image)"
+        ex["cpu_baseline"] = cpu
+    else:
+        ex["cpu_baseline"] = None
+    return ex
 
 
 if __name__ == "__main__":

@@ -83,6 +83,19 @@ typedef struct psx_feature {
     int   desc_idx[PSX_ORI_MAX];
 } psx_feature;
 
+/* popsift::Feature itself (features.h:23-37) as laid out by the x86-64 and gfx950 ABIs (72 bytes), with
+ * DEVICE descriptor pointers: what FeaturesDev::getFeatures() points at (features.h:104-122). */
+typedef struct psx_feature_dev {
+    int    debug_octave;
+    float  xpos;
+    float  ypos;
+    float  sigma;
+    int    num_ori;
+    float  orientation[PSX_ORI_MAX];
+    int    pad;
+    float* desc[PSX_ORI_MAX];
+} psx_feature_dev;
+
 /* popsift::InitialExtremum (sift_extremum.h:25-39) as stored by the extrema kernel. */
 typedef struct psx_iext {
     float xpos;
@@ -208,8 +221,9 @@ int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float
                        const int** d_feat_to_ext);
 
 /* FeaturesDev support (MatchingMode, popsift.cpp:346-383, sift_pyramid.cu:324-362): device
- * buffers owned by the caller and a device-to-device clone of the last results
- * (features as psx_feature records, descriptors, descriptor->extremum map). */
+ * buffers owned by the caller and a device-to-device clone of the last results: descriptors,
+ * descriptor->extremum map, and the features as psx_feature_dev records (= popsift::Feature, 72 bytes)
+ * whose desc[] point INTO d_descriptors, as Pyramid::clone_device_descriptors + prep_features leave them. */
 /* pinned, GPU-mapped host memory (hipHostMalloc): cheap targets for psx_attach_export and sources for
  * psx_upload_*.  Allocation is slow (pool the buffers). */
 int psx_host_alloc(size_t bytes, void** out);
@@ -235,6 +249,9 @@ int psx_match(int device, const float* d_left, int l_len, const float* d_right, 
 /* device_prop_t (common/device_prop.h:23-108): enumeration only; there are no texture limits. */
 int psx_device_count(int* count);
 int psx_device_info(int device, char* name, int name_len, size_t* total_mem, int* compute_units, int* clock_khz);
+/* PCI bus id ("0000:c1:00.0") of a device: lets the host library place its worker threads on the CPUs
+ * local to the GPU (sysfs local_cpulist) when it drives one PopSift per GPU (popsift.h:158,166-168). */
+int psx_device_pci(int device, char* bus_id, int len);
 
 /* ---- introspection for parity tests (Octave::download_and_save_array, sift_octave.cu:111-188) */
 
@@ -259,6 +276,20 @@ int psx_stage_times(psx_ctx* ctx, float ms[4]);
  * on the context's stream and returns the average duration in ms plus the algorithmic bytes
  * of one launch (8 bytes per pixel: plane read once, written once). */
 int psx_time_blur(psx_ctx* ctx, int octave, int level, int reps, float* avg_ms, double* bytes);
+
+/* In-pipeline timing of the dominant kernel: when enabled, every separable-Gaussian launch of octave 0
+ * (levels 1..L-1) INSIDE psx_extract / psx_build_pyramid carries a begin and an end event of its own
+ * dispatch (hipExtLaunchKernel: the kernel's start / end timestamps, the quantity rocprofv3 --kernel-trace
+ * reports); the launches run back to back with their real producers and consumers, not replayed in isolation.
+ * psx_blur_probe_times synchronises and returns the n = L-1 durations (ms) of the last extraction plus the
+ * algorithmic bytes of one launch (8 B per octave-0 pixel). */
+int psx_enable_blur_probe(psx_ctx* ctx, int on);
+int psx_blur_probe_times(psx_ctx* ctx, float* ms, int capacity, int* n, double* bytes_per_launch);
+
+/* Measured HBM roofline: a hand-written 16 B-per-lane streaming copy kernel over `bytes`
+ * (0 = 1 GiB) read + `bytes` written, `reps` timed launches after warm-up, HIP events on its own stream;
+ * the better of a plain and a non-temporal variant.  avg_ms per launch, bytes_moved = 2 * bytes. */
+int psx_copy_bench(int device, size_t bytes, int reps, float* avg_ms, double* bytes_moved);
 
 /* The HIP stream of the context as an opaque handle (hipStream_t), for callers that need to
  * order their own work (e.g. a torch tensor producer) against it. */

@@ -1120,7 +1120,11 @@ static osift_result* run_impl(const osift_config* cin, const void* img, int w, i
     }
     /* ori_prefix_sum, s_orientation.cu:320-362 */
     const int max_orientations = c->max_extrema + c->max_extrema / 4;
-    const int ori_allocated = imax(2 * c->max_extrema, max_orientations);
+    int ori_allocated = imax(2 * c->max_extrema, max_orientations);            /* sift_pyramid.cu:154-159 */
+    /* Pyramid::reallocExtrema (sift_pyramid.cu:179-209): more extrema than the initial max_extrema entries =>
+     * extrema buffers grow to the count rounded up to 1024 and the descriptor buffers to twice that.
+     * Orientations beyond the capacity are dropped here (the reference would write past its buffer). */
+    if (ext_total > c->max_extrema) ori_allocated = imax(ori_allocated, 2 * ((ext_total + 1024) & ~1023));
     int total_ori = 0;
     for (int i = 0; i < ext_total; i++) { r->ext[i].idx_ori = total_ori; total_ori += r->ext[i].num_ori; }
     if (total_ori > ori_allocated) total_ori = ori_allocated;

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 
-HIP_SOURCES = ["pyramid.hip", "extrema.hip", "orient_desc.hip", "gridfilter.hip", "match.hip", "api.hip"]
+HIP_SOURCES = ["pyramid.hip", "extrema.hip", "orient_desc.hip", "gridfilter.hip", "match.hip", "util.hip", "api.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # no implicit fused multiply-add: the arithmetic order is part of the parity contract
@@ -26,7 +26,7 @@ HIP_FLAGS = [
     "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "hip"),
 ]
 
-HOST_SOURCES = ["popsift.cpp", "sift_conf.cpp", "features.cpp", "device_prop.cpp"]
+HOST_SOURCES = ["popsift.cpp", "sift_conf.cpp", "features.cpp", "device_prop.cpp", "popsift_c.cpp"]
 HOST_FLAGS = ["-O2", "-std=c++14", "-fPIC", "-Wall", "-pthread",
               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "include")]
 

@@ -42,6 +42,10 @@ class Config(C.Structure):
 FEATURE_DTYPE = np.dtype([("debug_octave", "<i4"), ("xpos", "<f4"), ("ypos", "<f4"), ("sigma", "<f4"),
                           ("num_ori", "<i4"), ("orientation", "<f4", (ORI_MAX,)),
                           ("desc_idx", "<i4", (ORI_MAX,))])
+# popsift::Feature as stored in a FeaturesDev (psx_feature_dev, 72 bytes; desc[] are device addresses)
+FEATURE_DEV_DTYPE = np.dtype([("debug_octave", "<i4"), ("xpos", "<f4"), ("ypos", "<f4"), ("sigma", "<f4"),
+                              ("num_ori", "<i4"), ("orientation", "<f4", (ORI_MAX,)), ("pad", "<i4"),
+                              ("desc", "<u8", (ORI_MAX,))])
 IEXT_DTYPE = np.dtype([("xpos", "<f4"), ("ypos", "<f4"), ("lpos", "<i4"), ("sigma", "<f4"),
                        ("cell", "<i4"), ("ignore", "<i4")])
 EXT_DTYPE = np.dtype([("xpos", "<f4"), ("ypos", "<f4"), ("lpos", "<i4"), ("sigma", "<f4"),
@@ -56,7 +60,8 @@ SYMBOLS = [
     "psx_find_extrema", "psx_orientation", "psx_descriptors", "psx_extract", "psx_sync", "psx_counts",
     "psx_download", "psx_attach_export", "psx_device_results", "psx_dump_plane", "psx_dump_iext", "psx_dump_extrema",
     "psx_set_wait_mode", "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
-    "psx_host_alloc", "psx_host_free", "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_dev_write", "psx_clone_results", "psx_match", "psx_device_count", "psx_device_info",
+    "psx_host_alloc", "psx_host_free", "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_dev_write", "psx_clone_results", "psx_match", "psx_device_count", "psx_device_info", "psx_device_pci",
+    "psx_enable_blur_probe", "psx_blur_probe_times", "psx_copy_bench",
 ]
 
 _LIB = None
@@ -106,6 +111,10 @@ def lib():
         L.psx_time_blur.argtypes = [vp, C.c_int, C.c_int, C.c_int, fp, C.POINTER(C.c_double)]
         L.psx_stream.argtypes = [vp]
         L.psx_stream.restype = vp
+        L.psx_enable_blur_probe.argtypes = [vp, C.c_int]
+        L.psx_blur_probe_times.argtypes = [vp, fp, C.c_int, ip, C.POINTER(C.c_double)]
+        L.psx_copy_bench.argtypes = [C.c_int, C.c_size_t, C.c_int, fp, C.POINTER(C.c_double)]
+        L.psx_device_pci.argtypes = [C.c_int, C.c_char_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -276,6 +285,32 @@ class Context:
                                      desc.ctypes.data_as(C.c_void_p), no))
         return feats, desc
 
+    def clone_results(self, device=0):
+        """psx_clone_results into caller-owned device buffers (what FeaturesDev holds), read back:
+        (Feature records with device pointers, descriptors, descriptor->extremum map, device address of descriptor 0)."""
+        L = lib()
+        L.psx_dev_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.psx_dev_free.argtypes = [C.c_int, C.c_void_p]
+        L.psx_dev_read.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.psx_clone_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        ne, no = self.counts()
+        pf, pd, pr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        for p, n in ((pf, max(ne, 1) * FEATURE_DEV_DTYPE.itemsize), (pd, max(no, 1) * 512), (pr, max(no, 1) * 4)):
+            if L.psx_dev_alloc(device, n, C.byref(p)) != 0:
+                raise PopSiftError("psx_dev_alloc failed")
+        try:
+            self._chk(L.psx_clone_results(self._h, pf, pd, pr))
+            feats = np.zeros((ne,), dtype=FEATURE_DEV_DTYPE)
+            desc = np.zeros((no, 128), dtype=np.float32)
+            rev = np.zeros((no,), dtype=np.int32)
+            for arr, p in ((feats, pf), (desc, pd), (rev, pr)):
+                if arr.nbytes and L.psx_dev_read(device, arr.ctypes.data_as(C.c_void_p), p, arr.nbytes) != 0:
+                    raise PopSiftError("psx_dev_read failed")
+            return feats, desc, rev, pd.value
+        finally:
+            for p in (pf, pd, pr):
+                L.psx_dev_free(device, p)
+
     def attach_export(self, feat_buf, desc_buf):
         """Attach host buffers for zero-copy export.  feat_buf: uint8 buffer (numpy array or pinned
         torch tensor) of n*52 bytes, desc_buf: float32 buffer of m*128 floats.  None detaches."""
@@ -339,6 +374,117 @@ class Context:
         self._chk(lib().psx_time_blur(self._h, octave, level, reps, C.byref(ms), C.byref(by)))
         return ms.value, by.value
 
+    def enable_blur_probe(self, on=True):
+        self._chk(lib().psx_enable_blur_probe(self._h, 1 if on else 0))
+
+    def blur_probe_times(self):
+        """Durations (ms) of the octave-0 blur launches of the last extraction, timed in the pipeline, and the
+        algorithmic bytes of one launch."""
+        ms = (C.c_float * GAUSS_LEVELS)()
+        n, by = C.c_int(), C.c_double()
+        self._chk(lib().psx_blur_probe_times(self._h, ms, GAUSS_LEVELS, C.byref(n), C.byref(by)))
+        return [ms[i] for i in range(n.value)], by.value
+
     @property
     def stream(self):
         return lib().psx_stream(self._h)
+
+
+def copy_bench(device=0, nbytes=0, reps=10):
+    """Measured HBM roofline: (GB/s, ms per launch) of the 16 B/lane streaming copy kernel (psx_copy_bench)."""
+    ms, by = C.c_float(), C.c_double()
+    rc = lib().psx_copy_bench(device, nbytes, reps, C.byref(ms), C.byref(by))
+    if rc != 0:
+        raise PopSiftError("psx_copy_bench failed (%d)" % rc)
+    return by.value / (ms.value * 1e-3) / 1e9, ms.value
+
+
+# ---- the C++ host library through its flat C binding (include/popsift_c.h) --------------------------
+HOST_LIB_PATH = os.environ.get("POPSIFT_HOST_LIB") or os.path.join(_HERE, "lib", "libpopsift.so")
+HOST_SYMBOLS = ["popsift_c_create", "popsift_c_destroy", "popsift_c_enqueue_u8", "popsift_c_enqueue_f32",
+                "popsift_c_get", "popsift_c_feature_count", "popsift_c_descriptor_count", "popsift_c_copy",
+                "popsift_c_descriptors", "popsift_c_free", "popsift_c_last_error"]
+_HOST = None
+
+
+def host_lib():
+    global _HOST
+    if _HOST is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise PopSiftError("%s is missing: build it with `python -m popsift_amd.build`" % HOST_LIB_PATH)
+        lib()                                   # libpopsift.so links against libpopsift_hip.so
+        H = C.CDLL(HOST_LIB_PATH)
+        vp = C.c_void_p
+        H.popsift_c_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int]
+        H.popsift_c_create.restype = vp
+        H.popsift_c_destroy.argtypes = [vp]
+        H.popsift_c_destroy.restype = None
+        for n in ("popsift_c_enqueue_u8", "popsift_c_enqueue_f32"):
+            getattr(H, n).argtypes = [vp, C.c_int, C.c_int, vp]
+            getattr(H, n).restype = vp
+        H.popsift_c_get.argtypes = [vp]
+        H.popsift_c_get.restype = vp
+        H.popsift_c_feature_count.argtypes = [vp]
+        H.popsift_c_descriptor_count.argtypes = [vp]
+        H.popsift_c_copy.argtypes = [vp, vp, vp]
+        H.popsift_c_descriptors.argtypes = [vp]
+        H.popsift_c_descriptors.restype = vp
+        H.popsift_c_free.argtypes = [vp]
+        H.popsift_c_free.restype = None
+        H.popsift_c_last_error.restype = C.c_char_p
+        _HOST = H
+    return _HOST
+
+
+class PopSift:
+    """PopSift / SiftJob / FeaturesHost of the C++ library (popsift/popsift.h), through popsift_c.h:
+    enqueue(img) -> job handle, get(job) -> (features, descriptors) numpy arrays or just the counts."""
+
+    def __init__(self, cfg=None, device=0, float_images=False):
+        self.cfg = cfg if cfg is not None else default_config()
+        self._h = host_lib().popsift_c_create(C.byref(self.cfg), 1 if float_images else 0, device)
+        if not self._h:
+            raise PopSiftError("popsift_c_create failed: %s" % host_lib().popsift_c_last_error().decode())
+        self._float = float_images
+
+    def enqueue(self, img):
+        """img: C-contiguous (h, w) numpy array, uint8 or float32 (matching the image mode)."""
+        h, w = img.shape
+        f = host_lib().popsift_c_enqueue_f32 if self._float else host_lib().popsift_c_enqueue_u8
+        job = f(self._h, w, h, img.ctypes.data)
+        if not job:
+            raise PopSiftError("enqueue refused the image: %s" % host_lib().popsift_c_last_error().decode())
+        return job
+
+    def get_counts(self, job):
+        """SiftJob::get, then only the two counts; the FeaturesHost is deleted."""
+        H = host_lib()
+        f = H.popsift_c_get(job)
+        if not f:
+            raise PopSiftError("SiftJob::get failed: %s" % H.popsift_c_last_error().decode())
+        n = (H.popsift_c_feature_count(f), H.popsift_c_descriptor_count(f))
+        H.popsift_c_free(f)
+        return n
+
+    def get(self, job):
+        H = host_lib()
+        f = H.popsift_c_get(job)
+        if not f:
+            raise PopSiftError("SiftJob::get failed: %s" % H.popsift_c_last_error().decode())
+        ne, no = H.popsift_c_feature_count(f), H.popsift_c_descriptor_count(f)
+        feats = np.zeros((ne,), dtype=FEATURE_DTYPE)
+        desc = np.zeros((no, 128), dtype=np.float32)
+        H.popsift_c_copy(f, feats.ctypes.data, desc.ctypes.data)
+        H.popsift_c_free(f)
+        return feats, desc
+
+    def close(self):
+        if self._h:
+            host_lib().popsift_c_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

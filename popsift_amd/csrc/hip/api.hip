@@ -132,13 +132,17 @@ struct psx_ctx {
     psx_feature* x_dev_feat = nullptr;  float* x_dev_desc = nullptr;
     int x_feat_cap = 0, x_desc_cap = 0;
     bool x_registered_feat = false, x_registered_desc = false;
-    int* h_xcnt = nullptr;             // pinned [2]
+    int* h_xcnt = nullptr;             // pinned [4]: ext_total, ori_total, ori_raw
 
     bool timers = false;
     bool blocking_wait = false;        // psx_set_wait_mode: sleep on an event instead of spinning in hipStreamSynchronize
     hipEvent_t ev_wait = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    // in-pipeline timing of the octave-0 separable-Gaussian launches (psx_enable_blur_probe)
+    bool blur_probe = false;
+    hipEvent_t ev_blur[2 * PSX_GAUSS_LEVELS] = {};     // [2l], [2l+1]: begin / end of the level-(l+1) kernel
+    int  blur_probe_n = 0;             // levels timed in the last extraction
 };
 
 namespace {
@@ -309,8 +313,8 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), sizeof(PsxCounters)));
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_cnt), sizeof(PsxCounters), hipHostMallocDefault));
     PSX_HIPC(hipMemset(n->d_cnt, 0, sizeof(PsxCounters)));
-    PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_xcnt), 2 * sizeof(int), hipHostMallocDefault));
-    n->h_xcnt[0] = n->h_xcnt[1] = 0;
+    PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_xcnt), 4 * sizeof(int), hipHostMallocDefault));
+    n->h_xcnt[0] = n->h_xcnt[1] = n->h_xcnt[2] = n->h_xcnt[3] = 0;
     for (int i = 0; i < 5; i++) PSX_HIPC(hipEventCreate(&n->ev[i]));
     PSX_HIPC(hipEventCreate(&n->ev_t0));
     PSX_HIPC(hipEventCreate(&n->ev_t1));
@@ -339,6 +343,7 @@ int psx_destroy(psx_ctx* ctx)
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
+    for (int i = 0; i < 2 * PSX_GAUSS_LEVELS; i++) if (ctx->ev_blur[i]) (void)hipEventDestroy(ctx->ev_blur[i]);
     if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
     if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
@@ -373,6 +378,8 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     // kernels address a plane (and the padded resampled input) with 32-bit byte offsets from its base
     if (((size_t)((ow + 63) & ~63) + 2 * PSX_LEVEL0_PAD) * (size_t)oh * sizeof(float) >= ((size_t)1 << 32))
         return fail(ctx, PSX_ERR_INVALID, "psx_resize: octave 0 plane of 4 GiB or more is not supported");
+    // extremum candidates are packed as y << 32 | z << 24 | x
+    if (ow >= (1 << 24)) return fail(ctx, PSX_ERR_INVALID, "psx_resize: octave 0 wider than 2^24 - 1 columns is not supported");
 
     PsxParams& P = ctx->hp;
     memset(&P, 0, sizeof(P));
@@ -411,9 +418,13 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     if ((rc = grow(ctx, &ctx->d_up, &ctx->up_cap, (size_t)ctx->up_pitch * P.oct[0].h)) != PSX_OK) return rc;
     for (int o = 0; o < P.num_octaves; o++) P.oct[o].data = ctx->d_pyr + offs[o];
 
-    // buffers sized so that no counter read-back is needed before they are used
+    // Extrema buffers are sized for the worst case (max_extrema per octave, 100 B per entry); the descriptor
+    // buffers start at the reference's size, max(2 max_extrema, 1.25 max_extrema) entries of 512 B
+    // (sift_pyramid.cu:186-209), never shrink, and grow after the counter read-back when a frame needed more
+    // (regrow_descriptors below; the reference reallocates in Pyramid::reallocExtrema the same way).
     const size_t iext_need = (size_t)P.num_octaves * c.max_extrema;
-    const size_t ori_need = (size_t)imax(2 * (int)iext_need, c.max_extrema + c.max_extrema / 4);
+    const size_t ori_floor = (size_t)imax(2 * c.max_extrema, c.max_extrema + c.max_extrema / 4);
+    const size_t ori_need = ctx->desc_cap / 128 > ori_floor ? ctx->desc_cap / 128 : ori_floor;
     if ((rc = grow(ctx, &ctx->d_iext, &ctx->iext_cap, iext_need)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_iext_off, &ctx->iext_off_cap, iext_need)) != PSX_OK) return rc;
     // candidates before refinement: ~1.3x the survivors on natural images; room for 4x the cap per octave,
@@ -510,7 +521,7 @@ int psx_set_input_dev(psx_ctx* ctx, const void* dev_ptr, int w, int h, int is_fl
     return PSX_OK;
 }
 
-static int launch_blur_level(psx_ctx* ctx, int o, int level)
+static int launch_blur_level(psx_ctx* ctx, int o, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     const PsxParams& P = ctx->hp;
     const PsxOctave& oc = P.oct[o];
@@ -521,7 +532,7 @@ static int launch_blur_level(psx_ctx* ctx, int o, int level)
     }
     PSX_HIP(psx_launch_blur(oc.data + (size_t)(level - 1) * oc.plane, oc.data + (size_t)level * oc.plane,
                             oc.w, oc.h, oc.pitch, taps_from(ctx->inc_filter + level * PSX_GAUSS_ALIGN),
-                            ctx->inc_span[level], half_dst, half_pitch, ctx->stream));
+                            ctx->inc_span[level], half_dst, half_pitch, ctx->stream, ev0, ev1));
     return PSX_OK;
 }
 
@@ -550,11 +561,15 @@ int psx_build_pyramid(psx_ctx* ctx)
     PSX_HIP(psx_launch_level0(a, ctx->stream));
 
     ctx->ext_launched = false;
+    const bool probe = ctx->blur_probe;
     for (int o = 0; o < P.num_octaves; o++) {
         for (int level = 1; level < P.L; level++) {
-            int rc = launch_blur_level(ctx, o, level);
+            const bool pl = probe && o == 0;
+            int rc = launch_blur_level(ctx, o, level, pl ? ctx->ev_blur[2 * (level - 1)] : nullptr,
+                                       pl ? ctx->ev_blur[2 * (level - 1) + 1] : nullptr);
             if (rc != PSX_OK) return rc;
         }
+        if (probe && o == 0) ctx->blur_probe_n = P.L - 1;
         // the six planes of this octave are as cache-resident now as they will ever be
         if (ctx->interleave) PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
     }
@@ -666,7 +681,7 @@ int psx_extract(psx_ctx* ctx)
     if (!ctx->d_input || !ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_extract: no input image");
     // Optionally replay the 36-launch chain as one hipGraph (POPSIFT_HIP_GRAPH=1).  Not with the grid filter
     // (it reads counters on the host in mid-chain) and not with the per-stage timers.
-    const bool use_graph = !ctx->graph_off && !ctx->timers && ctx->cfg.filter_max_extrema <= 0;
+    const bool use_graph = !ctx->graph_off && !ctx->timers && !ctx->blur_probe && ctx->cfg.filter_max_extrema <= 0;
     if (!use_graph) return extract_chain(ctx);
     PSX_HIP(hipSetDevice(ctx->device));
     if (ctx->graph && (ctx->graph_input != ctx->d_input || ctx->graph_is_float != ctx->input_is_float ||
@@ -706,9 +721,12 @@ int psx_sync(psx_ctx* ctx)
     return PSX_OK;
 }
 
+static int fetch_counts(psx_ctx* ctx);
 static int fetch_counts_full(psx_ctx* ctx)
 {
     if (ctx->counts_valid && !ctx->counts_partial) return PSX_OK;
+    { int rc0 = fetch_counts(ctx); if (rc0 != PSX_OK) return rc0; }     // grows the descriptor buffers if needed
+    if (!ctx->counts_partial) return PSX_OK;
     PSX_HIP(hipSetDevice(ctx->device));
     PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
     { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
@@ -717,23 +735,53 @@ static int fetch_counts_full(psx_ctx* ctx)
     return PSX_OK;
 }
 
+// A frame produced more orientations than the descriptor buffers hold (they start at the reference's
+// 2 x max_extrema entries): grow them and redo the two stages that depend on the capacity -- the
+// orientation scan and the descriptors; the oriented extrema are still in place.  Pyramid::reallocExtrema,
+// sift_pyramid.cu:186-209.
+static int regrow_descriptors(psx_ctx* ctx, int ori_raw)
+{
+    PsxParams& P = ctx->hp;
+    const size_t need = (size_t)ori_raw + (size_t)ori_raw / 4 + 1024;
+    int rc;
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = grow(ctx, &ctx->d_desc, &ctx->desc_cap, need * 128)) != PSX_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_feat_to_ext, &ctx->f2e_cap, need)) != PSX_OK) return rc;
+    P.desc = ctx->d_desc;
+    P.feat_to_ext = ctx->d_feat_to_ext;
+    P.ori_capacity = (int)need;
+    *ctx->h_params_pin = P;
+    PSX_HIP(hipMemcpyAsync(ctx->d_params, ctx->h_params_pin, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->graph) { (void)hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
+    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, ctx->stream));
+    PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->hp.x_desc != nullptr, ctx->stream));
+    return PSX_OK;
+}
+
 static int fetch_counts(psx_ctx* ctx)
 {
     if (ctx->counts_valid) return PSX_OK;
     PSX_HIP(hipSetDevice(ctx->device));
-    if (ctx->hp.x_counts != nullptr) {
-        // export attached: the scan kernel already deposited the counters in pinned memory
-        { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
-        ctx->h_cnt->ext_total = ctx->h_xcnt[0];
-        ctx->h_cnt->ori_total = ctx->h_xcnt[1];
-        ctx->counts_valid = true;
-        ctx->counts_partial = true;
-        return PSX_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int raw;
+        if (ctx->hp.x_counts != nullptr) {
+            // export attached: the scan kernel already deposited the counters in pinned memory
+            { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
+            ctx->h_cnt->ext_total = ctx->h_xcnt[0];
+            ctx->h_cnt->ori_total = ctx->h_xcnt[1];
+            raw = ctx->h_xcnt[2];
+            ctx->counts_partial = true;
+        } else {
+            PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
+            { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
+            raw = ctx->h_cnt->ori_raw;
+            ctx->counts_partial = false;
+        }
+        if (raw <= ctx->hp.ori_capacity || attempt == 1) break;
+        int rc = regrow_descriptors(ctx, raw);
+        if (rc != PSX_OK) return rc;
     }
-    PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
-    { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
     ctx->counts_valid = true;
-    ctx->counts_partial = false;
     return PSX_OK;
 }
 
@@ -896,8 +944,8 @@ int psx_clone_results(psx_ctx* ctx, void* d_features, void* d_descriptors, int* 
     if (rc != PSX_OK) return rc;
     const int ne = ctx->h_cnt->ext_total, no = ctx->h_cnt->ori_total;
     if (ne > 0 && d_features)
-        PSX_HIP(hipMemcpyAsync(d_features, ctx->d_features, (size_t)ne * sizeof(psx_feature),
-                               hipMemcpyDeviceToDevice, ctx->stream));
+        PSX_HIP(psx_launch_feature_ptrs(ctx->d_features, static_cast<psx_feature_dev*>(d_features), ne,
+                                        static_cast<float*>(d_descriptors), d_descriptors ? no : 0, ctx->stream));
     if (no > 0 && d_descriptors)
         PSX_HIP(hipMemcpyAsync(d_descriptors, ctx->d_desc, (size_t)no * 128 * sizeof(float),
                                hipMemcpyDeviceToDevice, ctx->stream));
@@ -926,6 +974,15 @@ int psx_device_info(int device, char* name, int name_len, size_t* total_mem, int
     if (total_mem) *total_mem = p.totalGlobalMem;
     if (compute_units) *compute_units = p.multiProcessorCount;
     if (clock_khz) *clock_khz = p.clockRate;
+    return PSX_OK;
+}
+
+int psx_device_pci(int device, char* bus_id, int len)
+{
+    psx_ctx* ctx = nullptr;
+    if (!bus_id || len < 16) return PSX_ERR_INVALID;
+    bus_id[0] = 0;
+    PSX_HIP(hipDeviceGetPCIBusId(bus_id, len, device));
     return PSX_OK;
 }
 
@@ -1039,6 +1096,32 @@ int psx_debug_launch_extrema(psx_ctx* ctx, int o)
     return PSX_OK;
 }
 #endif
+
+
+int psx_enable_blur_probe(psx_ctx* ctx, int on)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    PSX_HIP(hipSetDevice(ctx->device));
+    if (on)
+        for (int i = 0; i < 2 * PSX_GAUSS_LEVELS; i++)
+            if (!ctx->ev_blur[i]) PSX_HIP(hipEventCreate(&ctx->ev_blur[i]));
+    ctx->blur_probe = on != 0;
+    ctx->blur_probe_n = 0;
+    return PSX_OK;
+}
+
+int psx_blur_probe_times(psx_ctx* ctx, float* ms, int capacity, int* n, double* bytes_per_launch)
+{
+    if (!ctx || !ms || !n) return PSX_ERR_INVALID;
+    if (!ctx->blur_probe) return fail(ctx, PSX_ERR_STATE, "the blur probe is not enabled");
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    *n = ctx->blur_probe_n;
+    for (int i = 0; i < ctx->blur_probe_n && i < capacity; i++)
+        PSX_HIP(hipEventElapsedTime(&ms[i], ctx->ev_blur[2 * i], ctx->ev_blur[2 * i + 1]));
+    if (bytes_per_launch) *bytes_per_launch = 8.0 * (double)ctx->hp.oct[0].w * (double)ctx->hp.oct[0].h;
+    return PSX_OK;
+}
 
 void* psx_stream(psx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 

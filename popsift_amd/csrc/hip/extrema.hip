@@ -450,6 +450,16 @@ hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& hp, Ps
     if (NZ < 1) return hipSuccess;
     const size_t smem = sizeof(float) * (size_t)NL * THP * TWP + sizeof(int) * (size_t)NZ * ETH * ETW;
     const dim3 grid(tiles_x * tiles_y), block(NT);
+    // levels >= 7 need more than the 64 KiB of dynamic LDS a kernel gets by default (72..107 KB of the 160 KB per CU)
+    if (smem > 64 * 1024) {
+        hipError_t e = hipSuccess;
+        switch (hp.sift_mode) {
+        case PSX_MODE_VLFEAT: e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extrema<PSX_MODE_VLFEAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); break;
+        case PSX_MODE_OPENCV: e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extrema<PSX_MODE_OPENCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); break;
+        default:              e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extrema<PSX_MODE_POPSIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); break;
+        }
+        if (e != hipSuccess) return e;
+    }
     switch (hp.sift_mode) {
     case PSX_MODE_VLFEAT:
         hipLaunchKernelGGL(k_extrema<PSX_MODE_VLFEAT>, grid, block, smem, s, d_params, d_cnt, octave, tiles_x);

@@ -122,6 +122,35 @@ __global__ void k_match_merge(const Top2* __restrict__ partial, int l_len, int n
 
 } // namespace
 
+// Scratch of one calling thread: a private non-blocking stream (no null-stream launch, so nothing else on
+// the device is synchronised) and buffers that only ever grow.  Freed when the thread exits.
+namespace {
+struct MatchScratch {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[4] = {0, 0, 0, 0};
+    void release()
+    {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        for (int i = 0; i < 4; i++) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr; device = -1;
+    }
+    bool need(int i, size_t bytes)
+    {
+        if (bytes <= cap[i] && buf[i]) return true;
+        (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0;
+        if (hipMalloc(&buf[i], bytes) != hipSuccess) return false;
+        cap[i] = bytes;
+        return true;
+    }
+    ~MatchScratch() { release(); }
+};
+thread_local MatchScratch t_scratch;
+} // namespace
+
 extern "C" int psx_match(int device, const float* d_left, int l_len, const float* d_right, int r_len,
                          int* host_match, float* host_dist)
 {
@@ -129,6 +158,12 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         return PSX_ERR_INVALID;
     if (l_len == 0) return PSX_OK;
     if (hipSetDevice(device) != hipSuccess) return PSX_ERR_HIP;
+    MatchScratch& sc = t_scratch;
+    if (sc.device != device) {
+        sc.release();
+        if (hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking) != hipSuccess) return PSX_ERR_HIP;
+        sc.device = device;
+    }
     // enough (left group, chunk) waves to fill the chip: 256 CUs x 4 SIMDs x 2 waves
     const int lgroups = (l_len + 63) / 64;
     int nchunks = (2048 + lgroups - 1) / lgroups;
@@ -137,25 +172,25 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
     const int chunk_len = r_len > 0 ? (r_len + nchunks - 1) / nchunks : 1;
     if (r_len > 0) nchunks = (r_len + chunk_len - 1) / chunk_len;
 
-    Top2* d_partial = nullptr; int* d_out = nullptr; float* d_dist = nullptr; float* d_rperm = nullptr;
-    int rc = PSX_OK;
-    if (hipMalloc(reinterpret_cast<void**>(&d_partial), sizeof(Top2) * (size_t)nchunks * l_len) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_rperm), sizeof(float) * 128 * (size_t)(r_len > 0 ? r_len : 1)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(int) * 3 * (size_t)l_len) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_dist), sizeof(float) * 2 * (size_t)l_len) != hipSuccess) {
-        rc = PSX_ERR_NOMEM;
-    } else {
-        if (r_len > 0)
-            hipLaunchKernelGGL(k_match_permute, dim3((r_len * 64 + 255) / 256), dim3(256), 0, 0, d_right, r_len, d_rperm);
-        hipLaunchKernelGGL(k_match_partial, dim3(lgroups, nchunks), dim3(64), 0, 0, d_left, l_len, d_rperm, r_len,
-                           chunk_len, d_partial);
-        hipLaunchKernelGGL(k_match_merge, dim3((l_len + 255) / 256), dim3(256), 0, 0, d_partial, l_len, nchunks,
-                           r_len, d_out, d_dist);
-        if (hipGetLastError() != hipSuccess ||
-            hipMemcpy(host_match, d_out, sizeof(int) * 3 * (size_t)l_len, hipMemcpyDeviceToHost) != hipSuccess ||
-            (host_dist && hipMemcpy(host_dist, d_dist, sizeof(float) * 2 * (size_t)l_len, hipMemcpyDeviceToHost) != hipSuccess))
-            rc = PSX_ERR_HIP;
-    }
-    (void)hipFree(d_partial); (void)hipFree(d_out); (void)hipFree(d_dist); (void)hipFree(d_rperm);
-    return rc;
+    if (!sc.need(0, sizeof(Top2) * (size_t)nchunks * l_len) ||
+        !sc.need(1, sizeof(float) * 128 * (size_t)(r_len > 0 ? r_len : 1)) ||
+        !sc.need(2, sizeof(int) * 3 * (size_t)l_len) || !sc.need(3, sizeof(float) * 2 * (size_t)l_len))
+        return PSX_ERR_NOMEM;
+    Top2* d_partial = static_cast<Top2*>(sc.buf[0]);
+    float* d_rperm = static_cast<float*>(sc.buf[1]);
+    int* d_out = static_cast<int*>(sc.buf[2]);
+    float* d_dist = static_cast<float*>(sc.buf[3]);
+    hipStream_t st = sc.stream;
+    if (r_len > 0)
+        hipLaunchKernelGGL(k_match_permute, dim3((r_len * 64 + 255) / 256), dim3(256), 0, st, d_right, r_len, d_rperm);
+    hipLaunchKernelGGL(k_match_partial, dim3(lgroups, nchunks), dim3(64), 0, st, d_left, l_len, d_rperm, r_len,
+                       chunk_len, d_partial);
+    hipLaunchKernelGGL(k_match_merge, dim3((l_len + 255) / 256), dim3(256), 0, st, d_partial, l_len, nchunks,
+                       r_len, d_out, d_dist);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(host_match, d_out, sizeof(int) * 3 * (size_t)l_len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (host_dist && hipMemcpyAsync(host_dist, d_dist, sizeof(float) * 2 * (size_t)l_len, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return PSX_ERR_HIP;
+    return PSX_OK;
 }

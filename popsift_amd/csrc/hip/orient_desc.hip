@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_NT = 1024;
 
-__device__ __forceinline__ void write_feature(const PsxParams* P, int i, const psx_extremum& ex, int excl)
+__device__ __forceinline__ void write_feature(const PsxParams* P, int i, const psx_extremum& ex, int excl, int limit)
 {
     // prep_features, sift_pyramid.cu:250-280 (descriptor pointers become indices, -1 == nullptr)
     psx_feature f;
@@ -284,7 +284,7 @@ __device__ __forceinline__ void write_feature(const PsxParams* P, int i, const p
     for (int k = 0; k < PSX_ORI_MAX; k++) {
         const bool on = k < ex.num_ori;
         f.orientation[k] = on ? ex.orientation[k] : 0.0f;
-        f.desc_idx[k] = (on && excl + k < P->ori_capacity) ? excl + k : -1;
+        f.desc_idx[k] = (on && excl + k < limit) ? excl + k : -1;
     }
     P->features[i] = f;
     if (P->x_features != nullptr && i < P->x_feat_capacity) P->x_features[i] = f;
@@ -315,7 +315,14 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
     }
     __syncthreads();
     const int total = s_total;
-    const int cap = P->ori_capacity;
+    // Descriptor capacity the reference would have for this frame: max(2 max_extrema, 1.25 max_extrema)
+    // (sift_pyramid.cu:154-159), grown to 2 x the extrema count rounded up to 1024 when there are more than
+    // max_extrema extrema (Pyramid::reallocExtrema, sift_pyramid.cu:179-209).  Orientations beyond it are
+    // dropped (the reference would write past its buffer).  The buffers of this context may be smaller: then
+    // the host grows them to `rule` and reruns this kernel (api.hip regrow_descriptors).
+    int rule = max(2 * P->max_extrema, P->max_extrema + P->max_extrema / 4);
+    if (total > P->max_extrema) rule = max(rule, 2 * ((total + 1024) & ~1023));
+    const int cap = min(P->ori_capacity, rule);
     const int* nori = P->ext_nori;
     // every thread owns SCAN_K consecutive extrema per pass; all 4 int4 loads are in flight at once
     constexpr int SCAN_K = 16;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
                 if (excl >= cap) {                 // no descriptor wave will visit this extremum
                     psx_extremum ex = P->extrema[i];
                     ex.idx_ori = excl;
-                    write_feature(P, i, ex, excl);
+                    write_feature(P, i, ex, excl, cap);
                 }
                 excl += n;
             }
@@ -378,7 +385,8 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
         if (lane == 0) {
             cnt->ext_total = total;
             cnt->ori_total = ori_total;
-            if (P->x_counts != nullptr) { P->x_counts[0] = total; P->x_counts[1] = ori_total; }
+            cnt->ori_raw = min(grand, rule);   // what the frame needs: the host grows the descriptor buffers up to it
+            if (P->x_counts != nullptr) { P->x_counts[0] = total; P->x_counts[1] = ori_total; P->x_counts[2] = min(grand, rule); }
         }
         // per-octave orientation counts (dct.ori_ct / ori_ps, s_orientation.cu:340-360), lane o = octave o
         int ps = ori_total;
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
         const PsxOctave oc = P->oct[ex.octave];
         const int width = oc.w, height = oc.h;
 
-        if (ori_num == 0 && lane == 0) write_feature(P, ext_idx, ex, ex.idx_ori);
+        if (ori_num == 0 && lane == 0) write_feature(P, ext_idx, ex, ex.idx_ori, total);
 
         for (int i = lane; i < DCOPIES * DSTRIDE; i += PSX_WAVE) acc[i] = 0u;
         wave_fence();

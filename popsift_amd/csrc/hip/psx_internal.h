@@ -61,7 +61,7 @@ struct PsxParams {
     // zero-copy export into mapped host memory (nullptr when detached)
     psx_feature*  x_features;
     float*        x_desc;
-    int*          x_counts;              // [0]=ext_total [1]=ori_total, pinned host memory
+    int*          x_counts;              // [0]=ext_total [1]=ori_total [2]=ori_raw, pinned host memory
     int           x_feat_capacity;
     int           x_desc_capacity;
 };
@@ -74,7 +74,8 @@ struct PsxCounters {
     int ori_ps[PSX_MAX_OCTAVES + 1];
     int ext_total;
     int ori_total;
-    int pad[2];
+    int ori_raw;                   // orientations before the clamp to ori_capacity
+    int pad;
     int iext_ct[PSX_MAX_OCTAVES];  // initial extrema per octave before the grid filter (set by k_gf_apply)
 };
 
@@ -95,9 +96,8 @@ struct PsxLevel0Args {
 hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s);
 hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch,
                            const PsxTaps& taps, int span,
-                           float* half_dst, int half_pitch, hipStream_t s);
-hipError_t psx_launch_downscale(const float* src, int sw, int sh, int spitch,
-                                float* dst, int W, int H, int pitch, hipStream_t s);
+                           float* half_dst, int half_pitch, hipStream_t s,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s);
 hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt,
                               int octave, hipStream_t s);
@@ -111,6 +111,8 @@ hipError_t psx_launch_gridfilter(const PsxParams* d_params, PsxCounters* d_cnt, 
                                  int* scratch, hipStream_t s);
 hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
 hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
+hipError_t psx_launch_feature_ptrs(const psx_feature* in, psx_feature_dev* out, int n, float* desc_base, int num_desc,
+                                   hipStream_t s);
 hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, bool exporting, hipStream_t s);
 
 // ---- small device helpers --------------------------------------------------------------------

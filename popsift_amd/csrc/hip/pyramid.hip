@@ -5,7 +5,6 @@
 //   normalizedSource::horiz + absoluteSource::vert (level 0 of octave 0)   -> k_upscale + k_blur<R,true>
 //   absoluteSource::horiz + absoluteSource::vert   (levels 1..L-1)         -> k_blur
 //   get_by_2_pick_every_second                                             -> fused into k_blur
-//                                                                             (k_downscale standalone)
 //   make_dog                                                               -> not materialised;
 //       the extrema kernel forms G[l+1]-G[l] on the fly (bit-identical single subtraction).
 //
@@ -24,6 +23,9 @@
 //   level 0 H (s_pyramid_build_ra.cu:17-55): pairs outermost-in, then centre, then *255
 #include "psx_internal.h"
 
+#include <hip/hip_ext.h>
+
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -130,7 +132,7 @@ __device__ __forceinline__ void vfilter2x4_km(const v2f* v, const PsxTaps& tp, v
     for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i], tp.g[0], o[i]);
 }
 
-template <int R, bool LEVEL0>
+template <int R, bool LEVEL0, bool DEFER = true>
 __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur(BlurArgs a)
 {
     using G = Geom2<R>;
@@ -218,9 +220,37 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
                 if (j < NLD - 1 || last_on) *reinterpret_cast<v4f*>(&s_stage[st_lds[j]]) = pre[j];
         };
 
+        // Results of the vertical pass are not stored at once: on gfx950 loads and stores share one counter
+        // (vmcnt), so "wait for the prefetched rows" at the top of the next step would also wait for stores
+        // issued a moment ago -- an exposed HBM write latency per step.  The four row pairs of step k stay in
+        // registers and are stored at the top of step k+1, behind the commit; by the next wait they are a
+        // whole step old.
+        v2f pend[4];
+        int pend_k = -1;                                   // step whose results are pending (thread uniform per wave group)
+        auto flush = [&]() {
+            if (pend_k < 0) return;
+            const int rel0 = pend_k * BR - 2 * R + v_rg * 4;
+            const int r_out0 = Y0 + rel0;
+            // uniform row base of the step; thread offsets are step invariant
+            char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + pend_k * BR) * a.pitch);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r_out = r_out0 + i;
+                if (r_out >= Y0 && r_out < Y1 && v_xok) {
+                    char* di = drow + (size_t)i * a.pitch * 4 + v_doff;
+                    if (v_pair) *reinterpret_cast<v2f*>(di) = pend[i]; else *reinterpret_cast<float*>(di) = pend[i].x;
+                    // get_by_2_pick_every_second: rows and columns 0,2,4,.. (v_x is even)
+                    if (a.half_dst != nullptr && (r_out & 1) == 0)
+                        a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
+                }
+            }
+            pend_k = -1;
+        };
+
         issue(0);
         for (int k = 0; k < nsteps; k++) {
             commit();
+            flush();
             BSTAMP(0);
             __syncthreads();
             BSTAMP(1);
@@ -266,23 +296,21 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
                     // pin the four results here: otherwise each chain is sunk into its own predicated
                     // store block and runs alone, dependent v_pk_fma_f32 back to back
                     asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-                    // uniform row base of this step; thread offsets are step invariant
-                    char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + k * BR) * a.pitch);
+                    if (DEFER) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int r_out = r_out0 + i;
-                        if (r_out >= Y0 && r_out < Y1 && v_xok) {
-                            char* di = drow + (size_t)i * a.pitch * 4 + v_doff;
-                            if (v_pair) *reinterpret_cast<v2f*>(di) = o[i]; else *reinterpret_cast<float*>(di) = o[i].x;
-                            // get_by_2_pick_every_second: rows and columns 0,2,4,.. (v_x is even)
-                            if (a.half_dst != nullptr && (r_out & 1) == 0)
-                                a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = o[i].x;
-                        }
+                        for (int i = 0; i < 4; i++) pend[i] = o[i];
+                        pend_k = k;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) pend[i] = o[i];
+                        pend_k = k;
+                        flush();
                     }
                 }
             }
             BSTAMP(4);
         }
+        flush();
     };
     if (interior) run(std::true_type{}); else run(std::false_type{});
 #ifdef PSX_PHASE_TIMING
@@ -410,17 +438,6 @@ __global__ __launch_bounds__(256) void k_upscale(UpArgs a)
     }
 }
 
-// get_by_2_pick_every_second (s_pyramid_build.cu:50-71), used only when the fused path is off
-__global__ void k_downscale(const float* src, int sw, int sh, int spitch, float* dst, int W, int H, int pitch)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W || y >= H) return;
-    const int rx = min(x << 1, sw - 1);
-    const int ry = min(y << 1, sh - 1);
-    dst[(size_t)y * pitch + x] = src[(size_t)ry * spitch + rx];
-}
-
 // make_dog (s_pyramid_build.cu:74-92) for one level pair; debug/dump use only
 __global__ void k_dog(const float* a, const float* b, float* d, int W, int H, int pitch)
 {
@@ -431,13 +448,27 @@ __global__ void k_dog(const float* a, const float* b, float* d, int W, int H, in
     d[i] = b[i] - a[i];
 }
 
+// Tuning switches for A/B measurements on the GPU (read once): POPSIFT_BLUR_STEPS = marching steps per chunk
+// on large planes (default 5), POPSIFT_BLUR_DEFER=0 stores the vertical results at once (the round-1 kernel).
+struct BlurTuning { int steps; bool defer; };
+inline const BlurTuning& blur_tuning()
+{
+    static const BlurTuning t = [] {
+        BlurTuning v{5, true};
+        if (const char* e = getenv("POPSIFT_BLUR_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.steps = n; }
+        if (const char* e = getenv("POPSIFT_BLUR_DEFER")) v.defer = e[0] != '0';
+        return v;
+    }();
+    return t;
+}
+
 inline void chunking(int W, int H, int R, int& chunk_rows, int& nchunks)
 {
     // S marching steps per chunk: the 2R warm-up rows cost ~2R/(S*BR) extra horizontal work, but a
     // chunk is a serial chain of S steps.  Large planes take S=5; small octaves trade efficiency
     // for more, shorter workgroups (they are latency bound, not bandwidth bound).
     const int nstrips = (W + TW - 1) / TW;
-    int S = 5;
+    int S = blur_tuning().steps;
     for (; S > 2; S--) {
         const int cr = S * BR - 2 * R;
         if (cr >= BR && nstrips * ((H + cr - 1) / cr) >= 384) break;
@@ -451,7 +482,7 @@ inline void chunking(int W, int H, int R, int& chunk_rows, int& nchunks)
 
 template <int R>
 hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, const PsxTaps& taps,
-                         float* half_dst, int half_pitch, hipStream_t s)
+                         float* half_dst, int half_pitch, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     BlurArgs a;
     a.src = src; a.dst = dst; a.half_dst = half_dst;
@@ -461,7 +492,16 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
     int nchunks;
     chunking(W, H, R, a.chunk_rows, nchunks);
     a.taps = taps; a.taps_v = taps;
-    hipLaunchKernelGGL((k_blur<R, false>), dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
+    const dim3 grid(a.nstrips * nchunks), block(NT);
+    if (ev0 != nullptr || ev1 != nullptr) {
+        // kernel begin / end timestamps of THIS dispatch (what rocprofv3 --kernel-trace reports)
+        if (blur_tuning().defer) hipExtLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, ev0, ev1, 0, a);
+        else                     hipExtLaunchKernelGGL((k_blur<R, false, false>), grid, block, 0, s, ev0, ev1, 0, a);
+    } else if (blur_tuning().defer) {
+        hipLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((k_blur<R, false, false>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -496,17 +536,17 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
 // Kernels are instantiated for a set of radii; a smaller radius runs on the next larger
 // instantiation with zero weights, which is bit-exact (fma(x, 0, acc) == acc).
 hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch, const PsxTaps& taps,
-                           int span, float* half_dst, int half_pitch, hipStream_t s)
+                           int span, float* half_dst, int half_pitch, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     const int R = span - 1;
-    if (R <= 5)  return launch_blur_r<5>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
-    if (R <= 7)  return launch_blur_r<7>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
-    if (R <= 8)  return launch_blur_r<8>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
-    if (R <= 10) return launch_blur_r<10>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
-    if (R <= 13) return launch_blur_r<13>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
-    if (R <= 16) return launch_blur_r<16>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
-    if (R <= 22) return launch_blur_r<22>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
-    if (R <= 30) return launch_blur_r<30>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s);
+    if (R <= 5)  return launch_blur_r<5>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
+    if (R <= 7)  return launch_blur_r<7>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
+    if (R <= 8)  return launch_blur_r<8>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
+    if (R <= 10) return launch_blur_r<10>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
+    if (R <= 13) return launch_blur_r<13>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
+    if (R <= 16) return launch_blur_r<16>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
+    if (R <= 22) return launch_blur_r<22>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
+    if (R <= 30) return launch_blur_r<30>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
     return hipErrorInvalidValue;
 }
 
@@ -518,13 +558,6 @@ hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s)
     if (R <= 16) return launch_level0_r<16>(a, s);
     if (R <= 30) return launch_level0_r<30>(a, s);
     return hipErrorInvalidValue;
-}
-
-hipError_t psx_launch_downscale(const float* src, int sw, int sh, int spitch,
-                                float* dst, int W, int H, int pitch, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_downscale, dim3((W + 255) / 256, H), dim3(256), 0, s, src, sw, sh, spitch, dst, W, H, pitch);
-    return hipGetLastError();
 }
 
 hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s)

@@ -4,8 +4,10 @@
 // usage: popsift_demo <w> <h> <raw-u8-or-f32-file> <out.txt> [--float] [--vlfeat|--opencv]
 //                     [--octaves N] [--repeat N] [--norm-multi M] [--classic] [--match <second-raw-file>]
 //                     [--filter-max N] grid filter as AliceVision configures it (LargestScaleFirst)
-//                     [--bench N]   stream N frames through enqueue/get with at most 16 jobs outstanding and
-//                                   print the sustained rate (host images in, FeaturesHost out)
+//                     [--bench N]   stream N frames through enqueue/get with at most 16 jobs outstanding per
+//                                   device and print the sustained rate (host images in, FeaturesHost out)
+//                     [--devices D] with --bench: D PopSift replicas in this process, one per GPU
+//                                   (popsift.h:158,166-168); frame i goes to replica i mod D (BASELINE config 4)
 // writes: one line per descriptor:  x y sigma orientation d0..d127  (full float precision)
 // --match: MatchingMode as in the reference's popsift-match (src/application/match.cpp:257-275): both images
 //          are extracted into FeaturesDev objects and lFeatures->match(rFeatures) prints one line per descriptor
@@ -19,7 +21,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <algorithm>
 #include <iostream>
+#include <memory>
 #include <queue>
 #include <vector>
 
@@ -31,6 +35,7 @@ int main( int argc, char** argv )
     int repeat = 1;
     const char* match_file = nullptr;
     int bench = 0;
+    int devices = 1;
     popsift::Config config;
     for( int i = 5; i < argc; i++ ) {
         if( !strcmp( argv[i], "--float" ) ) is_float = true;
@@ -42,6 +47,7 @@ int main( int argc, char** argv )
         else if( !strcmp( argv[i], "--repeat" ) && i + 1 < argc ) repeat = atoi( argv[++i] );
         else if( !strcmp( argv[i], "--match" ) && i + 1 < argc ) match_file = argv[++i];
         else if( !strcmp( argv[i], "--bench" ) && i + 1 < argc ) bench = atoi( argv[++i] );
+        else if( !strcmp( argv[i], "--devices" ) && i + 1 < argc ) devices = std::max( 1, atoi( argv[++i] ) );
         else if( !strcmp( argv[i], "--filter-max" ) && i + 1 < argc ) {     // AliceVision: setFilterMaxExtrema + LargestScaleFirst
             config.setFilterMaxExtrema( atoi( argv[++i] ) );
             config.setFilterSorting( popsift::Config::LargestScaleFirst );
@@ -78,29 +84,43 @@ int main( int argc, char** argv )
     }
 
     if( bench > 0 ) {
-        PopSift bsift( config, popsift::Config::ExtractingMode, is_float ? PopSift::FloatImages : PopSift::ByteImages );
-        std::queue<SiftJob*> q;
+        // N replicas, one PopSift per device, results gathered by pointer hand-off only (no device-to-device traffic)
+        std::vector<std::unique_ptr<PopSift>> sifts;
+        for( int d = 0; d < devices; d++ )
+            sifts.emplace_back( new PopSift( config, popsift::Config::ExtractingMode,
+                                             is_float ? PopSift::FloatImages : PopSift::ByteImages, d ) );
+        std::vector<std::queue<SiftJob*>> q( devices );
+        std::vector<size_t> frames_of( devices, 0 );
         size_t kp = 0;
-        auto drain_one = [&]() {
-            SiftJob* j = q.front(); q.pop();
+        auto drain_one = [&]( int d ) {
+            SiftJob* j = q[d].front(); q[d].pop();
             popsift::Features* fl = j->get();
             if( fl ) { kp += fl->getFeatureCount(); delete fl; }
             delete j;
         };
-        auto submit = [&]() {
-            SiftJob* j = is_float ? bsift.enqueue( w, h, (const float*)raw.data() ) : bsift.enqueue( w, h, raw.data() );
-            if( j ) q.push( j );
+        auto submit = [&]( int i ) {
+            const int d = i % devices;                       // frame i -> GPU i mod N
+            SiftJob* j = is_float ? sifts[d]->enqueue( w, h, (const float*)raw.data() ) : sifts[d]->enqueue( w, h, raw.data() );
+            if( j ) { q[d].push( j ); frames_of[d]++; }
+            if( q[d].size() > 16 ) drain_one( d );
         };
-        for( int i = 0; i < 32; i++ ) { submit(); if( q.size() > 16 ) drain_one(); }       // warm-up
-        while( !q.empty() ) drain_one();
+        auto drain_all = [&]() { for( int d = 0; d < devices; d++ ) while( !q[d].empty() ) drain_one( d ); };
+        for( int i = 0; i < 32 * devices; i++ ) submit( i );          // warm-up
+        drain_all();
         kp = 0;
+        std::fill( frames_of.begin(), frames_of.end(), 0 );
         const auto t0 = std::chrono::steady_clock::now();
-        for( int i = 0; i < bench; i++ ) { submit(); if( q.size() > 16 ) drain_one(); }
-        while( !q.empty() ) drain_one();
+        for( int i = 0; i < bench; i++ ) submit( i );
+        drain_all();
         const double dt = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
         printf( "bench: %d frames %dx%d in %.3f s: %.3f ms/frame, %.0f Mpix/s, %.0f keypoints/frame\n", bench, w, h, dt,
                 dt / bench * 1e3, (double)w * h * bench / dt / 1e6, (double)kp / bench );
-        bsift.uninit();
+        if( devices > 1 ) {
+            printf( "devices: %d, frames per device:", devices );
+            for( int d = 0; d < devices; d++ ) printf( " %zu", frames_of[d] );
+            printf( "\n" );
+        }
+        for( auto& s : sifts ) s->uninit();
         return 0;
     }
 

@@ -6,6 +6,7 @@
 #include "popsift/sift_extremum.h"
 
 #include "popsift_hip.h"
+#include <cstddef>
 
 #include <algorithm>
 #include <cerrno>
@@ -185,6 +186,11 @@ std::ostream& operator<<( std::ostream& ostr, const Feature& feature )
     return ostr;
 }
 
+// FeaturesDev hands out device arrays of popsift::Feature; the C-ABI fills them as psx_feature_dev
+static_assert( sizeof(Feature) == sizeof(psx_feature_dev), "popsift::Feature and psx_feature_dev must have the same layout" );
+static_assert( offsetof(Feature, desc) == offsetof(psx_feature_dev, desc), "popsift::Feature::desc offset" );
+static_assert( offsetof(Feature, orientation) == offsetof(psx_feature_dev, orientation), "popsift::Feature::orientation offset" );
+
 FeaturesDev::FeaturesDev( ) : _ext( nullptr ), _ori( nullptr ), _rev( nullptr ), _device( 0 ) { }
 
 FeaturesDev::FeaturesDev( int num_ext, int num_ori ) : _ext( nullptr ), _ori( nullptr ), _rev( nullptr ), _device( 0 )
@@ -205,7 +211,7 @@ void FeaturesDev::reset( int num_ext, int num_ori )
     psx_dev_free( _device, _ori ); _ori = nullptr;
     psx_dev_free( _device, _rev ); _rev = nullptr;
     void *e = nullptr, *o = nullptr, *r = nullptr;
-    if( psx_dev_alloc( _device, (size_t)num_ext * sizeof(psx_feature), &e ) != PSX_OK ||
+    if( psx_dev_alloc( _device, (size_t)num_ext * sizeof(Feature), &e ) != PSX_OK ||
         psx_dev_alloc( _device, (size_t)num_ori * sizeof(Descriptor), &o ) != PSX_OK ||
         psx_dev_alloc( _device, (size_t)num_ori * sizeof(int), &r ) != PSX_OK )
         fatal( __FILE__, __LINE__, "Runtime error:\n    Failed to allocate device memory for features" );

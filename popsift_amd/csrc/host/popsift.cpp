@@ -1,9 +1,11 @@
 // popsift.cpp -- PopSift / SiftJob on top of the C-ABI (include/popsift_hip.h).
 //
 // Reference behaviour restated: popsift.cpp:25-503.  Differences in mechanism (not in contract):
-//   * one dispatcher thread drives PIPE_DEPTH extraction contexts (each = pyramid + HIP stream);
-//     a job is uploaded and its whole kernel chain queued without any host synchronisation, the
-//     dispatcher only blocks on the OLDEST frame in flight, so several frames overlap on the GPU;
+//   * POPSIFT_PIPE_DEPTH (default 8) worker threads, one extraction context (pyramid + HIP stream)
+//     each: a worker uploads its job, queues the whole kernel chain without any host synchronisation
+//     and sleeps on a blocking event until that frame is done, so several frames overlap on the GPU;
+//   * the automatic octave count (Config::octaves < 0) is resolved ONCE per PopSift from the first image
+//     enqueued, as the reference does (popsift.cpp:118-122), and handed to every context explicitly;
 //   * results arrive by zero-copy export (psx_attach_export): no per-image pin/unpin
 //     (features.cu:86-111), no D2H copy commands;
 //   * every failure is caught, stored in the job and re-thrown from get(); a job is always
@@ -27,6 +29,9 @@
 #include <iostream>
 #include <sstream>
 #include <unistd.h>
+#include <sched.h>
+#include <cctype>
+#include <cstdio>
 
 using namespace std;
 
@@ -144,6 +149,7 @@ struct PopSift::Impl
     std::atomic<int>             want_desc{ 32768 };     // descriptor capacity of the next export buffer
     std::mutex                   cfg_mutex;
     std::atomic<bool>            contexts_exist{ false };
+    int                          octaves_resolved = -1;  // sticky automatic octave count (popsift.cpp:118-122); cfg_mutex
     // POPSIFT_PROFILE=1: seconds spent per phase (all workers), printed by uninit()
     std::mutex                   prof_mutex;
     double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0;
@@ -185,7 +191,18 @@ bool PopSift::configure( const popsift::Config& config, bool /*force*/ )
     if( _impl->contexts_exist ) return false;          // popsift.cpp:81-83
     _config = config;
     _config.levels = std::max( 2, config.levels );     // popsift.cpp:86
+    _impl->octaves_resolved = -1;
     return true;
+}
+
+// PopSift::private_apply_scale_factor (popsift.cpp:109-126): with Config::octaves < 0 the octave count is
+// derived from the FIRST image this PopSift sees and then stays (the reference writes it into _config).
+void PopSift::resolveOctaves( int w, int h )
+{
+    std::lock_guard<std::mutex> g( _impl->cfg_mutex );
+    if( _config.octaves >= 0 || _impl->octaves_resolved >= 0 ) return;
+    const float scaleFactor = 1.0f / powf( 2.0f, -_config.getUpscaleFactor() );
+    _impl->octaves_resolved = std::max( int( floor( logf( (float)std::min( w, h ) ) / logf( 2.0f ) ) - 3.0f + scaleFactor ), 1 );
 }
 
 void PopSift::uninit( )
@@ -258,6 +275,7 @@ SiftJob* PopSift::enqueue( int w, int h, const unsigned char* imageData )
         cerr << __FILE__ << ":" << __LINE__ << " Image too large" << endl << testTextureFitErrorString( a, w, h );
         return nullptr;
     }
+    resolveOctaves( w, h );
     SiftJob* job = new SiftJob( w, h, imageData );
     _impl->queue.push( job );
     return job;
@@ -273,6 +291,7 @@ SiftJob* PopSift::enqueue( int w, int h, const float* imageData )
         cerr << __FILE__ << ":" << __LINE__ << " Image too large" << endl << testTextureFitErrorString( a, w, h );
         return nullptr;
     }
+    resolveOctaves( w, h );
     SiftJob* job = new SiftJob( w, h, imageData );
     _impl->queue.push( job );
     return job;
@@ -366,10 +385,45 @@ popsift::FeaturesDev* collect_dev( Slot& s, int device )
 
 } // namespace
 
+namespace {
+// Best effort: run this worker on the CPUs local to the GPU's PCIe root (the upload staging copy and the
+// result hand-off then stay on the GPU's NUMA node; it matters with 8 GPUs x 8 workers on a two-socket host).
+// POPSIFT_NUMA_PIN=0 disables it.  Linux sysfs only; any failure leaves the affinity untouched.
+void pin_to_device_numa_node( int device )
+{
+    const char* e = getenv( "POPSIFT_NUMA_PIN" );
+    if( e != nullptr && e[0] == '0' ) return;
+    char bus[64];
+    if( psx_device_pci( device, bus, sizeof(bus) ) != PSX_OK || bus[0] == 0 ) return;
+    for( char* c = bus; *c; c++ ) *c = (char)tolower( *c );
+    const std::string path = std::string( "/sys/bus/pci/devices/" ) + bus + "/local_cpulist";
+    FILE* f = fopen( path.c_str(), "r" );
+    if( f == nullptr ) return;
+    char line[4096] = { 0 };
+    const bool got = fgets( line, sizeof(line), f ) != nullptr;
+    fclose( f );
+    if( !got ) return;
+    cpu_set_t allowed, want;
+    if( sched_getaffinity( 0, sizeof(allowed), &allowed ) != 0 ) return;
+    CPU_ZERO( &want );
+    int n = 0;
+    for( char* tok = strtok( line, ",\n" ); tok != nullptr; tok = strtok( nullptr, ",\n" ) ) {
+        int a = 0, b = 0;
+        const int k = sscanf( tok, "%d-%d", &a, &b );
+        if( k < 1 ) continue;
+        if( k == 1 ) b = a;
+        for( int c = a; c <= b && c < CPU_SETSIZE; c++ )
+            if( CPU_ISSET( c, &allowed ) ) { CPU_SET( c, &want ); n++; }
+    }
+    if( n > 0 ) sched_setaffinity( 0, sizeof(want), &want );
+}
+} // namespace
+
 void PopSift::dispatchLoop( )
 {
     Impl& p = *_impl;
     Slot s;
+    pin_to_device_numa_node( _device );
     double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0; int n_done = 0;
 
     for( ;; ) {
@@ -384,6 +438,7 @@ void PopSift::dispatchLoop( )
                     std::lock_guard<std::mutex> g( p.cfg_mutex );   // configure() is refused from now on (popsift.cpp:81-83)
                     p.contexts_exist = true;
                     to_psx( _config, pc );
+                    if( pc.octaves < 0 && p.octaves_resolved >= 0 ) pc.octaves = p.octaves_resolved;
                 }
                 if( psx_create( _device, &pc, &s.ctx ) != PSX_OK ) {
                     const char* m = psx_last_error( nullptr );

@@ -5,9 +5,10 @@
 // a single-shot future and returns a heap FeaturesHost* the caller deletes.
 //
 // Implementation differs (MI355X-first): no HIP/CUDA type appears in this header; a PopSift
-// owns PSX_PIPE_DEPTH extraction contexts of the C-ABI (include/popsift_hip.h), each with its
-// own pyramid and HIP stream, and ONE dispatcher thread that keeps them all in flight and
-// fulfils the jobs in FIFO order.  The reference runs 2 threads over 3 queues with one pyramid
+// owns POPSIFT_PIPE_DEPTH (default 8) worker threads, each with its own extraction context of the
+// C-ABI (include/popsift_hip.h: pyramid + HIP stream).  A worker takes the next job from the queue,
+// uploads, queues the whole kernel chain, sleeps until its frame is done and fulfils the job, so
+// several frames overlap on the GPU.  The reference runs 2 threads over 3 queues with one pyramid
 // and synchronises the whole device four times per image (popsift.cpp:293-344).
 #pragma once
 
@@ -123,6 +124,7 @@ private:
     struct Impl;
     void start();
     void dispatchLoop();
+    void resolveOctaves( int w, int h );
 
     std::unique_ptr<Impl> _impl;
     popsift::Config _config;

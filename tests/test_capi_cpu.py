@@ -22,6 +22,19 @@ def test_library_exports_every_declared_symbol(capi):
     assert set(capi.SYMBOLS) == declared
 
 
+def test_host_library_exports_the_c_binding(capi):
+    """include/popsift_c.h (flat C binding of PopSift / SiftJob / FeaturesHost) vs libpopsift.so."""
+    hdr = open(os.path.join(ROOT, "include", "popsift_c.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(popsift_c_[a-z0-9_]+)\s*\(", code))
+    assert len(declared) >= 10
+    H = capi.host_lib()
+    assert not [s for s in sorted(declared) if not hasattr(H, s)]
+    assert set(capi.HOST_SYMBOLS) == declared
+    for forbidden in ("hipStream_t", "#include <hip", "torch", "std::"):
+        assert forbidden not in code
+
+
 def test_header_cites_reference_and_has_no_device_types():
     hdr = open(os.path.join(ROOT, "include", "popsift_hip.h")).read()
     code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)      # strip comments
@@ -88,19 +101,16 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
 
 
-def test_shard_range_partitions_every_frame():
-    from popsift_amd.dispatch import shard_range, round_robin
-    for n in (0, 1, 7, 64, 65):
-        for world in (1, 2, 4, 8):
-            seen = []
-            for r in range(world):
-                b, e = shard_range(n, world, r)
-                assert 0 <= b <= e <= n
-                seen += list(range(b, e))
-            assert seen == list(range(n))
-            sizes = [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
-            assert max(sizes) - min(sizes) <= 1
-    assert round_robin(5, 2) == [0, 1, 0, 1, 0]
+def test_bench_frame_rule_is_round_robin_over_gpus():
+    """bench.py's dispatch rule (BASELINE config 4): global frame i goes to GPU i mod N; every rank gets BATCH
+    distinct base frames and the union over ranks is 8N distinct frames."""
+    import bench
+    for world in (1, 2, 4, 8):
+        seeds = [[bench.frame_seed(j, r, world) for j in range(bench.BATCH)] for r in range(world)]
+        flat = sorted(s for row in seeds for s in row)
+        assert flat == list(range(1000, 1000 + bench.BATCH * world))
+        for r, row in enumerate(seeds):
+            assert all((s - 1000) % world == r for s in row)
 
 
 def _host_lib():

@@ -1,0 +1,113 @@
+"""GPU tests of the API surface added in round 2: measurement entry points, FeaturesDev feature records,
+descriptor-buffer growth, the flat C binding of PopSift / SiftJob (include/popsift_c.h) and the per-PopSift
+automatic octave count."""
+import numpy as np
+import pytest
+
+from popsift_amd.synth import synth
+from tests.parity import assert_parity, budget, match_features
+
+pytestmark = pytest.mark.gpu
+
+
+def test_copy_bench_and_blur_probe(capi):
+    gbs, ms = capi.copy_bench(0, 1 << 28, 3)          # 256 MiB + 256 MiB: quick; bench.py uses 1 GiB
+    assert 500.0 < gbs < 8000.0 and ms > 0
+    ctx = capi.Context(capi.default_config(octaves=3))
+    ctx.upload(synth(1024, 768, 1))
+    ctx.enable_blur_probe(True)
+    ctx.extract()
+    ctx.extract()
+    ms_l, by = ctx.blur_probe_times()
+    assert len(ms_l) == ctx.num_levels - 1 and by == 8.0 * 2048 * 1536
+    assert all(0.0 < m < 5.0 for m in ms_l), ms_l
+    # same launches replayed in isolation: same order of magnitude
+    iso = [ctx.time_blur(0, l, 10)[0] for l in range(1, ctx.num_levels)]
+    assert all(0.2 < a / b < 5.0 for a, b in zip(ms_l, iso)), (ms_l, iso)
+    # the probe does not change results
+    f1, d1 = ctx.download()
+    ctx.enable_blur_probe(False)
+    ctx.extract()
+    f2, d2 = ctx.download()
+    assert len(f1) == len(f2) and len(d1) == len(d2)
+    ctx.close()
+
+
+def test_features_dev_records_point_into_descriptor_array(capi):
+    """FeaturesDev::getFeatures() (features.h:104-122): device array of popsift::Feature (72 bytes) whose desc[]
+    are device pointers into the cloned descriptor array, as Pyramid::clone_device_descriptors leaves them."""
+    ctx = capi.Context(capi.default_config(octaves=3))
+    ctx.upload(synth(400, 300, 9))
+    ctx.extract()
+    fh, dh = ctx.download()
+    fd, dd, rev, base = ctx.clone_results()
+    assert capi.FEATURE_DEV_DTYPE.itemsize == 72
+    assert len(fd) == len(fh) and np.array_equal(dd, dh)
+    for name in ("debug_octave", "xpos", "ypos", "sigma", "num_ori", "orientation"):
+        assert np.array_equal(fd[name], fh[name]), name
+    idx = fh["desc_idx"].astype(np.int64)
+    expect = np.where(idx >= 0, base + idx * 512, 0).astype(np.uint64)
+    assert np.array_equal(fd["desc"], expect)
+    # reverse map: descriptor j belongs to the keypoint that lists it
+    for k in range(4):
+        sel = fh["num_ori"] > k
+        assert np.array_equal(rev[fh["desc_idx"][sel, k]], np.flatnonzero(sel))
+    ctx.close()
+
+
+def test_descriptor_buffers_grow_like_realloc_extrema(oracle, capi):
+    """max_extrema = 300 per octave: the descriptor buffers start at 2 x 300 entries (sift_pyramid.cu:154-159);
+    the frame has ~1000 extrema > max_extrema, so the reference's reallocExtrema grows them to 2 x 2048.  The HIP
+    path grows after the counter read-back and reruns scan + descriptors: same features as the oracle."""
+    img = synth(640, 480, 77)
+    kw = dict(octaves=4, max_extrema=300)
+    ref = oracle.run(oracle.default_config(**kw), img)
+    assert ref.ext_total > 600 and ref.ori_total > 600
+    for export in (False, True):
+        ctx = capi.Context(capi.default_config(**kw))
+        if export:
+            fbuf = np.zeros(4096 * capi.FEATURE_DTYPE.itemsize, np.uint8)
+            dbuf = np.zeros(8192 * 128, np.float32)
+            ctx.attach_export(fbuf, dbuf)
+        ctx.upload(img)
+        ctx.extract()
+        ne, no = ctx.counts()
+        assert (ne, abs(no - ref.ori_total) <= 1) == (ref.ext_total, True)
+        fb, db = ctx.exported() if export else ctx.download()
+        m = match_features(ref.features(), ref.descriptors(), fb, db)
+        assert_parity(m, what="regrow export=%s" % export, **budget(len(fb)))
+        # a second frame on the grown buffers
+        ctx.extract()
+        assert ctx.counts() == (ne, no)
+        ctx.close()
+
+
+def test_c_binding_matches_c_abi(oracle, capi):
+    """include/popsift_c.h: PopSift::enqueue / SiftJob::get through the flat C binding gives the oracle's
+    feature set (this is the path bench.py's headline number times)."""
+    img = synth(512, 384, 31)
+    ps = capi.PopSift(capi.default_config(octaves=4))
+    jobs = [ps.enqueue(img) for _ in range(5)]
+    res = [ps.get(j) for j in jobs]
+    ps.close()
+    ref = oracle.run(oracle.default_config(octaves=4), img)
+    for fb, db in res:
+        assert len(fb) == ref.ext_total
+        assert_parity(match_features(ref.features(), ref.descriptors(), fb, db), what="C binding", **budget(len(fb)))
+
+
+def test_auto_octaves_resolved_once_per_popsift(oracle, capi):
+    """Config::octaves = -1: the octave count comes from the FIRST image a PopSift sees and then sticks
+    (popsift.cpp:118-122), whichever of the 8 worker contexts extracts a later image."""
+    small, large = synth(160, 120, 3), synth(640, 480, 4)
+    first_oct = max(int(np.floor(np.log2(120.0)) - 3 + 2), 1)           # scaleFactor = 2 for the default x2 upsample
+    ps = capi.PopSift(capi.default_config(octaves=-1))
+    jobs = [ps.enqueue(small)] + [ps.enqueue(large) for _ in range(12)] + [ps.enqueue(small)]
+    res = [ps.get(j) for j in jobs]
+    ps.close()
+    ref_l = oracle.run(oracle.default_config(octaves=first_oct), large)
+    ref_s = oracle.run(oracle.default_config(octaves=first_oct), small)
+    for (fb, db), ref in zip(res, [ref_s] + [ref_l] * 12 + [ref_s]):
+        assert len(fb) == ref.ext_total, (len(fb), ref.ext_total)
+        assert fb["debug_octave"].max() <= first_oct - 1
+        assert_parity(match_features(ref.features(), ref.descriptors(), fb, db), what="auto octaves", **budget(len(fb)))
