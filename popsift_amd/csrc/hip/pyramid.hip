@@ -54,6 +54,9 @@ struct BlurArgs {
     int nstrips, chunk_rows;
     PsxTaps taps;               // horizontal taps (and vertical, unless LEVEL0)
     PsxTaps taps_v;             // LEVEL0 only: vertical taps
+#ifdef PSX_PHASE_TIMING
+    int dbg;                    // measurement build only: 1 = all loads from 64 cache-resident rows, 2 = no stores
+#endif
 };
 
 // the same chain on two adjacent columns at once (v_pk_fma_f32): v[j] = (T[.][c], T[.][c+1])
@@ -199,7 +202,10 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
 #pragma unroll
             for (int j = 0; j < NLD; j++) {
                 if (j < NLD - 1 || last_on) {
-                    const int y = psx_clampi(ybase + st_row[j], 0, a.H - 1);
+                    int y = psx_clampi(ybase + st_row[j], 0, a.H - 1);
+#ifdef PSX_PHASE_TIMING
+                    if (a.dbg & 1) y &= 63;
+#endif
                     if (INTERIOR) {
                         const unsigned off = (unsigned)(y * a.src_pitch + st_x[j]) * 4u;
                         pre[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.src) + off);
@@ -229,15 +235,22 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
         int pend_k = -1;                                   // step whose results are pending (thread uniform per wave group)
         auto flush = [&]() {
             if (pend_k < 0) return;
+#ifdef PSX_PHASE_TIMING
+            if (a.dbg & 2) { pend_k = -1; return; }
+#endif
             const int rel0 = pend_k * BR - 2 * R + v_rg * 4;
             const int r_out0 = Y0 + rel0;
             // uniform row base of the step; thread offsets are step invariant
             char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + pend_k * BR) * a.pitch);
+#ifdef PSX_PHASE_TIMING
+            if (a.dbg & 4) drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(64 + (blockIdx.x & 7) * 40) * a.pitch);   // stores stay in L2
+#endif
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int r_out = r_out0 + i;
                 if (r_out >= Y0 && r_out < Y1 && v_xok) {
                     char* di = drow + (size_t)i * a.pitch * 4 + v_doff;
+                    // plain stores: non-temporal ones measured 4 % slower in the pipeline (the next level reads these rows)
                     if (v_pair) *reinterpret_cast<v2f*>(di) = pend[i]; else *reinterpret_cast<float*>(di) = pend[i].x;
                     // get_by_2_pick_every_second: rows and columns 0,2,4,.. (v_x is even)
                     if (a.half_dst != nullptr && (r_out & 1) == 0)
@@ -492,15 +505,17 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
     int nchunks;
     chunking(W, H, R, a.chunk_rows, nchunks);
     a.taps = taps; a.taps_v = taps;
+#ifdef PSX_PHASE_TIMING
+    { const char* e = getenv("POPSIFT_BLUR_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
     const dim3 grid(a.nstrips * nchunks), block(NT);
-    if (ev0 != nullptr || ev1 != nullptr) {
-        // kernel begin / end timestamps of THIS dispatch (what rocprofv3 --kernel-trace reports)
-        if (blur_tuning().defer) hipExtLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, ev0, ev1, 0, a);
-        else                     hipExtLaunchKernelGGL((k_blur<R, false, false>), grid, block, 0, s, ev0, ev1, 0, a);
-    } else if (blur_tuning().defer) {
-        hipLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, a);
+    const bool ext = ev0 != nullptr || ev1 != nullptr;       // kernel begin / end timestamps of THIS dispatch (what rocprofv3 --kernel-trace reports)
+    if (blur_tuning().defer) {
+        if (ext) hipExtLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, ev0, ev1, 0, a);
+        else     hipLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, a);
     } else {
-        hipLaunchKernelGGL((k_blur<R, false, false>), grid, block, 0, s, a);
+        if (ext) hipExtLaunchKernelGGL((k_blur<R, false, false>), grid, block, 0, s, ev0, ev1, 0, a);
+        else     hipLaunchKernelGGL((k_blur<R, false, false>), grid, block, 0, s, a);
     }
     return hipGetLastError();
 }
@@ -526,6 +541,9 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
     int nchunks;
     chunking(h.W, h.H, R, a.chunk_rows, nchunks);
     a.taps = h.taps_h; a.taps_v = h.taps_v;
+#ifdef PSX_PHASE_TIMING
+    a.dbg = 0;
+#endif
     hipLaunchKernelGGL((k_blur<R, true>), dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
