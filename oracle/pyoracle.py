@@ -21,6 +21,8 @@ GAUSS_VLFEAT_COMPUTE, GAUSS_VLFEAT_RELATIVE, GAUSS_VLFEAT_RELATIVE_ALL, GAUSS_OP
     GAUSS_FIXED9, GAUSS_FIXED15 = range(6)
 MODE_POPSIFT, MODE_OPENCV, MODE_VLFEAT = 0, 1, 2
 NORM_ROOTSIFT, NORM_CLASSIC = 0, 1
+SCALE_DIRECT, SCALE_DEFAULT = 0, 1
+DESC_LOOP, DESC_ILOOP, DESC_GRID, DESC_IGRID, DESC_NOTILE = range(5)
 FILTER_RANDOM, FILTER_LARGEST_FIRST, FILTER_SMALLEST_FIRST = 0, 1, 2
 
 
@@ -32,6 +34,7 @@ class Config(C.Structure):
         ("norm_multi", C.c_int), ("max_extrema", C.c_int), ("assume_initial_blur", C.c_int),
         ("initial_blur", C.c_float), ("filter_max_extrema", C.c_int),
         ("filter_grid_size", C.c_int), ("grid_filter_mode", C.c_int), ("literal_tex", C.c_int),
+        ("scaling_mode", C.c_int), ("desc_mode", C.c_int),
     ]
 
 
@@ -43,6 +46,14 @@ class Tables(C.Structure):
         ("dd_filter", C.c_float * (MAX_OCTAVES * GAUSS_ALIGN)),
         ("dd_sigma", C.c_float * MAX_OCTAVES),
         ("dd_span", C.c_int * MAX_OCTAVES),
+        ("abs0_filter", C.c_float * (GAUSS_LEVELS * GAUSS_ALIGN)),
+        ("abs0_sigma", C.c_float * GAUSS_LEVELS),
+        ("abs0_span", C.c_int * GAUSS_LEVELS),
+        ("absN_filter", C.c_float * (GAUSS_LEVELS * GAUSS_ALIGN)),
+        ("absN_sigma", C.c_float * GAUSS_LEVELS),
+        ("absN_span", C.c_int * GAUSS_LEVELS),
+        ("inc_ifilter", C.c_float * (GAUSS_LEVELS * GAUSS_ALIGN)),
+        ("inc_ispan", C.c_int * GAUSS_LEVELS),
     ]
 
 
@@ -129,6 +140,14 @@ def gauss_tables(cfg):
         "dd_filter": np.array(t.dd_filter, dtype=np.float32).reshape(MAX_OCTAVES, GAUSS_ALIGN),
         "dd_sigma": np.array(t.dd_sigma, dtype=np.float32),
         "dd_span": np.array(t.dd_span, dtype=np.int32),
+        "abs0_filter": np.array(t.abs0_filter, dtype=np.float32).reshape(GAUSS_LEVELS, GAUSS_ALIGN),
+        "abs0_sigma": np.array(t.abs0_sigma, dtype=np.float32),
+        "abs0_span": np.array(t.abs0_span, dtype=np.int32),
+        "absN_filter": np.array(t.absN_filter, dtype=np.float32).reshape(GAUSS_LEVELS, GAUSS_ALIGN),
+        "absN_sigma": np.array(t.absN_sigma, dtype=np.float32),
+        "absN_span": np.array(t.absN_span, dtype=np.int32),
+        "inc_ifilter": np.array(t.inc_ifilter, dtype=np.float32).reshape(GAUSS_LEVELS, GAUSS_ALIGN),
+        "inc_ispan": np.array(t.inc_ispan, dtype=np.int32),
     }
 
 

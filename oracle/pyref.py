@@ -56,6 +56,14 @@ def gauss_tables(cfg):
         "dd_filter": np.array(t.dd_filter, dtype=np.float32).reshape(po.MAX_OCTAVES, po.GAUSS_ALIGN),
         "dd_sigma": np.array(t.dd_sigma, dtype=np.float32),
         "dd_span": np.array(t.dd_span, dtype=np.int32),
+        "abs0_filter": np.array(t.abs0_filter, dtype=np.float32).reshape(po.GAUSS_LEVELS, po.GAUSS_ALIGN),
+        "abs0_sigma": np.array(t.abs0_sigma, dtype=np.float32),
+        "abs0_span": np.array(t.abs0_span, dtype=np.int32),
+        "absN_filter": np.array(t.absN_filter, dtype=np.float32).reshape(po.GAUSS_LEVELS, po.GAUSS_ALIGN),
+        "absN_sigma": np.array(t.absN_sigma, dtype=np.float32),
+        "absN_span": np.array(t.absN_span, dtype=np.int32),
+        "inc_ifilter": np.array(t.inc_ifilter, dtype=np.float32).reshape(po.GAUSS_LEVELS, po.GAUSS_ALIGN),
+        "inc_ispan": np.array(t.inc_ispan, dtype=np.int32),
     }
 
 

@@ -53,6 +53,8 @@ Config make_config(const osift_config* c)
     conf.setFilterMaxExtrema(c->filter_max_extrema);
     conf.setFilterGridSize(c->filter_grid_size);
     conf.setFilterSorting((Config::GridFilterMode)c->grid_filter_mode);
+    conf.setScalingMode((Config::ScalingMode)c->scaling_mode);
+    conf.setDescMode((Config::DescMode)c->desc_mode);
     return conf;
 }
 
@@ -175,6 +177,14 @@ int ref_gauss_tables(const osift_config* c, osift_tables* t)
     memcpy(t->dd_filter, h_gauss.dd.filter, sizeof(t->dd_filter));
     memcpy(t->dd_sigma, h_gauss.dd.sigma, sizeof(t->dd_sigma));
     memcpy(t->dd_span, h_gauss.dd.span, sizeof(t->dd_span));
+    memcpy(t->abs0_filter, h_gauss.abs_o0.filter, sizeof(t->abs0_filter));
+    memcpy(t->abs0_sigma, h_gauss.abs_o0.sigma, sizeof(t->abs0_sigma));
+    memcpy(t->abs0_span, h_gauss.abs_o0.span, sizeof(t->abs0_span));
+    memcpy(t->absN_filter, h_gauss.abs_oN.filter, sizeof(t->absN_filter));
+    memcpy(t->absN_sigma, h_gauss.abs_oN.sigma, sizeof(t->absN_sigma));
+    memcpy(t->absN_span, h_gauss.abs_oN.span, sizeof(t->absN_span));
+    memcpy(t->inc_ifilter, h_gauss.inc.i_filter, sizeof(t->inc_ifilter));
+    memcpy(t->inc_ispan, h_gauss.inc.i_span, sizeof(t->inc_ispan));
     return 0;
 }
 

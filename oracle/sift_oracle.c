@@ -62,6 +62,8 @@ void osift_config_default(osift_config* c)
     c->assume_initial_blur = 1;
     c->initial_blur = 0.5f;
     c->filter_max_extrema = -1;
+    c->scaling_mode = OSIFT_SCALE_DEFAULT;
+    c->desc_mode = OSIFT_DESC_LOOP;
     c->filter_grid_size = 2;
     c->grid_filter_mode = OSIFT_FILTER_RANDOM;
     c->literal_tex = 0;
@@ -151,6 +153,37 @@ int osift_gauss_tables(const osift_config* c, osift_tables* t)
         t->dd_sigma[oct] = scalbnf(b, -oct);
     }
     compute_blur_table(c->gauss_mode, OSIFT_MAX_OCTAVES, t->dd_sigma, t->dd_span, t->dd_filter);
+
+    /* abs_o0 (:188-197): octave 0 directly from the input image */
+    for (int lvl = 0; lvl < stages; lvl++) {
+        const float sigmaS = sigma0 * powf(2.0f, (float)(lvl) / (float)levels);
+        t->abs0_sigma[lvl] = sqrtf(fabsf(sigmaS * sigmaS - initial_blur * initial_blur));
+    }
+    compute_blur_table(c->gauss_mode, OSIFT_GAUSS_LEVELS, t->abs0_sigma, t->abs0_span, t->abs0_filter);
+    /* abs_oN (:199-214): levels >= 1 directly from level 0 of their octave */
+    t->absN_sigma[0] = 0;
+    for (int lvl = 1; lvl < stages; lvl++) {
+        const float sigmaP = sigma0;
+        const float sigmaS = sigma0 * powf(2.0f, (float)(lvl) / (float)levels);
+        t->absN_sigma[lvl] = sqrtf(sigmaS * sigmaS - sigmaP * sigmaP);
+    }
+    compute_blur_table(c->gauss_mode, OSIFT_GAUSS_LEVELS, t->absN_sigma, t->absN_span, t->absN_filter);
+    /* transformBlurTable (:373-410) of the inc table: tap pairs (x, x+1) become a ratio u = a/(a+b) (odd index)
+     * and a multiplier v = a+b (even index) for one hardware-interpolated fetch per pair */
+    for (int level = 0; level < OSIFT_GAUSS_LEVELS; level++) {
+        int isp = t->inc_span[level];
+        if (!(isp & 1)) isp += 1;
+        t->inc_ispan[level] = isp;
+        const float* f = t->inc_filter + level * OSIFT_GAUSS_ALIGN;
+        float* fi = t->inc_ifilter + level * OSIFT_GAUSS_ALIGN;
+        for (int x = 1; x < isp; x += 2) {
+            const float a = f[x], b = f[x + 1];
+            fi[x] = a / (a + b);
+            fi[x + 1] = a + b;
+        }
+        fi[0] = f[0];
+        for (int x = isp; x < OSIFT_GAUSS_ALIGN; x++) fi[x] = 0;
+    }
     return 0;
 }
 
@@ -395,6 +428,260 @@ static void make_dog(osift_result* r, int o)
         #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; i++) d[i] = b[i] - a[i];
     }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Alternative pyramid modes (s_pyramid_build.cu:478-546)                     */
+/* ------------------------------------------------------------------------- */
+
+/* readTex (assist.h:68-77) on a LINEAR-filtered layered texture of one plane: unnormalised coordinates,
+ * clamp addressing, filtering model as for the input image (1.8 fixed-point weights).  x, y are the
+ * arguments of readTex, which adds 0.5 to both. */
+static float plane_linear(const float* p, int W, int H, float x, float y)
+{
+    const float xs = x + 0.5f, ys = y + 0.5f;
+    const float xb = xs - 0.5f, yb = ys - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    float a = xb - fx, b = yb - fy;
+    a = rintf(a * 256.0f) * (1.0f / 256.0f);
+    b = rintf(b * 256.0f) * (1.0f / 256.0f);
+    const int i = (int)fx, j = (int)fy;
+    const int i0 = clampi(i, 0, W - 1), i1 = clampi(i + 1, 0, W - 1);
+    const int j0 = clampi(j, 0, H - 1), j1 = clampi(j + 1, 0, H - 1);
+    const float r0 = lerpf(p[(size_t)j0 * W + i0], p[(size_t)j0 * W + i1], a);
+    const float r1 = lerpf(p[(size_t)j1 * W + i0], p[(size_t)j1 * W + i1], a);
+    return lerpf(r0, r1, b);
+}
+
+/* normalizedSource::horiz / horiz_level / horiz_all (s_pyramid_build_ra.cu:17-132): one level of octave o
+ * filtered horizontally straight from the input image, per-tap texture coordinates, result * 255 */
+static void h_from_input(const tex_in* t, int W, int H, const float* filter, int span, float shift, float* intm)
+{
+    #pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++) {
+        const float read_y = ((float)y + shift) / H;
+        for (int x = 0; x < W; x++) {
+            const float read_x = ((float)x + shift) / W;
+            float out = 0.0f;
+            for (int offset = span; offset > 0; offset--) {
+                const float g = filter[offset];
+                const float offrel = (float)offset / W;
+                const float v1 = tex2d_norm(t, read_x - offrel, read_y);
+                const float v2 = tex2d_norm(t, read_x + offrel, read_y);
+                out = fmaf(v1 + v2, g, out);
+            }
+            out = fmaf(tex2d_norm(t, read_x, read_y), filter[0], out);
+            intm[(size_t)y * W + x] = out * 255.0f;
+        }
+    }
+}
+
+/* absoluteSource::vert / vert_abs0 (s_pyramid_build_aa.cu:52-122) */
+static void v_plain(const float* intm, float* dst, int W, int H, const float* f, int span)
+{
+    #pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float out = 0.0f;
+            for (int offset = span; offset > 0; offset--) {
+                const float g = f[offset];
+                out = fmaf(intm[(size_t)clampi(y - offset, 0, H - 1) * W + x], g, out);
+                out = fmaf(intm[(size_t)clampi(y + offset, 0, H - 1) * W + x], g, out);
+            }
+            out = fmaf(intm[(size_t)y * W + x], f[0], out);
+            dst[(size_t)y * W + x] = out;
+        }
+}
+
+/* absoluteSourceInterpolated::horiz / vert (s_pyramid_build_ai.cu:17-69): tap pairs through one linear fetch */
+static void hv_interp(const float* src, float* dst, int W, int H, const float* fi, int ispan, int vertical)
+{
+    #pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float out = 0.0f;
+            for (int offset = 1; offset <= ispan; offset += 2) {
+                const float u = fi[offset];
+                const float off = offset + (1.0f - u);
+                float val;
+                if (vertical) val = plane_linear(src, W, H, (float)x, (float)y - off) + plane_linear(src, W, H, (float)x, (float)y + off);
+                else          val = plane_linear(src, W, H, (float)x - off, (float)y) + plane_linear(src, W, H, (float)x + off, (float)y);
+                const float v = fi[offset + 1];
+                out = fmaf(val, v, out);
+            }
+            out = fmaf(plane_linear(src, W, H, (float)x, (float)y), fi[0], out);
+            dst[(size_t)y * W + x] = out;
+        }
+}
+
+/* absoluteSource::horiz (s_pyramid_build_aa.cu:17-50) */
+static void h_plain(const float* src, float* intm, int W, int H, const float* f, int span)
+{
+    #pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++) {
+        const float* row = src + (size_t)y * W;
+        for (int x = 0; x < W; x++) {
+            float out = 0.0f;
+            out = fmaf(row[x], f[0], out);
+            out = fmaf(row[clampi(x - span, 0, W - 1)] + row[clampi(x + span, 0, W - 1)], f[span], out);
+            for (int offset = span - 1; offset > 0; offset--)
+                out = fmaf(row[clampi(x - offset, 0, W - 1)] + row[clampi(x + offset, 0, W - 1)], f[offset], out);
+            intm[(size_t)y * W + x] = out;
+        }
+    }
+}
+
+/* fixedSpan::relativeTexAddress::octave_fixed (s_pyramid_fixed.cu:120-190): octave 0, every level straight
+ * from the input image with the first SHIFT+1 taps of abs_o0; vertical first, then horizontal (the warp
+ * shuffles of octave_fixed_horiz see lane N's vertical value for column idx-SHIFT and hand lane N the sum
+ * centred on column idx) */
+static void fixed_octave0(osift_result* r, const tex_in* t, int SHIFT)
+{
+    const osift_config* c = &r->cfg;
+    const int W = r->W[0], H = r->H[0];
+    const float tshift = 0.5f * powf(2.0f, c->upscale_factor);
+    const float mul_w = 1.0f / (float)W, mul_h = 1.0f / (float)H;          /* __frcp_rn */
+    float* vbuf = (float*)malloc(sizeof(float) * (size_t)(W + 2 * SHIFT) * H);
+    for (int level = 0; level < r->L; level++) {
+        const float* f = r->tab.abs0_filter + level * OSIFT_GAUSS_ALIGN;
+        float* dst = r->data[0] + (size_t)level * W * H;
+        const int VW = W + 2 * SHIFT;
+        #pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; y++)
+            for (int cx = -SHIFT; cx < W + SHIFT; cx++) {
+                const float xpos = ((float)cx + tshift) * mul_w;
+                const float ypos = ((float)y + tshift) * mul_h;
+                float val = tex2d_norm(t, xpos, ypos);
+                float fval = val * f[0];
+                for (int i = 1; i <= SHIFT; i++) {
+                    val  = tex2d_norm(t, xpos, ypos - i * mul_h);
+                    val += tex2d_norm(t, xpos, ypos + i * mul_h);
+                    fval = fmaf(val, f[i], fval);
+                }
+                vbuf[(size_t)y * VW + cx + SHIFT] = fval;
+            }
+        #pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const float* v = vbuf + (size_t)y * VW + x + SHIFT;
+                float out = v[0] * f[0];
+                for (int i = 1; i <= SHIFT; i++) out = fmaf(v[-i] + v[i], f[i], out);
+                dst[(size_t)y * W + x] = out * 255.0f;
+            }
+    }
+    free(vbuf);
+}
+
+/* fixedSpan::absoluteTexAddress::octave_fixed (s_pyramid_fixed.cu:48-116): levels 1..L-1 of an octave from its
+ * level 0 with the first SHIFT+1 taps of abs_oN */
+static void fixed_octaveN(osift_result* r, int o, int SHIFT)
+{
+    const int W = r->W[o], H = r->H[o];
+    const float* src = r->data[o];
+    const int VW = W + 2 * SHIFT;
+    float* vbuf = (float*)malloc(sizeof(float) * (size_t)VW * H);
+    for (int level = 1; level < r->L; level++) {
+        const float* f = r->tab.absN_filter + level * OSIFT_GAUSS_ALIGN;
+        float* dst = r->data[o] + (size_t)level * W * H;
+        #pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; y++)
+            for (int cx = -SHIFT; cx < W + SHIFT; cx++) {
+                const int xc = clampi(cx, 0, W - 1);
+                float val = src[(size_t)y * W + xc];
+                float fval = val * f[0];
+                for (int i = 1; i <= SHIFT; i++) {
+                    val = src[(size_t)clampi(y - i, 0, H - 1) * W + xc] + src[(size_t)clampi(y + i, 0, H - 1) * W + xc];
+                    fval = fmaf(val, f[i], fval);
+                }
+                vbuf[(size_t)y * VW + cx + SHIFT] = fval;
+            }
+        #pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const float* v = vbuf + (size_t)y * VW + x + SHIFT;
+                float out = v[0] * f[0];
+                for (int i = 1; i <= SHIFT; i++) out = fmaf(v[-i] + v[i], f[i], out);
+                dst[(size_t)y * W + x] = out;
+            }
+    }
+    free(vbuf);
+}
+
+/* Pyramid::build_pyramid (s_pyramid_build.cu:459-594): all branches.  Returns 0, or -1 for the combinations
+ * the reference rejects with POP_FATAL (Fixed9 / Fixed15 with levels != 3, s_pyramid_fixed.cu:270-292). */
+static int build_pyramid(osift_result* r, const tex_in* t)
+{
+    const osift_config* c = &r->cfg;
+    const int gm = c->gauss_mode;
+    const int fixed = (gm == OSIFT_GAUSS_FIXED9 || gm == OSIFT_GAUSS_FIXED15);
+    const int direct = (c->scaling_mode == OSIFT_SCALE_DIRECT);
+    const int SHIFT = (gm == OSIFT_GAUSS_FIXED9) ? 4 : 7;
+    if (fixed && r->L != 6) return -1;
+    if (!fixed && !direct && (gm == OSIFT_GAUSS_VLFEAT_COMPUTE || gm == OSIFT_GAUSS_OPENCV_COMPUTE)) {
+        /* default branch, s_pyramid_build.cu:547-586 */
+        for (int o = 0; o < r->num_octaves; o++) {
+            if (o == 0) octave0_level0(r, t);
+            else downscale(r, o);
+            for (int level = 1; level < r->L; level++) blur_level(r, o, level);
+        }
+        return 0;
+    }
+    const osift_tables* T = &r->tab;
+    for (int o = 0; o < r->num_octaves; o++) {
+        const int W = r->W[o], H = r->H[o];
+        const size_t n = (size_t)W * H;
+        float* intm = (float*)malloc(sizeof(float) * n);
+        /* horiz_from_input_image (s_pyramid_build.cu:96-126) */
+        float shift = 0.5f;
+        if (o == 0 && (c->sift_mode == OSIFT_MODE_POPSIFT || c->sift_mode == OSIFT_MODE_VLFEAT))
+            shift = 0.5f * powf(2.0f, c->upscale_factor - o);
+        if (fixed) {
+            if (o == 0) fixed_octave0(r, t, SHIFT);
+            else {
+                if (direct) {
+                    h_from_input(t, W, H, T->dd_filter + o * OSIFT_GAUSS_ALIGN, T->dd_span[o], shift, intm);
+                    v_plain(intm, r->data[o], W, H, T->inc_filter, T->inc_span[0]);
+                } else downscale(r, o);
+                fixed_octaveN(r, o, SHIFT);
+            }
+        } else if (direct) {
+            const int interp = (gm == OSIFT_GAUSS_VLFEAT_RELATIVE);
+            for (int level = 0; level < r->L; level++) {
+                float* dst = r->data[o] + level * n;
+                if (level == 0) h_from_input(t, W, H, T->dd_filter + o * OSIFT_GAUSS_ALIGN, T->dd_span[o], shift, intm);
+                else if (interp) hv_interp(r->data[o] + (level - 1) * n, intm, W, H, T->inc_ifilter + level * OSIFT_GAUSS_ALIGN, T->inc_ispan[level], 0);
+                else h_plain(r->data[o] + (level - 1) * n, intm, W, H, T->inc_filter + level * OSIFT_GAUSS_ALIGN, T->inc_span[level]);
+                if (interp) hv_interp(intm, dst, W, H, T->inc_ifilter + level * OSIFT_GAUSS_ALIGN, T->inc_ispan[level], 1);
+                else v_plain(intm, dst, W, H, T->inc_filter + level * OSIFT_GAUSS_ALIGN, T->inc_span[level]);
+            }
+        } else if (gm == OSIFT_GAUSS_VLFEAT_RELATIVE) {
+            for (int level = 0; level < r->L; level++) {
+                float* dst = r->data[o] + level * n;
+                const float* fi = T->inc_ifilter + level * OSIFT_GAUSS_ALIGN;
+                if (level == 0) {
+                    if (o == 0) {
+                        h_from_input(t, W, H, T->dd_filter, T->dd_span[0], shift, intm);
+                        hv_interp(intm, dst, W, H, fi, T->inc_ispan[0], 1);
+                    } else downscale(r, o);
+                } else {
+                    hv_interp(r->data[o] + (level - 1) * n, intm, W, H, fi, T->inc_ispan[level], 0);
+                    hv_interp(intm, dst, W, H, fi, T->inc_ispan[level], 1);
+                }
+            }
+        } else if (o == 0 && gm == OSIFT_GAUSS_VLFEAT_RELATIVE_ALL) {
+            /* horiz_all_from_input_image + vert_all_from_interm(NotInterpolated_FromFirst) */
+            for (int level = 0; level < r->L; level++) {
+                h_from_input(t, W, H, T->abs0_filter + level * OSIFT_GAUSS_ALIGN, T->abs0_span[level], shift, intm);
+                v_plain(intm, r->data[0] + level * n, W, H, T->abs0_filter + level * OSIFT_GAUSS_ALIGN, T->abs0_span[level]);
+            }
+        } else {
+            if (o == 0) octave0_level0(r, t);
+            else downscale(r, o);
+            for (int level = 1; level < r->L; level++) blur_level(r, o, level);
+        }
+        free(intm);
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1057,6 +1344,292 @@ static void normalize_desc(const osift_config* c, float* d)
 }
 
 /* ------------------------------------------------------------------------- */
+/* Alternative descriptor modes                                              */
+/* ------------------------------------------------------------------------- */
+
+/* get_gradiant on a linear texture with a rotated stencil (s_gradiant.h:72-88): the gradient in the
+ * keypoint's frame, so the angle needs no "- ang" afterwards */
+static inline void get_gradiant_rot(float* grad, float* theta, float x, float y, float cos_t, float sin_t,
+                                    const float* plane, int W, int H)
+{
+    const float dx = plane_linear(plane, W, H, x + cos_t, y + sin_t) - plane_linear(plane, W, H, x - cos_t, y - sin_t);
+    const float dy = plane_linear(plane, W, H, x - sin_t, y + cos_t) - plane_linear(plane, W, H, x + sin_t, y - cos_t);
+    *grad = hypotf(dx, dy);
+    *theta = atan2f(dy, dx);
+}
+
+/* point-texture gradient at float coordinates that are integers after rounding (s_gradiant.h:56-69 called
+ * with float arguments from s_desc_grid.cu:78: the int parameters truncate them) */
+static inline void get_gradiant_pt(float* grad, float* theta, int x, int y, const float* plane, int W, int H)
+{
+    const float dx = rdata(plane, W, H, x + 1, y) - rdata(plane, W, H, x - 1, y);
+    const float dy = rdata(plane, W, H, x, y + 1) - rdata(plane, W, H, x, y - 1);
+    *grad = hypotf(dx, dy);
+    *theta = atan2f(dy, dx);
+}
+
+/* the shuffle_down tree of a group of `width` lanes as lane 0 sees it (lanes beyond the group read their own value) */
+static float group_sum(const float* lane_vals, int width)
+{
+    float v[32];
+    memcpy(v, lane_vals, sizeof(float) * (size_t)width);
+    for (int delta = width / 2; delta >= 1; delta >>= 1) {
+        float nv[32];
+        for (int l = 0; l < width; l++) nv[l] = v[l] + (l + delta < width ? v[l + delta] : v[l]);
+        memcpy(v, nv, sizeof(float) * (size_t)width);
+    }
+    return v[0];
+}
+
+/* ext_desc_iloop (s_desc_iloop.cu:19-130): per tile a 32 x 32 grid of sample points in the tile's own
+ * 2x2-SBP support, gradients by bilinear interpolation in the rotated frame */
+static void descriptor_iloop(const osift_result* r, const osift_ext* ext, float ang, float* features)
+{
+    const int o = ext->octave;
+    const int W = r->W[o], H = r->H[o];
+    const float x = ext->xpos, y = ext->ypos;
+    const float SBP = fabsf(DESC_MAGNIFY * ext->sigma);
+    const float* plane = r->data[o] + (size_t)clampi(ext->lpos, 0, r->L - 1) * W * H;
+    for (int i = 0; i < 128; i++) features[i] = 0.0f;
+    if (SBP == 0) return;
+    const float cos_t = cosf(ang), sin_t = sinf(ang);          /* __sincosf */
+    const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+    for (int iy = 0; iy < 4; iy++)
+    for (int ix = 0; ix < 4; ix++) {
+        const int tile = (((iy << 2) + ix) << 3);
+        const float offx = ix - 1.5f, offy = iy - 1.5f;
+        const float ptx = fmaf(csbp, offx, -ssbp * offy);
+        const float pty = fmaf(csbp, offy,  ssbp * offx);
+        const float bsz = fabsf(cos_t) + fabsf(sin_t);
+        float dpt[32][9];
+        memset(dpt, 0, sizeof(dpt));
+        for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 32; j++) {
+            const float dx = (-bsz + j * bsz / 16.0f);
+            const float dy = (-bsz + i * bsz / 16.0f);
+            const float nx = fmaf(cos_t, dx,  sin_t * dy);
+            const float ny = fmaf(cos_t, dy, -sin_t * dx);
+            const float nnx = fabsf(nx), nny = fabsf(ny);
+            if (nnx < 1.0f && nny < 1.0f) {
+                const float jj = x + ptx + dx * SBP;
+                const float ii = y + pty + dy * SBP;
+                float mod, th;
+                get_gradiant_rot(&mod, &th, jj, ii, cos_t, sin_t, plane, W, H);
+                const float dnx = nx + offx, dny = ny + offy;
+                const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3));   /* __expf */
+                const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod;
+                th += (th <  0.0f  ? PI2_F : 0.0f);
+                th -= (th >= PI2_F ? PI2_F : 0.0f);
+                desc_bin_accum(th, wgt, dpt[j]);
+            }
+        }
+        for (int l = 0; l < 32; l++) dpt[l][0] += dpt[l][8];
+        for (int b = 0; b < 8; b++) {
+            float v[32];
+            for (int l = 0; l < 32; l++) v[l] = dpt[l][b];
+            features[tile + b] = group_sum(v, 32);
+        }
+    }
+}
+
+/* ext_desc_grid (s_desc_grid.cu:19-124): per tile a 16 x 16 grid of sample points snapped to pixel centres */
+static void descriptor_grid(const osift_result* r, const osift_ext* ext, float ang, float* features)
+{
+    const int o = ext->octave;
+    const int W = r->W[o], H = r->H[o];
+    const float x = ext->xpos, y = ext->ypos;
+    const float SBP = fabsf(DESC_MAGNIFY * ext->sigma);
+    const float* plane = r->data[o] + (size_t)clampi(ext->lpos, 0, r->L - 1) * W * H;
+    for (int i = 0; i < 128; i++) features[i] = 0.0f;
+    if (SBP == 0) return;
+    const float cos_t = cosf(ang), sin_t = sinf(ang);          /* __sincosf */
+    const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+    for (int iy = 0; iy < 4; iy++)
+    for (int ix = 0; ix < 4; ix++) {
+        const int tile = (((iy << 2) + ix) << 3);
+        const float offx = ix - 1.5f, offy = iy - 1.5f;
+        const float ptx = fmaf(csbp, offx, fmaf(-ssbp, offy, x));
+        const float pty = fmaf(csbp, offy, fmaf( ssbp, offx, y));
+        const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t;           /* lft_dn */
+        const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;               /* rgt_stp */
+        const float usx = -sin_t / 8.0f, usy = cos_t / 8.0f;              /* up__stp */
+        float dpt[16][9];
+        memset(dpt, 0, sizeof(dpt));
+        for (int xd = 0; xd < 16; xd++)
+        for (int yd = 0; yd < 16; yd++) {
+            /* float2 pixo = lft_dn + (xd+0.5f) * rgt_stp + (yd+0.5f) * up__stp; pix = pixo * SBP;
+             * pix = round(pt + pix) - pt  -- as the device compiler contracts it (nvcc -fmad=true) */
+            float pox = fmaf(yd + 0.5f, usx, fmaf(xd + 0.5f, rsx, ldx));
+            float poy = fmaf(yd + 0.5f, usy, fmaf(xd + 0.5f, rsy, ldy));
+            float pix_x = roundf(fmaf(pox, SBP, ptx)) - ptx;
+            float pix_y = roundf(fmaf(poy, SBP, pty)) - pty;
+            pox = pix_x / SBP; poy = pix_y / SBP;
+            float mod, th;
+            get_gradiant_pt(&mod, &th, (int)(ptx + pix_x), (int)(pty + pix_y), plane, W, H);
+            const float npx = fmaf(cos_t, pox,  sin_t * poy);
+            const float npy = fmaf(cos_t, poy, -sin_t * pox);
+            const float dnx = npx + offx, dny = npy + offy;
+            const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3));
+            const float wx = 1.0f - fabsf(npx), wy = 1.0f - fabsf(npy);
+            if (wx < 0.0f || wy < 0.0f) continue;
+            const float wgt = ww * wx * wy * mod;
+            th -= ang;
+            th += (th <  0.0f  ? PI2_F : 0.0f);
+            th -= (th >= PI2_F ? PI2_F : 0.0f);
+            desc_bin_accum(th, wgt, dpt[xd]);
+        }
+        for (int l = 0; l < 16; l++) dpt[l][0] += dpt[l][8];
+        for (int b = 0; b < 8; b++) {
+            float v[16];
+            for (int l = 0; l < 16; l++) v[l] = dpt[l][b];
+            features[tile + b] = group_sum(v, 16);
+        }
+    }
+}
+
+/* sift_constants.cu:34-47: desc_gauss[40][40], desc_tile[16] */
+static float g_desc_gauss[40][40];
+static float g_desc_tile[16];
+static int   g_desc_tables_done = 0;
+static void init_desc_tables(void)
+{
+    if (g_desc_tables_done) return;
+    const float dn_step = 1.0f / 8.0f;
+    const float dn_base = 0.5f * dn_step - 20.0f * dn_step;
+    for (int yy = 0; yy < 40; yy++)
+        for (int xx = 0; xx < 40; xx++) {
+            const float dnx = dn_base + xx * dn_step;
+            const float dny = dn_base + yy * dn_step;
+            g_desc_gauss[yy][xx] = expf(-scalbnf(dnx * dnx + dny * dny, -3));
+        }
+    for (int i = 0; i < 16; i++) {
+        const float nx = -1.0f + 1.0f / 16.0f + i * 1.0f / 8.0f;
+        g_desc_tile[i] = 1.0f - fabsf(nx);
+    }
+    g_desc_tables_done = 1;
+}
+
+/* th * M_4RPI rounded up (__fmul_ru, s_desc_igrid.cu:48) */
+static __attribute__((noinline)) float mul_ru(float a, float b)
+{
+    unsigned int csr = _mm_getcsr();
+    fp_dep1(&a); fp_dep1(&b);
+    _mm_setcsr((csr & ~_MM_ROUND_MASK) | _MM_ROUND_UP);
+    fp_dep1(&a); fp_dep1(&b);
+    float t = a * b;
+    fp_dep1(&t);
+    _mm_setcsr(csr);
+    fp_dep1(&t);
+    return t;
+}
+
+/* ext_desc_igrid (s_desc_igrid.cu:19-72): per tile 16 x 16 fixed sample points in the keypoint frame, bilinear
+ * gradients, tabulated Gaussian and tile weights; xor-tree reduction over 16 lanes */
+static void descriptor_igrid(const osift_result* r, const osift_ext* ext, float ang, float* features)
+{
+    const int o = ext->octave;
+    const int W = r->W[o], H = r->H[o];
+    const float x = ext->xpos, y = ext->ypos;
+    const float* plane = r->data[o] + (size_t)clampi(ext->lpos, 0, r->L - 1) * W * H;
+    for (int i = 0; i < 128; i++) features[i] = 0.0f;
+    if (ext->sigma == 0) return;
+    const float SBP = fabsf(DESC_MAGNIFY * ext->sigma);
+    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    init_desc_tables();
+    for (int iy = 0; iy < 4; iy++)
+    for (int ix = 0; ix < 4; ix++) {
+        const int tile = (((iy << 2) + ix) << 3);
+        float dpt[16][8];
+        memset(dpt, 0, sizeof(dpt));
+        for (int xd = 0; xd < 16; xd++)
+        for (int yd = 0; yd < 16; yd++) {
+            const float stepx = ix - 2.5f + 1.0f / 16.0f + xd / 8.0f;
+            const float stepy = iy - 2.5f + 1.0f / 16.0f + yd / 8.0f;
+            const float ptx = fmaf(cos_t, stepx, -sin_t * stepy);
+            const float pty = fmaf(cos_t, stepy,  sin_t * stepx);
+            float mod, th;
+            get_gradiant_rot(&mod, &th, fmaf(ptx, SBP, x), fmaf(pty, SBP, y), cos_t, sin_t, plane, W, H);
+            th += (th <  0.0f  ? PI2_F : 0.0f);
+            th -= (th >= PI2_F ? PI2_F : 0.0f);
+            const float ww = g_desc_gauss[iy * 8 + yd][ix * 8 + xd];
+            const float wgt = ww * g_desc_tile[xd] * g_desc_tile[yd] * mod;
+            const float tth = mul_ru(th, M_4RPI_F);
+            const int   fo  = (int)floorf(tth);
+            const float do0 = tth - fo;
+            const int fo1 = (fo + 1) & 7, fo0 = fo & 7;
+            dpt[xd][fo1] = fmaf(wgt, do0, dpt[xd][fo1]);
+            dpt[xd][fo0] = fmaf(wgt, 1.0f - do0, dpt[xd][fo0]);
+        }
+        for (int b = 0; b < 8; b++) {
+            /* shuffle_xor 1, 2, 4, 8 over 16 lanes */
+            float v[16];
+            for (int l = 0; l < 16; l++) v[l] = dpt[l][b];
+            for (int m = 1; m <= 8; m <<= 1) {
+                float nv[16];
+                for (int l = 0; l < 16; l++) nv[l] = v[l] + v[l ^ m];
+                memcpy(v, nv, sizeof(v));
+            }
+            features[tile + b] = v[b];       /* lane threadIdx.x = b writes features[tile + b] */
+        }
+    }
+}
+
+/* ext_desc_notile (s_desc_notile.cu:31-95): one 40 x 40 grid of sample points for the whole window; the thread
+ * (tx 0..31, ty 0..3) owns columns tx and tx+8 and rows 8 ty .. 8 ty + 15; 8-lane shuffle tree */
+static void descriptor_notile(const osift_result* r, const osift_ext* ext, float ang, float* features)
+{
+    const int o = ext->octave;
+    const int W = r->W[o], H = r->H[o];
+    const float x = ext->xpos, y = ext->ypos;
+    const float* plane = r->data[o] + (size_t)clampi(ext->lpos, 0, r->L - 1) * W * H;
+    for (int i = 0; i < 128; i++) features[i] = 0.0f;
+    if (ext->sigma == 0) return;
+    const float SBP = fabsf(DESC_MAGNIFY * ext->sigma);
+    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    const float stepbase = -2.5f + 1.0f / 16.0f;
+    init_desc_tables();
+    for (int out_y = 0; out_y < 4; out_y++) {
+        float dpt[32][8];
+        memset(dpt, 0, sizeof(dpt));
+        for (int tx = 0; tx < 32; tx++) {
+            const int in_x = tx & 7;
+            for (int xoff = 0; xoff < 2; xoff++) {
+                const int xd = (xoff << 3) + in_x;
+                const int newx = (xoff << 3) + tx;
+                for (int yoff = 0; yoff < 2; yoff++)
+                for (int in_y = 0; in_y < 8; in_y++) {
+                    const int yd = (yoff << 3) + in_y;
+                    const int newy = (out_y << 3) + yd;
+                    const float wgt = g_desc_tile[xd] * g_desc_tile[yd];
+                    const float stepx = stepbase + scalbnf((float)newx, -3);
+                    const float stepy = stepbase + scalbnf((float)newy, -3);
+                    const float ptx = fmaf(cos_t, stepx, -sin_t * stepy);
+                    const float pty = fmaf(cos_t, stepy,  sin_t * stepx);
+                    float mod, th;
+                    get_gradiant_rot(&mod, &th, fmaf(ptx, SBP, x), fmaf(pty, SBP, y), cos_t, sin_t, plane, W, H);
+                    th += (th < 0.0f ? PI2_F : 0.0f);
+                    const float tth = th * M_4RPI_F;
+                    const int   fo  = (int)floorf(th * M_4RPI_F);
+                    const float do0 = tth - fo;
+                    const int fo0 = fo & 7, fo1 = (fo0 + 1) & 7;
+                    const float ww = g_desc_gauss[newy][newx] * mod;
+                    const float ow0 = (1.0f - do0) * ww, ow1 = do0 * ww;
+                    dpt[tx][fo0] = fmaf(wgt, ow0, dpt[tx][fo0]);
+                    dpt[tx][fo1] = fmaf(wgt, ow1, dpt[tx][fo1]);
+                }
+            }
+        }
+        for (int g = 0; g < 4; g++)
+            for (int b = 0; b < 8; b++) {
+                float v[8];
+                for (int l = 0; l < 8; l++) v[l] = dpt[g * 8 + l][b];
+                /* features[out_y * 32 + tx] = dpt[in_x] after the tree has moved lane 0's sum to all 8 lanes */
+                features[out_y * 32 + g * 8 + b] = group_sum(v, 8);
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Driver (popsift.cpp:109-144, sift_pyramid.cu:108-134,227-240,250-322)      */
 /* ------------------------------------------------------------------------- */
 static osift_result* run_impl(const osift_config* cin, const void* img, int w, int h, int is_float, int full)
@@ -1088,13 +1661,8 @@ static osift_result* run_impl(const osift_config* cin, const void* img, int w, i
         oh = (int)ceilf(oh / 2.0f);
     }
 
-    /* build_pyramid default branch, s_pyramid_build.cu:547-586 */
     tex_in t = { img, w, h, is_float };
-    for (int o = 0; o < r->num_octaves; o++) {
-        if (o == 0) octave0_level0(r, &t);
-        else downscale(r, o);
-        for (int level = 1; level < r->L; level++) blur_level(r, o, level);
-    }
+    if (build_pyramid(r, &t) != 0) { osift_free(r); return NULL; }
     for (int o = 0; o < r->num_octaves; o++) make_dog(r, o);
     if (!full) return r;
 
@@ -1135,12 +1703,20 @@ static osift_result* run_impl(const osift_config* cin, const void* img, int w, i
             if (r->ext[i].idx_ori + k < total_ori) r->feat_to_ext[r->ext[i].idx_ori + k] = i;
 
     r->desc = (float*)calloc((size_t)(total_ori > 0 ? total_ori : 1) * 128, sizeof(float));
+    init_desc_tables();
     #pragma omp parallel for schedule(dynamic, 8)
     for (int j = 0; j < total_ori; j++) {
         const osift_ext* e = &r->ext[r->feat_to_ext[j]];
         const int ori_num = j - e->idx_ori;
-        descriptor_one(r, e, e->orientation[ori_num], r->desc + (size_t)j * 128);
-        normalize_desc(c, r->desc + (size_t)j * 128);
+        float* dj = r->desc + (size_t)j * 128;
+        switch (c->desc_mode) {                                  /* sift_desc.cu:66-83 */
+        case OSIFT_DESC_ILOOP:  descriptor_iloop(r, e, e->orientation[ori_num], dj); break;
+        case OSIFT_DESC_GRID:   descriptor_grid(r, e, e->orientation[ori_num], dj); break;
+        case OSIFT_DESC_IGRID:  descriptor_igrid(r, e, e->orientation[ori_num], dj); break;
+        case OSIFT_DESC_NOTILE: descriptor_notile(r, e, e->orientation[ori_num], dj); break;
+        default:                descriptor_one(r, e, e->orientation[ori_num], dj); break;
+        }
+        normalize_desc(c, dj);
     }
 
     /* prep_features, sift_pyramid.cu:250-280 */

@@ -20,6 +20,11 @@
  *   output mapping          sift_pyramid.cu:250-280
  *   grid filter             s_filtergrid.cu:36-325
  *   2-NN matcher            features.cu:160-225 (osift_match)
+ *   alternative pyramids    s_pyramid_build.cu:478-546, s_pyramid_build_ai.cu:17-132, s_pyramid_build_ra.cu:57-132,
+ *                           s_pyramid_build_aa.cu:88-188, s_pyramid_fixed.cu:24-298 (VLFeat_Relative,
+ *                           VLFeat_Relative_All, Fixed9 / Fixed15, ScaleDirect)
+ *   alternative descriptors s_desc_iloop.cu:19-149, s_desc_grid.cu:19-145, s_desc_igrid.cu:19-108,
+ *                           s_desc_notile.cu:31-128, s_gradiant.h:56-88, sift_constants.cu:34-47
  *
  * PARITY PIN STATUS: PINNED.  The reference ships no golden vectors of its own (its goldens are
  * an external reference.tgz fetched by wget, testScripts/downloadOxfordDataset.sh.in:4-9), so
@@ -57,6 +62,8 @@ enum { OSIFT_GAUSS_VLFEAT_COMPUTE = 0, OSIFT_GAUSS_VLFEAT_RELATIVE = 1,
 enum { OSIFT_MODE_POPSIFT = 0, OSIFT_MODE_OPENCV = 1, OSIFT_MODE_VLFEAT = 2 };
 enum { OSIFT_NORM_ROOTSIFT = 0, OSIFT_NORM_CLASSIC = 1 };
 enum { OSIFT_FILTER_RANDOM = 0, OSIFT_FILTER_LARGEST_FIRST = 1, OSIFT_FILTER_SMALLEST_FIRST = 2 };
+enum { OSIFT_SCALE_DIRECT = 0, OSIFT_SCALE_DEFAULT = 1 };
+enum { OSIFT_DESC_LOOP = 0, OSIFT_DESC_ILOOP = 1, OSIFT_DESC_GRID = 2, OSIFT_DESC_IGRID = 3, OSIFT_DESC_NOTILE = 4 };
 
 typedef struct osift_config {
     int   octaves;            /* -1 = auto (popsift.cpp:118-122) */
@@ -77,6 +84,8 @@ typedef struct osift_config {
     int   grid_filter_mode;   /* RandomScale */
     int   literal_tex;        /* oracle-only: 1 = per-tap texture coordinates exactly as
                                  s_pyramid_build_ra.cu:35-50; 0 = upsampled-row form */
+    int   scaling_mode;       /* ScaleDefault (sift_conf.h:75-80) */
+    int   desc_mode;          /* Loop (sift_conf.h:85-97) */
 } osift_config;
 
 /* sift_extremum.h:25-39 (fields used on the path) */
@@ -115,6 +124,15 @@ typedef struct osift_tables {
     float dd_filter[OSIFT_MAX_OCTAVES * OSIFT_GAUSS_ALIGN];
     float dd_sigma[OSIFT_MAX_OCTAVES];
     int   dd_span[OSIFT_MAX_OCTAVES];
+    /* tables of the alternative pyramid modes (gauss_filter.cu:188-214, 373-410) */
+    float abs0_filter[OSIFT_GAUSS_LEVELS * OSIFT_GAUSS_ALIGN];   /* abs_o0: octave 0 directly from the input */
+    float abs0_sigma[OSIFT_GAUSS_LEVELS];
+    int   abs0_span[OSIFT_GAUSS_LEVELS];
+    float absN_filter[OSIFT_GAUSS_LEVELS * OSIFT_GAUSS_ALIGN];   /* abs_oN: levels >= 1 from level 0 of their octave */
+    float absN_sigma[OSIFT_GAUSS_LEVELS];
+    int   absN_span[OSIFT_GAUSS_LEVELS];
+    float inc_ifilter[OSIFT_GAUSS_LEVELS * OSIFT_GAUSS_ALIGN];   /* inc.i_filter: (ratio, multiplier) pairs */
+    int   inc_ispan[OSIFT_GAUSS_LEVELS];
 } osift_tables;
 
 typedef struct osift_result osift_result;

@@ -110,3 +110,83 @@ def test_fuzz_oracle_vs_reference(oracle, ref, w, h, seed, kw):
     if r.ext_total:
         m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors(), norm_scale=float(2 ** kw["norm_multi"]))
         assert m["kp_match"] == 1.0 and m["ori_match"] == 1.0 and m["desc_match"] == 1.0, m
+
+
+# ---- alternative pyramid / descriptor modes --------------------------------------
+@pytest.mark.parametrize("kw", [dict(gauss_mode=1), dict(gauss_mode=2), dict(gauss_mode=4), dict(gauss_mode=5),
+                                dict(gauss_mode=1, levels=4, sigma=1.4, upscale_factor=0.0)])
+def test_alternative_gauss_tables_bit_equal_reference(oracle, ref, kw):
+    """abs_o0 / abs_oN / interpolated (ratio, multiplier) tables of init_filter (gauss_filter.cu:188-214, 373-410)."""
+    a = ref.gauss_tables(oracle.default_config(**kw))
+    b = oracle.gauss_tables(oracle.default_config(**kw))
+    for k in a:
+        # unused levels (sigma 0) of the fixed-span modes hold 0/0 in both
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+ALT_PYRAMIDS = [
+    dict(gauss_mode=1),                                   # VLFeat_Relative: bilinear-paired taps
+    dict(gauss_mode=2),                                   # VLFeat_Relative_All: octave 0 straight from the input
+    dict(gauss_mode=4), dict(gauss_mode=5),               # Fixed9 / Fixed15
+    dict(scaling_mode=0),                                 # ScaleDirect
+    dict(scaling_mode=0, gauss_mode=1), dict(scaling_mode=0, gauss_mode=4), dict(scaling_mode=0, gauss_mode=3),
+    dict(gauss_mode=1, upscale_factor=0.0, sift_mode=1), dict(gauss_mode=2, upscale_factor=-1.0, sift_mode=2),
+]
+
+
+@pytest.mark.parametrize("kw", ALT_PYRAMIDS)
+def test_alternative_pyramid_modes_match_reference(oracle, ref, kw):
+    """Every branch of Pyramid::build_pyramid (s_pyramid_build.cu:478-546) through the reference's own kernels and
+    the oracle: planes bit-identical, same extrema, identical feature sets."""
+    img = synth(96, 72, 5)
+    cfg = oracle.default_config(octaves=3, **kw)
+    r, o = ref.run(cfg, img), oracle.run(cfg, img)
+    assert r.dims == o.dims and r.num_levels == o.num_levels
+    for oc in range(r.num_octaves):
+        for l in range(r.num_levels):
+            assert np.array_equal(r.gauss(oc, l), o.gauss(oc, l)), (oc, l)
+        for l in range(r.num_levels - 1):
+            assert np.array_equal(r.dog(oc, l), o.dog(oc, l)), (oc, l)
+        assert len(r.iext(oc)) == len(o.iext(oc))
+    assert r.ext_total == o.ext_total and r.ori_total == o.ori_total
+    m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors())
+    assert m["kp_miss"] == 0 and m["ori_miss"] == 0 and m["desc_miss"] == 0, m
+
+
+def test_fixed_modes_need_three_levels(oracle, ref):
+    """make_octave only exists for levels = 3 (s_pyramid_fixed.cu:270-292): the reference throws, the oracle refuses."""
+    img = synth(64, 48, 1)
+    cfg = oracle.default_config(octaves=2, gauss_mode=4, levels=4)
+    with pytest.raises(RuntimeError):
+        oracle.run(cfg, img)
+
+
+@pytest.mark.parametrize("desc_mode,name", [(1, "iloop"), (3, "igrid"), (4, "notile")])
+def test_interpolating_descriptor_modes_match_reference(oracle, ref, desc_mode, name):
+    """ext_desc_iloop / igrid / notile: bilinear gradients in the keypoint frame.  Keypoint positions of oracle and
+    reference differ by <= 8e-6 px (contraction choices inside solve), which moves some 1.8 fixed-point bilinear
+    weights by one step: descriptors agree to ~5e-5 (tolerance 1e-3)."""
+    img = synth(120, 90, 17)
+    cfg = oracle.default_config(octaves=3, desc_mode=desc_mode)
+    r, o = ref.run(cfg, img), oracle.run(cfg, img)
+    assert r.ext_total == o.ext_total and r.ori_total == o.ori_total > 40
+    m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors())
+    assert m["kp_miss"] == 0 and m["ori_miss"] == 0 and m["desc_miss"] == 0 and m["max_desc_dist"] < 2e-4, m
+    # and the mode really is a different descriptor than "loop"
+    loop = oracle.run(oracle.default_config(octaves=3), img)
+    assert np.abs(loop.descriptors() - o.descriptors()).max() > 1e-2
+
+
+def test_grid_descriptor_mode_matches_reference(oracle, ref):
+    """ext_desc_grid snaps its 16 x 16 sample points per tile to pixels through  (int)(pt + (round(pt + pix) - pt))
+    (s_desc_grid.cu:72-78): whenever |round(..)| < |pt| / 2 the float sum may land one ulp BELOW the integer and
+    truncate to the neighbouring pixel -- decided by the last bit of pt, i.e. of the keypoint position.  Oracle and
+    reference positions differ in that bit for some keypoints (see above), so a fraction of the descriptors near the
+    image border differs by up to ~0.02; the rest agrees to 1e-5."""
+    img = synth(200, 150, 3)
+    cfg = oracle.default_config(octaves=4, desc_mode=2)
+    r, o = ref.run(cfg, img), oracle.run(cfg, img)
+    assert r.ext_total == o.ext_total and r.ori_total == o.ori_total > 150
+    m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors())
+    assert m["kp_miss"] == 0 and m["ori_miss"] == 0
+    assert m["desc_miss"] <= 0.1 * m["desc_compared"] and m["max_desc_dist"] < 0.05, m
