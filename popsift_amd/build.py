@@ -2,7 +2,9 @@
 
   popsift_amd/lib/libpopsift_hip.so   C-ABI + HIP kernels for gfx950 (hipcc)
   popsift_amd/lib/libpopsift.so       C++14 host library: PopSift / SiftJob / Config / Features (g++)
-  popsift_amd/lib/popsift_demo        small C++ driver over the C++ API (used by tests)
+  popsift_amd/lib/popsift_demo        small C++ driver over the C++ API (raw frames; used by tests)
+  popsift_amd/lib/popsift-demo        the command line extractor (PGM/PPM in, output-features.txt out; reference main.cpp)
+  popsift_amd/lib/popsift-match       the MatchingMode tool (reference match.cpp)
 
 hipcc cross-compiles gfx950 without a GPU.  Objects are cached by source mtime.
 """
@@ -17,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 
-HIP_SOURCES = ["pyramid.hip", "extrema.hip", "orient_desc.hip", "gridfilter.hip", "match.hip", "util.hip", "api.hip"]
+HIP_SOURCES = ["pyramid.hip", "pyramid_alt.hip", "extrema.hip", "orient_desc.hip", "gridfilter.hip", "match.hip", "util.hip", "api.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # no implicit fused multiply-add: the arithmetic order is part of the parity contract
@@ -26,7 +28,7 @@ HIP_FLAGS = [
     "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "hip"),
 ]
 
-HOST_SOURCES = ["popsift.cpp", "sift_conf.cpp", "features.cpp", "device_prop.cpp", "popsift_c.cpp"]
+HOST_SOURCES = ["popsift.cpp", "sift_conf.cpp", "features.cpp", "device_prop.cpp", "popsift_c.cpp", "log_dump.cpp"]
 HOST_FLAGS = ["-O2", "-std=c++14", "-fPIC", "-Wall", "-pthread",
               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "include")]
 
@@ -105,6 +107,13 @@ def build_host(verbose=False):
     if os.path.exists(demo_src) and (_newer(demo, [demo_src, so] + hdrs)):
         _run(["g++"] + HOST_FLAGS + [demo_src, "-o", demo, "-L", LIBDIR, "-lpopsift", "-lpopsift_hip",
                                       "-Wl,-rpath,$ORIGIN"])
+    # command line tools with the reference's option surface (src/application/main.cpp, match.cpp)
+    appdir = os.path.join(hostdir, "app")
+    for exe, srcs in (("popsift-demo", ["main.cpp", "pgmread.cpp"]), ("popsift-match", ["match.cpp", "pgmread.cpp"])):
+        paths = [os.path.join(appdir, f) for f in srcs]
+        out = os.path.join(LIBDIR, exe)
+        if all(os.path.exists(f) for f in paths) and _newer(out, paths + [so, os.path.join(appdir, "options.h")] + hdrs):
+            _run(["g++"] + HOST_FLAGS + paths + ["-o", out, "-L", LIBDIR, "-lpopsift", "-lpopsift_hip", "-Wl,-rpath,$ORIGIN"])
     return so
 
 

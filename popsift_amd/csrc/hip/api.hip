@@ -82,6 +82,13 @@ struct psx_ctx {
     float dd_filter[PSX_MAX_OCTAVES * PSX_GAUSS_ALIGN];
     int   dd_span[PSX_MAX_OCTAVES];
     float dd_sigma[PSX_MAX_OCTAVES];
+    // tables of the alternative pyramid modes (gauss_filter.cu:188-214, 373-410)
+    float abs0_filter[PSX_GAUSS_LEVELS * PSX_GAUSS_ALIGN]; int abs0_span[PSX_GAUSS_LEVELS];
+    float absN_filter[PSX_GAUSS_LEVELS * PSX_GAUSS_ALIGN]; int absN_span[PSX_GAUSS_LEVELS];
+    float inc_ifilter[PSX_GAUSS_LEVELS * PSX_GAUSS_ALIGN]; int inc_ispan[PSX_GAUSS_LEVELS];
+    bool  alt_pyramid = false;         // any branch of build_pyramid other than the default one
+    float* d_intm = nullptr;           size_t intm_cap = 0;     // scratch planes of the alternative branches
+    float* d_vbuf = nullptr;           size_t vbuf_cap = 0;
 
     int in_w = 0, in_h = 0;
     int octaves_resolved = -1;         // sticky auto-octave value (popsift.cpp:118-122)
@@ -201,6 +208,37 @@ int compute_tables(const psx_config* cfg, float* inc_filter, int* inc_span, floa
     return PSX_OK;
 }
 
+// abs_o0, abs_oN and the interpolated (ratio, multiplier) form of the inc table
+void compute_alt_tables(psx_ctx* n)
+{
+    const psx_config& c = n->cfg;
+    const float sigma0 = c.sigma;
+    const int levels = c.levels, stages = levels + 3;
+    const float initial_blur = c.assume_initial_blur ? c.initial_blur * powf(2.0f, c.upscale_factor) : 0.0f;
+    float s0[PSX_GAUSS_LEVELS] = {0}, sN[PSX_GAUSS_LEVELS] = {0};
+    for (int lvl = 0; lvl < stages; lvl++) {
+        const float sigmaS = sigma0 * powf(2.0f, (float)(lvl) / (float)levels);
+        s0[lvl] = sqrtf(fabsf(sigmaS * sigmaS - initial_blur * initial_blur));
+        if (lvl > 0) sN[lvl] = sqrtf(sigmaS * sigmaS - sigma0 * sigma0);
+    }
+    blur_table(c.gauss_mode, PSX_GAUSS_LEVELS, s0, n->abs0_span, n->abs0_filter);
+    blur_table(c.gauss_mode, PSX_GAUSS_LEVELS, sN, n->absN_span, n->absN_filter);
+    for (int level = 0; level < PSX_GAUSS_LEVELS; level++) {       // GaussTable::transformBlurTable
+        int isp = n->inc_span[level];
+        if (!(isp & 1)) isp += 1;
+        n->inc_ispan[level] = isp;
+        const float* f = n->inc_filter + level * PSX_GAUSS_ALIGN;
+        float* fi = n->inc_ifilter + level * PSX_GAUSS_ALIGN;
+        for (int x = 0; x < PSX_GAUSS_ALIGN; x++) fi[x] = 0.0f;
+        for (int x = 1; x < isp; x += 2) {
+            const float a = f[x], b = f[x + 1];
+            fi[x] = a / (a + b);
+            fi[x + 1] = a + b;
+        }
+        fi[0] = f[0];
+    }
+}
+
 PsxTaps taps_from(const float* row)
 {
     PsxTaps t;
@@ -268,13 +306,15 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     *out = nullptr;
     psx_config c = *cfg;
     c.levels = imax(2, c.levels);                      // popsift.cpp:86
-    // branches of build_pyramid outside the default one, and descriptor modes other than loop
-    if (c.gauss_mode != PSX_GAUSS_VLFEAT_COMPUTE && c.gauss_mode != PSX_GAUSS_OPENCV_COMPUTE)
-        return fail(nullptr, PSX_ERR_INVALID, "gauss mode not supported by the HIP path (only vlfeat, opencv)");
-    if (c.scaling_mode != PSX_SCALE_DEFAULT)
-        return fail(nullptr, PSX_ERR_INVALID, "scaling mode ScaleDirect not supported by the HIP path");
-    if (c.desc_mode != PSX_DESC_LOOP)
+    if (c.gauss_mode < PSX_GAUSS_VLFEAT_COMPUTE || c.gauss_mode > PSX_GAUSS_FIXED15)
+        return fail(nullptr, PSX_ERR_INVALID, "ERROR: The mode for computing Gauss filter scan is invalid");   // gauss_filter.cu:292-296
+    if (c.scaling_mode != PSX_SCALE_DEFAULT && c.scaling_mode != PSX_SCALE_DIRECT)
+        return fail(nullptr, PSX_ERR_INVALID, "invalid scaling mode");
+    if (c.desc_mode < PSX_DESC_LOOP || c.desc_mode > PSX_DESC_NOTILE)
         return fail(nullptr, PSX_ERR_INVALID, "not yet");   // sift_desc.cu:80-82
+    // make_octave exists for levels = 3 only (s_pyramid_fixed.cu:270-292)
+    if ((c.gauss_mode == PSX_GAUSS_FIXED9 || c.gauss_mode == PSX_GAUSS_FIXED15) && c.levels != 3)
+        return fail(nullptr, PSX_ERR_INVALID, "Unsupported number of levels for making all octaves at once");
     if (c.sift_mode != PSX_MODE_POPSIFT && c.sift_mode != PSX_MODE_OPENCV && c.sift_mode != PSX_MODE_VLFEAT)
         return fail(nullptr, PSX_ERR_INVALID, "invalid sift mode");
     if (c.max_extrema <= 0 || c.filter_grid_size <= 0)
@@ -297,6 +337,9 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     int rc = compute_tables(&n->cfg, n->inc_filter, n->inc_span, n->inc_sigma, n->dd_filter, n->dd_span,
                             n->dd_sigma, &why);
     if (rc != PSX_OK) { delete n; return fail(nullptr, rc, why); }
+    compute_alt_tables(n);
+    n->alt_pyramid = !(c.scaling_mode == PSX_SCALE_DEFAULT &&
+                       (c.gauss_mode == PSX_GAUSS_VLFEAT_COMPUTE || c.gauss_mode == PSX_GAUSS_OPENCV_COMPUTE));
     ctx = nullptr;
 #define PSX_HIPC(call)                                                                          \
     do {                                                                                        \
@@ -335,6 +378,7 @@ int psx_destroy(psx_ctx* ctx)
     if (ctx->x_registered_desc) (void)hipHostUnregister(ctx->x_host_desc);
     if (ctx->h_xcnt) (void)hipHostFree(ctx->h_xcnt);
     (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr); (void)hipFree(ctx->d_up);
+    (void)hipFree(ctx->d_intm); (void)hipFree(ctx->d_vbuf);
     (void)hipFree(ctx->d_gf_keys); (void)hipFree(ctx->d_gf_vals); (void)hipFree(ctx->d_gf_temp);
     (void)hipFree(ctx->d_gf_scratch);
     (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off); (void)hipFree(ctx->d_cand); (void)hipFree(ctx->d_cand_ct);
@@ -417,6 +461,10 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     ctx->up_pitch = ((P.oct[0].w + 63) / 64) * 64 + 2 * PSX_LEVEL0_PAD;
     if ((rc = grow(ctx, &ctx->d_up, &ctx->up_cap, (size_t)ctx->up_pitch * P.oct[0].h)) != PSX_OK) return rc;
     for (int o = 0; o < P.num_octaves; o++) P.oct[o].data = ctx->d_pyr + offs[o];
+    if (ctx->alt_pyramid) {
+        if ((rc = grow(ctx, &ctx->d_intm, &ctx->intm_cap, P.oct[0].plane + 64)) != PSX_OK) return rc;
+        if ((rc = grow(ctx, &ctx->d_vbuf, &ctx->vbuf_cap, (size_t)(P.oct[0].pitch + 64) * P.oct[0].h)) != PSX_OK) return rc;
+    }
 
     // Extrema buffers are sized for the worst case (max_extrema per octave, 100 B per entry); the descriptor
     // buffers start at the reference's size, max(2 max_extrema, 1.25 max_extrema) entries of 512 B
@@ -549,6 +597,30 @@ int psx_build_pyramid(psx_ctx* ctx)
     PSX_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(PsxCounters), ctx->stream));
     PSX_HIP(hipMemsetAsync(ctx->d_cand_ct, 0, sizeof(int) * (size_t)P.num_octaves * PSX_CAND_SUB * 32, ctx->stream));
 
+    if (ctx->alt_pyramid) {
+        PsxAltArgs q;
+        q.hp = &ctx->hp;
+        q.img = ctx->d_input; q.w = ctx->in_w; q.h = ctx->in_h; q.is_float = ctx->input_is_float;
+        q.gauss_mode = c.gauss_mode; q.scaling_mode = c.scaling_mode; q.sift_mode = c.sift_mode;
+        q.upscale_factor = c.upscale_factor;
+        q.inc_filter = ctx->inc_filter; q.inc_ifilter = ctx->inc_ifilter; q.dd_filter = ctx->dd_filter;
+        q.abs0_filter = ctx->abs0_filter; q.absN_filter = ctx->absN_filter;
+        q.inc_span = ctx->inc_span; q.inc_ispan = ctx->inc_ispan; q.dd_span = ctx->dd_span; q.abs0_span = ctx->abs0_span;
+        q.intm = ctx->d_intm; q.vbuf = ctx->d_vbuf; q.vbuf_pitch = P.oct[0].pitch + 64;
+        q.user = ctx;
+        q.after_octave = ctx->interleave ? +[](void* u, int o) -> hipError_t {
+            psx_ctx* cx = static_cast<psx_ctx*>(u);
+            return psx_launch_extrema(cx->d_params, cx->hp, cx->d_cnt, o, cx->stream);
+        } : nullptr;
+        ctx->ext_launched = false;
+        const hipError_t e = psx_launch_pyramid_alt(q, ctx->stream);
+        if (e == hipErrorInvalidValue) return fail(ctx, PSX_ERR_INVALID, "Unsupported number of levels for making all octaves at once");
+        PSX_HIP(e);
+        ctx->ext_launched = ctx->interleave;
+        if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        return PSX_OK;
+    }
+
     PsxLevel0Args a;
     a.img = ctx->d_input; a.w = ctx->in_w; a.h = ctx->in_h; a.is_float = ctx->input_is_float;
     a.dst = P.oct[0].data; a.W = P.oct[0].w; a.H = P.oct[0].h; a.pitch = P.oct[0].pitch;
@@ -653,7 +725,10 @@ int psx_descriptors(psx_ctx* ctx)
     if (!ctx) return PSX_ERR_INVALID;
     if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_descriptors: no pyramid");
     PSX_HIP(hipSetDevice(ctx->device));
-    PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->hp.x_desc != nullptr, ctx->stream));
+    if (ctx->cfg.desc_mode == PSX_DESC_LOOP)
+        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->hp.x_desc != nullptr, ctx->stream));
+    else
+        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, ctx->stream));
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     return PSX_OK;
 }
@@ -754,7 +829,10 @@ static int regrow_descriptors(psx_ctx* ctx, int ori_raw)
     PSX_HIP(hipMemcpyAsync(ctx->d_params, ctx->h_params_pin, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->graph) { (void)hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, ctx->stream));
-    PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->hp.x_desc != nullptr, ctx->stream));
+    if (ctx->cfg.desc_mode == PSX_DESC_LOOP)
+        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->hp.x_desc != nullptr, ctx->stream));
+    else
+        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, ctx->stream));
     return PSX_OK;
 }
 

@@ -403,6 +403,29 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
     }
 }
 
+// normalize_histogram (s_desc_norm_rs.h:42-77 / s_desc_norm_l2.h:86-135); the lane owns bins 2*lane, 2*lane+1 of
+// descriptor j and stores them (device array and, when attached, the zero-copy export)
+__device__ __forceinline__ void normalize_store(const PsxParams* P, int j, int lane, float a, float b)
+{
+    if (P->norm_mode == PSX_NORM_ROOTSIFT) {
+        const float sum = wave_sum(a + b);
+        a = ldexpf(sqrtf(a / sum), P->norm_multi);
+        b = ldexpf(sqrtf(b / sum), P->norm_multi);
+    } else {
+        float norm = sqrtf(wave_sum(a * a + b * b));
+        a = fminf(a, 0.2f * norm);
+        b = fminf(b, 0.2f * norm);
+        norm = wave_sum(a * a + b * b);
+        norm = 1.0f / sqrtf(norm);
+        norm = ldexpf(norm, P->norm_multi);
+        a = a * norm;
+        b = b * norm;
+    }
+    reinterpret_cast<float2*>(P->desc + (size_t)j * 128)[lane] = make_float2(a, b);
+    if (P->x_desc != nullptr && j < P->x_desc_capacity)
+        reinterpret_cast<float2*>(P->x_desc + (size_t)j * 128)[lane] = make_float2(a, b);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Descriptor ("loop" mode) + normalisation + Feature record
 //
@@ -555,24 +578,261 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
             sa += acc[c * DSTRIDE + rbin];
             sb += acc[c * DSTRIDE + rbin + 1];
         }
-        float a = (float)sa * (1.0f / DFIX), b = (float)sb * (1.0f / DFIX);
-        if (P->norm_mode == PSX_NORM_ROOTSIFT) {
-            const float sum = wave_sum(a + b);
-            a = ldexpf(sqrtf(a / sum), P->norm_multi);
-            b = ldexpf(sqrtf(b / sum), P->norm_multi);
-        } else {
-            float norm = sqrtf(wave_sum(a * a + b * b));
-            a = fminf(a, 0.2f * norm);
-            b = fminf(b, 0.2f * norm);
-            norm = wave_sum(a * a + b * b);
-            norm = 1.0f / sqrtf(norm);
-            norm = ldexpf(norm, P->norm_multi);
-            a = a * norm;
-            b = b * norm;
+        normalize_store(P, j, lane, (float)sa * (1.0f / DFIX), (float)sb * (1.0f / DFIX));
+        wave_fence();
+    }
+}
+
+// ConstInfo::desc_gauss[40][40] / desc_tile[16] (sift_constants.cu:34-47), evaluated on demand with the same
+// float operations instead of a __constant__ table
+__device__ __forceinline__ float desc_gauss_entry(int yy, int xx)
+{
+    const float dn_step = 1.0f / 8.0f;
+    const float dn_base = 0.5f * dn_step - 20.0f * dn_step;
+    const float dnx = dn_base + xx * dn_step;
+    const float dny = dn_base + yy * dn_step;
+    return expf(-ldexpf(dnx * dnx + dny * dny, -3));
+}
+__device__ __forceinline__ float desc_tile_entry(int i)
+{
+    const float nx = -1.0f + 1.0f / 16.0f + i * 1.0f / 8.0f;
+    return 1.0f - fabsf(nx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Alternative descriptor modes: iloop, grid, igrid, notile (s_desc_iloop.cu, s_desc_grid.cu, s_desc_igrid.cu,
+// s_desc_notile.cu).  Each samples the window differently and therefore yields a DIFFERENT descriptor than
+// "loop"; they exist for API completeness of Config::setDescMode and follow the CPU restatement
+// (oracle/sift_oracle.c descriptor_iloop / _grid / _igrid / _notile) operation by operation.  One wave64 per
+// descriptor; the reference's 32- / 16- / 8-lane groups (one tile each) sit side by side in the wave: 2, 4 or
+// 8 tiles per pass.  Every lane accumulates into its own 8 (+1 wrap) bins -- a private LDS column, no atomics
+// -- and the groups are then reduced with the reference's shuffle trees.  Gradients come from a software
+// model of the linear-filtered layered texture (1.8 fixed-point weights), as in pyramid_alt.hip.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float d_lerp(float p, float q, float a) { return fmaf(a, q, (1.0f - a) * p); }
+__device__ __forceinline__ float d_plane_linear(const float* p, int W, int H, int pitch, float x, float y)
+{
+    const float xs = x + 0.5f, ys = y + 0.5f;
+    const float xb = xs - 0.5f, yb = ys - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    const float a = rintf((xb - fx) * 256.0f) * (1.0f / 256.0f);
+    const float b = rintf((yb - fy) * 256.0f) * (1.0f / 256.0f);
+    const int i = (int)fx, jj = (int)fy;
+    const int i0 = psx_clampi(i, 0, W - 1), i1 = psx_clampi(i + 1, 0, W - 1);
+    const int j0 = psx_clampi(jj, 0, H - 1), j1 = psx_clampi(jj + 1, 0, H - 1);
+    const float r0 = d_lerp(p[(size_t)j0 * pitch + i0], p[(size_t)j0 * pitch + i1], a);
+    const float r1 = d_lerp(p[(size_t)j1 * pitch + i0], p[(size_t)j1 * pitch + i1], a);
+    return d_lerp(r0, r1, b);
+}
+// get_gradiant with the rotated stencil on the linear texture (s_gradiant.h:72-88)
+__device__ __forceinline__ void d_gradiant_rot(float& grad, float& theta, float x, float y, float cos_t, float sin_t,
+                                               const float* plane, int W, int H, int pitch)
+{
+    const float dx = d_plane_linear(plane, W, H, pitch, x + cos_t, y + sin_t) - d_plane_linear(plane, W, H, pitch, x - cos_t, y - sin_t);
+    const float dy = d_plane_linear(plane, W, H, pitch, x - sin_t, y + cos_t) - d_plane_linear(plane, W, H, pitch, x + sin_t, y - cos_t);
+    grad = hypotf(dx, dy);
+    theta = atan2f(dy, dx);
+}
+// get_gradiant on the point texture at integer coordinates (s_gradiant.h:56-69)
+__device__ __forceinline__ void d_gradiant_pt(float& grad, float& theta, int x, int y, const float* plane, int W, int H, int pitch)
+{
+    auto rd = [&](int xx, int yy) { return plane[(size_t)psx_clampi(yy, 0, H - 1) * pitch + psx_clampi(xx, 0, W - 1)]; };
+    const float dx = rd(x + 1, y) - rd(x - 1, y);
+    const float dy = rd(x, y + 1) - rd(x, y - 1);
+    grad = hypotf(dx, dy);
+    theta = atan2f(dy, dx);
+}
+
+constexpr int ALT_BINS = 9;
+// one contribution into the lane's private bins (column `lane` of a [9][64] block)
+__device__ __forceinline__ void alt_add(float* bins, int lane, int b, float v) { bins[b * PSX_WAVE + lane] += v; }
+
+template <int MODE>
+__global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restrict__ P, const PsxCounters* cnt)
+{
+    __shared__ float s_bins[WPB][ALT_BINS * PSX_WAVE];
+    __shared__ float s_out[WPB][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* bins = s_bins[wave];
+    float* out = s_out[wave];
+
+    const int total = cnt->ori_total;
+    const int nwaves = gridDim.x * WPB;
+    for (int jv = blockIdx.x * WPB + wave; jv < total; jv += nwaves) {
+        const int j = __builtin_amdgcn_readfirstlane(jv);
+        const int ext_idx = P->feat_to_ext[j];
+        const psx_extremum ex = P->extrema[ext_idx];
+        const int ori_num = psx_clampi(j - ex.idx_ori, 0, PSX_ORI_MAX - 1);
+        const float ang = ex.orientation[ori_num];
+        const PsxOctave oc = P->oct[ex.octave];
+        const int W = oc.w, H = oc.h, pitch = oc.pitch;
+        if (ori_num == 0 && lane == 0) write_feature(P, ext_idx, ex, ex.idx_ori, total);
+
+        const float x = ex.xpos, y = ex.ypos;
+        const float* plane = oc.data + (size_t)psx_clampi(ex.lpos, 0, P->L - 1) * oc.plane;
+        const float SBP = fabsf(DESC_MAGNIFY * ex.sigma);
+        for (int i = lane; i < 128; i += PSX_WAVE) out[i] = 0.0f;
+        wave_fence();
+
+        if (SBP != 0.0f) {
+            const float cos_t = cosf(ang), sin_t = sinf(ang);      // __sincosf
+            const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+
+            if (MODE == PSX_DESC_ILOOP) {
+                // 32 lanes per tile, lane = j of the 32 x 32 sample grid, 2 tiles per pass
+                const int sub = lane & 31, half = lane >> 5;
+                for (int pass = 0; pass < 8; pass++) {
+                    const int tz = pass * 2 + half;
+                    const int ix = tz & 3, iy = tz >> 2;
+                    const float offx = ix - 1.5f, offy = iy - 1.5f;
+                    const float ptx = fmaf(csbp, offx, -ssbp * offy);
+                    const float pty = fmaf(csbp, offy,  ssbp * offx);
+                    const float bsz = fabsf(cos_t) + fabsf(sin_t);
+#pragma unroll
+                    for (int b = 0; b < ALT_BINS; b++) bins[b * PSX_WAVE + lane] = 0.0f;
+                    for (int i = 0; i < 32; i++) {
+                        const float dx = (-bsz + sub * bsz / 16.0f);
+                        const float dy = (-bsz + i * bsz / 16.0f);
+                        const float nx = fmaf(cos_t, dx,  sin_t * dy);
+                        const float ny = fmaf(cos_t, dy, -sin_t * dx);
+                        const float nnx = fabsf(nx), nny = fabsf(ny);
+                        if (nnx < 1.0f && nny < 1.0f) {
+                            const float jj = x + ptx + dx * SBP;
+                            const float ii = y + pty + dy * SBP;
+                            float mod, th;
+                            d_gradiant_rot(mod, th, jj, ii, cos_t, sin_t, plane, W, H, pitch);
+                            const float dnx = nx + offx, dny = ny + offy;
+                            const float ww = expf(-ldexpf(dnx * dnx + dny * dny, -3));
+                            const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod;
+                            th += (th <  0.0f  ? PI2_F : 0.0f);
+                            th -= (th >= PI2_F ? PI2_F : 0.0f);
+                            const float tth = th * M_4RPI_F;
+                            const int   fo0 = (int)floorf(tth);
+                            const float do0 = tth - fo0;
+                            const int   fo  = fo0 % 8;
+                            alt_add(bins, lane, fo, (1.0f - do0) * wgt);
+                            alt_add(bins, lane, fo + 1, do0 * wgt);
+                        }
+                    }
+                    bins[lane] += bins[8 * PSX_WAVE + lane];                 // dpt[0] += dpt[8]
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        float v = bins[b * PSX_WAVE + lane];
+#pragma unroll
+                        for (int d = 16; d >= 1; d >>= 1) v += __shfl_down(v, d, 32);
+                        if (sub == 0) out[tz * 8 + b] = v;
+                    }
+                }
+            } else if (MODE == PSX_DESC_GRID || MODE == PSX_DESC_IGRID) {
+                // 16 lanes per tile (lane = xd), 4 tiles per pass, 16 samples (yd) per lane
+                const int xd = lane & 15, q = lane >> 4;
+                for (int pass = 0; pass < 4; pass++) {
+                    const int tz = pass * 4 + q;
+                    const int ix = tz & 3, iy = tz >> 2;
+                    const float offx = ix - 1.5f, offy = iy - 1.5f;
+#pragma unroll
+                    for (int b = 0; b < ALT_BINS; b++) bins[b * PSX_WAVE + lane] = 0.0f;
+                    if (MODE == PSX_DESC_GRID) {
+                        const float ptx = fmaf(csbp, offx, fmaf(-ssbp, offy, x));
+                        const float pty = fmaf(csbp, offy, fmaf( ssbp, offx, y));
+                        const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t;
+                        const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;
+                        const float usx = -sin_t / 8.0f, usy = cos_t / 8.0f;
+                        for (int yd = 0; yd < 16; yd++) {
+                            float pox = fmaf(yd + 0.5f, usx, fmaf(xd + 0.5f, rsx, ldx));
+                            float poy = fmaf(yd + 0.5f, usy, fmaf(xd + 0.5f, rsy, ldy));
+                            const float pix_x = roundf(fmaf(pox, SBP, ptx)) - ptx;
+                            const float pix_y = roundf(fmaf(poy, SBP, pty)) - pty;
+                            pox = pix_x / SBP; poy = pix_y / SBP;
+                            float mod, th;
+                            d_gradiant_pt(mod, th, (int)(ptx + pix_x), (int)(pty + pix_y), plane, W, H, pitch);
+                            const float npx = fmaf(cos_t, pox,  sin_t * poy);
+                            const float npy = fmaf(cos_t, poy, -sin_t * pox);
+                            const float dnx = npx + offx, dny = npy + offy;
+                            const float ww = expf(-ldexpf(dnx * dnx + dny * dny, -3));
+                            const float wx = 1.0f - fabsf(npx), wy = 1.0f - fabsf(npy);
+                            if (wx < 0.0f || wy < 0.0f) continue;
+                            const float wgt = ww * wx * wy * mod;
+                            th -= ang;
+                            th += (th <  0.0f  ? PI2_F : 0.0f);
+                            th -= (th >= PI2_F ? PI2_F : 0.0f);
+                            const float tth = th * M_4RPI_F;
+                            const int   fo0 = (int)floorf(tth);
+                            const float do0 = tth - fo0;
+                            const int   fo  = fo0 % 8;
+                            alt_add(bins, lane, fo, (1.0f - do0) * wgt);
+                            alt_add(bins, lane, fo + 1, do0 * wgt);
+                        }
+                        bins[lane] += bins[8 * PSX_WAVE + lane];
+                    } else {
+                        for (int yd = 0; yd < 16; yd++) {
+                            const float stepx = ix - 2.5f + 1.0f / 16.0f + xd / 8.0f;
+                            const float stepy = iy - 2.5f + 1.0f / 16.0f + yd / 8.0f;
+                            const float ptx = fmaf(cos_t, stepx, -sin_t * stepy);
+                            const float pty = fmaf(cos_t, stepy,  sin_t * stepx);
+                            float mod, th;
+                            d_gradiant_rot(mod, th, fmaf(ptx, SBP, x), fmaf(pty, SBP, y), cos_t, sin_t, plane, W, H, pitch);
+                            th += (th <  0.0f  ? PI2_F : 0.0f);
+                            th -= (th >= PI2_F ? PI2_F : 0.0f);
+                            const float ww = desc_gauss_entry(iy * 8 + yd, ix * 8 + xd);
+                            const float wgt = ww * desc_tile_entry(xd) * desc_tile_entry(yd) * mod;
+                            const float tth = th * M_4RPI_F;
+                            const int   fo  = (int)floorf(tth);
+                            const float do0 = tth - fo;
+                            alt_add(bins, lane, (fo + 1) & 7, wgt * do0);
+                            alt_add(bins, lane, fo & 7, wgt * (1.0f - do0));
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        float v = bins[b * PSX_WAVE + lane];
+#pragma unroll
+                        for (int d = 8; d >= 1; d >>= 1) v += __shfl_down(v, d, 16);
+                        if (xd == 0) out[tz * 8 + b] = v;
+                    }
+                }
+            } else {
+                // notile: threads (tx 0..31, ty 0..3) of the reference = 2 passes of a wave64
+                const int tx = lane & 31, in_x = tx & 7;
+                const float stepbase = -2.5f + 1.0f / 16.0f;
+                for (int pass = 0; pass < 2; pass++) {
+                    const int out_y = pass * 2 + (lane >> 5);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) bins[b * PSX_WAVE + lane] = 0.0f;
+                    for (int xoff = 0; xoff < 2; xoff++) {
+                        const int xd = (xoff << 3) + in_x;
+                        const int newx = (xoff << 3) + tx;
+                        for (int yd = 0; yd < 16; yd++) {
+                            const int newy = (out_y << 3) + yd;
+                            const float wgt = desc_tile_entry(xd) * desc_tile_entry(yd);
+                            const float stepx = stepbase + ldexpf((float)newx, -3);
+                            const float stepy = stepbase + ldexpf((float)newy, -3);
+                            const float ptx = fmaf(cos_t, stepx, -sin_t * stepy);
+                            const float pty = fmaf(cos_t, stepy,  sin_t * stepx);
+                            float mod, th;
+                            d_gradiant_rot(mod, th, fmaf(ptx, SBP, x), fmaf(pty, SBP, y), cos_t, sin_t, plane, W, H, pitch);
+                            th += (th < 0.0f ? PI2_F : 0.0f);
+                            const float tth = th * M_4RPI_F;
+                            const int   fo  = (int)floorf(tth);
+                            const float do0 = tth - fo;
+                            const int fo0 = fo & 7, fo1 = (fo0 + 1) & 7;
+                            const float ww = desc_gauss_entry(newy, newx) * mod;
+                            alt_add(bins, lane, fo0, wgt * ((1.0f - do0) * ww));
+                            alt_add(bins, lane, fo1, wgt * (do0 * ww));
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        float v = bins[b * PSX_WAVE + lane];
+#pragma unroll
+                        for (int d = 4; d >= 1; d >>= 1) v += __shfl_down(v, d, 8);
+                        if (in_x == 0) out[out_y * 32 + (tx >> 3) * 8 + b] = v;
+                    }
+                }
+            }
         }
-        reinterpret_cast<float2*>(P->desc + (size_t)j * 128)[lane] = make_float2(a, b);
-        if (P->x_desc != nullptr && j < P->x_desc_capacity)
-            reinterpret_cast<float2*>(P->x_desc + (size_t)j * 128)[lane] = make_float2(a, b);
+        wave_fence();
+        normalize_store(P, j, lane, out[2 * lane], out[2 * lane + 1]);
         wave_fence();
     }
 }
@@ -588,6 +848,19 @@ hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt,
 hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s)
 {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_NT), 0, s, d_params, d_cnt);
+    return hipGetLastError();
+}
+
+hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, hipStream_t s)
+{
+    const dim3 grid(2048), block(NT);
+    switch (desc_mode) {
+    case PSX_DESC_ILOOP:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_ILOOP>, grid, block, 0, s, d_params, d_cnt); break;
+    case PSX_DESC_GRID:   hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_GRID>, grid, block, 0, s, d_params, d_cnt); break;
+    case PSX_DESC_IGRID:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_IGRID>, grid, block, 0, s, d_params, d_cnt); break;
+    case PSX_DESC_NOTILE: hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_NOTILE>, grid, block, 0, s, d_params, d_cnt); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

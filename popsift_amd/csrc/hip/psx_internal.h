@@ -98,6 +98,20 @@ hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch
                            const PsxTaps& taps, int span,
                            float* half_dst, int half_pitch, hipStream_t s,
                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// every non-default branch of Pyramid::build_pyramid (pyramid_alt.hip)
+struct PsxAltArgs {
+    const PsxParams* hp;
+    const void* img; int w, h, is_float;
+    int gauss_mode, scaling_mode, sift_mode;
+    float upscale_factor;
+    const float *inc_filter, *inc_ifilter, *dd_filter, *abs0_filter, *absN_filter;      // host tables
+    const int *inc_span, *inc_ispan, *dd_span, *abs0_span;
+    float* intm;                 // scratch: one plane of octave 0 (pitch x height)
+    float* vbuf; int vbuf_pitch; // scratch of the fixed-span modes: pitch + 2*7 columns
+    hipError_t (*after_octave)(void* user, int octave);   // e.g. launch the octave's extrema scan
+    void* user;
+};
+hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s);
 hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s);
 hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt,
                               int octave, hipStream_t s);
@@ -114,6 +128,7 @@ hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStr
 hipError_t psx_launch_feature_ptrs(const psx_feature* in, psx_feature_dev* out, int n, float* desc_base, int num_desc,
                                    hipStream_t s);
 hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, bool exporting, hipStream_t s);
+hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, hipStream_t s);
 
 // ---- small device helpers --------------------------------------------------------------------
 __device__ __forceinline__ int psx_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

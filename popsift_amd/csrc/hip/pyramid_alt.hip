@@ -1,0 +1,280 @@
+// pyramid_alt.hip -- the non-default branches of Pyramid::build_pyramid (s_pyramid_build.cu:478-546):
+//   GaussMode VLFeat_Relative      tap pairs through one linear-filtered fetch  (s_pyramid_build_ai.cu:17-69)
+//   GaussMode VLFeat_Relative_All  octave 0: every level straight from the input (s_pyramid_build_ra.cu:92-132,
+//                                  s_pyramid_build_aa.cu:124-186)
+//   GaussMode Fixed9 / Fixed15     9- / 15-tap octaves, levels from level 0     (s_pyramid_fixed.cu:24-298)
+//   ScalingMode ScaleDirect        level 0 of EVERY octave straight from the input (s_pyramid_build_ra.cu:17-55)
+//
+// These modes exist for API completeness of setGaussMode / setScalingMode; each gives a different numerical
+// result and has its own branch in the CPU restatement (oracle/sift_oracle.c build_pyramid), pinned against the
+// reference's own kernels.  They are written for exactness, not for the roofline: one thread per output pixel,
+// separate horizontal / vertical launches through an intermediate plane, the reference's operation order with
+// explicit fmaf (this file is compiled with -ffp-contract=off).  The texture unit the reference relies on
+// (normalised / unnormalised coordinates, clamp addressing, linear filtering with 1.8 fixed-point weights) is
+// software here, as in pyramid.hip.
+#include "psx_internal.h"
+
+namespace {
+
+constexpr int ANT = 256;
+
+struct AltImg { const void* px; int w, h, is_float; };
+
+// ---- the input image as a normalised, clamped, linearly filtered texture (s_image.cu:138-167) ----
+__device__ __forceinline__ float a_texel(const AltImg& t, int i, int j)
+{
+    i = psx_clampi(i, 0, t.w - 1);
+    j = psx_clampi(j, 0, t.h - 1);
+    if (t.is_float) return static_cast<const float*>(t.px)[(size_t)j * t.w + i];
+    return (float)static_cast<const uint8_t*>(t.px)[(size_t)j * t.w + i] / 255.0f;
+}
+__device__ __forceinline__ void a_axis(float cn, int size, int& i0, float& a)
+{
+    const float tb = cn * (float)size - 0.5f;
+    const float fl = floorf(tb);
+    a = rintf((tb - fl) * 256.0f) * (1.0f / 256.0f);       // 1.8 fixed-point filter weight
+    i0 = (int)fl;
+}
+__device__ __forceinline__ float a_lerp(float p, float q, float a) { return fmaf(a, q, (1.0f - a) * p); }
+__device__ __forceinline__ float tex2d_norm(const AltImg& t, float un, float vn)
+{
+    int i0, j0; float a, b;
+    a_axis(un, t.w, i0, a);
+    a_axis(vn, t.h, j0, b);
+    const float r0 = a_lerp(a_texel(t, i0, j0),     a_texel(t, i0 + 1, j0),     a);
+    const float r1 = a_lerp(a_texel(t, i0, j0 + 1), a_texel(t, i0 + 1, j0 + 1), a);
+    return a_lerp(r0, r1, b);
+}
+
+// ---- a Gaussian plane as an unnormalised, clamped, linearly filtered texture; (x, y) are the arguments of
+// readTex (assist.h:68-77), which adds 0.5 ----
+__device__ __forceinline__ float plane_linear(const float* p, int W, int H, int pitch, float x, float y)
+{
+    const float xs = x + 0.5f, ys = y + 0.5f;
+    const float xb = xs - 0.5f, yb = ys - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    const float a = rintf((xb - fx) * 256.0f) * (1.0f / 256.0f);
+    const float b = rintf((yb - fy) * 256.0f) * (1.0f / 256.0f);
+    const int i = (int)fx, j = (int)fy;
+    const int i0 = psx_clampi(i, 0, W - 1), i1 = psx_clampi(i + 1, 0, W - 1);
+    const int j0 = psx_clampi(j, 0, H - 1), j1 = psx_clampi(j + 1, 0, H - 1);
+    const float r0 = a_lerp(p[(size_t)j0 * pitch + i0], p[(size_t)j0 * pitch + i1], a);
+    const float r1 = a_lerp(p[(size_t)j1 * pitch + i0], p[(size_t)j1 * pitch + i1], a);
+    return a_lerp(r0, r1, b);
+}
+
+// normalizedSource::horiz / horiz_level / horiz_all (s_pyramid_build_ra.cu:17-132)
+__global__ __launch_bounds__(ANT) void k_alt_h_input(AltImg t, float* intm, int W, int H, int pitch, PsxTaps f, int span, float shift)
+{
+    const int x = blockIdx.x * ANT + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const float read_x = ((float)x + shift) / W;
+    const float read_y = ((float)y + shift) / H;
+    float out = 0.0f;
+    for (int offset = span; offset > 0; offset--) {
+        const float offrel = (float)offset / W;
+        const float v1 = tex2d_norm(t, read_x - offrel, read_y);
+        const float v2 = tex2d_norm(t, read_x + offrel, read_y);
+        out = fmaf(v1 + v2, f.g[offset], out);
+    }
+    out = fmaf(tex2d_norm(t, read_x, read_y), f.g[0], out);
+    intm[(size_t)y * pitch + x] = out * 255.0f;
+}
+
+// absoluteSource::vert / vert_abs0 (s_pyramid_build_aa.cu:52-122)
+__global__ __launch_bounds__(ANT) void k_alt_v_plain(const float* intm, float* dst, int W, int H, int pitch, PsxTaps f, int span)
+{
+    const int x = blockIdx.x * ANT + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    float out = 0.0f;
+    for (int offset = span; offset > 0; offset--) {
+        const float g = f.g[offset];
+        out = fmaf(intm[(size_t)psx_clampi(y - offset, 0, H - 1) * pitch + x], g, out);
+        out = fmaf(intm[(size_t)psx_clampi(y + offset, 0, H - 1) * pitch + x], g, out);
+    }
+    out = fmaf(intm[(size_t)y * pitch + x], f.g[0], out);
+    dst[(size_t)y * pitch + x] = out;
+}
+
+// absoluteSource::horiz (s_pyramid_build_aa.cu:17-50): centre, the (zero-weight) outermost pair, then inwards
+__global__ __launch_bounds__(ANT) void k_alt_h_plain(const float* src, float* intm, int W, int H, int pitch, PsxTaps f, int span)
+{
+    const int x = blockIdx.x * ANT + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const float* row = src + (size_t)y * pitch;
+    float out = 0.0f;
+    out = fmaf(row[x], f.g[0], out);
+    out = fmaf(row[psx_clampi(x - span, 0, W - 1)] + row[psx_clampi(x + span, 0, W - 1)], f.g[span], out);
+    for (int offset = span - 1; offset > 0; offset--)
+        out = fmaf(row[psx_clampi(x - offset, 0, W - 1)] + row[psx_clampi(x + offset, 0, W - 1)], f.g[offset], out);
+    intm[(size_t)y * pitch + x] = out;
+}
+
+// absoluteSourceInterpolated::horiz / vert (s_pyramid_build_ai.cu:17-69)
+template <bool VERTICAL>
+__global__ __launch_bounds__(ANT) void k_alt_interp(const float* src, float* dst, int W, int H, int pitch, PsxTaps fi, int ispan)
+{
+    const int x = blockIdx.x * ANT + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    float out = 0.0f;
+    for (int offset = 1; offset <= ispan; offset += 2) {
+        const float u = fi.g[offset];
+        const float off = offset + (1.0f - u);
+        float val;
+        if (VERTICAL) val = plane_linear(src, W, H, pitch, (float)x, (float)y - off) + plane_linear(src, W, H, pitch, (float)x, (float)y + off);
+        else          val = plane_linear(src, W, H, pitch, (float)x - off, (float)y) + plane_linear(src, W, H, pitch, (float)x + off, (float)y);
+        out = fmaf(val, fi.g[offset + 1], out);
+    }
+    out = fmaf(plane_linear(src, W, H, pitch, (float)x, (float)y), fi.g[0], out);
+    dst[(size_t)y * pitch + x] = out;
+}
+
+// fixedSpan::relativeTexAddress::octave_fixed_vert (s_pyramid_fixed.cu:123-140): column cx - SHIFT of the vbuf
+__global__ __launch_bounds__(ANT) void k_fixed_v_input(AltImg t, float* vbuf, int W, int H, int vpitch, PsxTaps f, int SHIFT, float tshift)
+{
+    const int cx = blockIdx.x * ANT + threadIdx.x - SHIFT, y = blockIdx.y;
+    if (cx >= W + SHIFT) return;
+    const float mul_w = 1.0f / (float)W, mul_h = 1.0f / (float)H;        // __frcp_rn
+    const float xpos = ((float)cx + tshift) * mul_w;
+    const float ypos = ((float)y + tshift) * mul_h;
+    float val = tex2d_norm(t, xpos, ypos);
+    float fval = val * f.g[0];
+    for (int i = 1; i <= SHIFT; i++) {
+        val  = tex2d_norm(t, xpos, ypos - i * mul_h);
+        val += tex2d_norm(t, xpos, ypos + i * mul_h);
+        fval = fmaf(val, f.g[i], fval);
+    }
+    vbuf[(size_t)y * vpitch + cx + SHIFT] = fval;
+}
+
+// fixedSpan::absoluteTexAddress::octave_fixed_vert (s_pyramid_fixed.cu:51-70)
+__global__ __launch_bounds__(ANT) void k_fixed_v_plane(const float* src, int pitch, float* vbuf, int W, int H, int vpitch, PsxTaps f, int SHIFT)
+{
+    const int cx = blockIdx.x * ANT + threadIdx.x - SHIFT, y = blockIdx.y;
+    if (cx >= W + SHIFT) return;
+    const int xc = psx_clampi(cx, 0, W - 1);
+    float val = src[(size_t)y * pitch + xc];
+    float fval = val * f.g[0];
+    for (int i = 1; i <= SHIFT; i++) {
+        val = src[(size_t)psx_clampi(y - i, 0, H - 1) * pitch + xc] + src[(size_t)psx_clampi(y + i, 0, H - 1) * pitch + xc];
+        fval = fmaf(val, f.g[i], fval);
+    }
+    vbuf[(size_t)y * vpitch + cx + SHIFT] = fval;
+}
+
+// octave_fixed_horiz (s_pyramid_fixed.cu:24-44) as lane N of the warp sees it after shuffle_down(out, SHIFT)
+__global__ __launch_bounds__(ANT) void k_fixed_h(const float* vbuf, int vpitch, float* dst, int W, int H, int pitch, PsxTaps f, int SHIFT, float scale)
+{
+    const int x = blockIdx.x * ANT + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const float* v = vbuf + (size_t)y * vpitch + x + SHIFT;
+    float out = v[0] * f.g[0];
+    for (int i = 1; i <= SHIFT; i++) out = fmaf(v[-i] + v[i], f.g[i], out);
+    dst[(size_t)y * pitch + x] = (scale != 1.0f) ? out * scale : out;
+}
+
+// get_by_2_pick_every_second (s_pyramid_build.cu:50-71)
+__global__ __launch_bounds__(ANT) void k_alt_downscale(const float* src, int sw, int sh, int spitch, float* dst, int W, int H, int pitch)
+{
+    const int x = blockIdx.x * ANT + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    dst[(size_t)y * pitch + x] = src[(size_t)min(y << 1, sh - 1) * spitch + min(x << 1, sw - 1)];
+}
+
+inline dim3 grid_for(int W, int H) { return dim3((W + ANT - 1) / ANT, H); }
+
+} // namespace
+
+// Pyramid::build_pyramid for every mode combination outside the default branch; mirrors build_pyramid() of
+// oracle/sift_oracle.c statement by statement.  Returns hipErrorInvalidValue for Fixed9 / Fixed15 with levels != 3
+// (the reference: POP_FATAL "Unsupported number of levels for making all octaves at once").
+hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
+{
+    const PsxParams& P = *a.hp;
+    const int gm = a.gauss_mode;
+    const bool fixed = (gm == PSX_GAUSS_FIXED9 || gm == PSX_GAUSS_FIXED15);
+    const bool direct = (a.scaling_mode == PSX_SCALE_DIRECT);
+    const int SHIFT = (gm == PSX_GAUSS_FIXED9) ? 4 : 7;
+    if (fixed && P.L != 6) return hipErrorInvalidValue;
+    const AltImg img{a.img, a.w, a.h, a.is_float};
+    auto taps = [](const float* row) { PsxTaps t; for (int i = 0; i < PSX_GAUSS_ALIGN; i++) t.g[i] = row[i]; return t; };
+    auto inc = [&](int l) { return taps(a.inc_filter + l * PSX_GAUSS_ALIGN); };
+    auto inci = [&](int l) { return taps(a.inc_ifilter + l * PSX_GAUSS_ALIGN); };
+    for (int o = 0; o < P.num_octaves; o++) {
+        const PsxOctave& oc = P.oct[o];
+        const int W = oc.w, H = oc.h, pitch = oc.pitch;
+        const dim3 g = grid_for(W, H), b(ANT);
+        auto plane = [&](int l) { return oc.data + (size_t)l * oc.plane; };
+        float shift = 0.5f;
+        if (o == 0 && (a.sift_mode == PSX_MODE_POPSIFT || a.sift_mode == PSX_MODE_VLFEAT))
+            shift = 0.5f * powf(2.0f, a.upscale_factor - o);
+        auto downscale = [&]() {
+            const PsxOctave& po = P.oct[o - 1];
+            hipLaunchKernelGGL(k_alt_downscale, g, b, 0, s, po.data + (size_t)(P.L - 3) * po.plane, po.w, po.h, po.pitch,
+                               plane(0), W, H, pitch);
+        };
+        auto fixed_levels = [&](int first, bool from_input) {
+            const int vpitch = a.vbuf_pitch;
+            const dim3 gv((W + 2 * SHIFT + ANT - 1) / ANT, H);
+            for (int level = first; level < P.L; level++) {
+                const PsxTaps f = taps((from_input ? a.abs0_filter : a.absN_filter) + level * PSX_GAUSS_ALIGN);
+                if (from_input) {
+                    const float tshift = 0.5f * powf(2.0f, a.upscale_factor);
+                    hipLaunchKernelGGL(k_fixed_v_input, gv, b, 0, s, img, a.vbuf, W, H, vpitch, f, SHIFT, tshift);
+                } else {
+                    hipLaunchKernelGGL(k_fixed_v_plane, gv, b, 0, s, plane(0), pitch, a.vbuf, W, H, vpitch, f, SHIFT);
+                }
+                hipLaunchKernelGGL(k_fixed_h, g, b, 0, s, a.vbuf, vpitch, plane(level), W, H, pitch, f, SHIFT, from_input ? 255.0f : 1.0f);
+            }
+        };
+        if (fixed) {
+            if (o == 0) fixed_levels(0, true);
+            else {
+                if (direct) {
+                    hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, taps(a.dd_filter + o * PSX_GAUSS_ALIGN), a.dd_span[o], shift);
+                    hipLaunchKernelGGL(k_alt_v_plain, g, b, 0, s, a.intm, plane(0), W, H, pitch, inc(0), a.inc_span[0]);
+                } else downscale();
+                fixed_levels(1, false);
+            }
+        } else if (direct) {
+            const bool interp = (gm == PSX_GAUSS_VLFEAT_RELATIVE);
+            for (int level = 0; level < P.L; level++) {
+                if (level == 0) hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, taps(a.dd_filter + o * PSX_GAUSS_ALIGN), a.dd_span[o], shift);
+                else if (interp) hipLaunchKernelGGL(k_alt_interp<false>, g, b, 0, s, plane(level - 1), a.intm, W, H, pitch, inci(level), a.inc_ispan[level]);
+                else hipLaunchKernelGGL(k_alt_h_plain, g, b, 0, s, plane(level - 1), a.intm, W, H, pitch, inc(level), a.inc_span[level]);
+                if (interp) hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(level), W, H, pitch, inci(level), a.inc_ispan[level]);
+                else hipLaunchKernelGGL(k_alt_v_plain, g, b, 0, s, a.intm, plane(level), W, H, pitch, inc(level), a.inc_span[level]);
+            }
+        } else if (gm == PSX_GAUSS_VLFEAT_RELATIVE) {
+            for (int level = 0; level < P.L; level++) {
+                if (level == 0) {
+                    if (o == 0) {
+                        hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, taps(a.dd_filter), a.dd_span[0], shift);
+                        hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(0), W, H, pitch, inci(0), a.inc_ispan[0]);
+                    } else downscale();
+                } else {
+                    hipLaunchKernelGGL(k_alt_interp<false>, g, b, 0, s, plane(level - 1), a.intm, W, H, pitch, inci(level), a.inc_ispan[level]);
+                    hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(level), W, H, pitch, inci(level), a.inc_ispan[level]);
+                }
+            }
+        } else if (o == 0 && gm == PSX_GAUSS_VLFEAT_RELATIVE_ALL) {
+            for (int level = 0; level < P.L; level++) {
+                const PsxTaps f = taps(a.abs0_filter + level * PSX_GAUSS_ALIGN);
+                hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, f, a.abs0_span[level], shift);
+                hipLaunchKernelGGL(k_alt_v_plain, g, b, 0, s, a.intm, plane(level), W, H, pitch, f, a.abs0_span[level]);
+            }
+        } else {
+            // the default arithmetic for this octave (VLFeat_Relative_All beyond octave 0): the fused kernels of pyramid.hip
+            if (o == 0) return hipErrorInvalidValue;       // not reached: the default branch is psx_build_pyramid's own
+            downscale();
+            for (int level = 1; level < P.L; level++) {
+                hipError_t e = psx_launch_blur(plane(level - 1), plane(level), W, H, pitch, inc(level), a.inc_span[level], nullptr, 0, s);
+                if (e != hipSuccess) return e;
+            }
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (a.after_octave) { e = a.after_octave(a.user, o); if (e != hipSuccess) return e; }
+    }
+    return hipSuccess;
+}

@@ -13,6 +13,7 @@
 #include "popsift/popsift.h"
 #include "popsift/features.h"
 #include "host_pool.h"
+#include "log_dump.h"
 
 #include "popsift_hip.h"
 
@@ -469,7 +470,14 @@ void PopSift::dispatchLoop( )
             check( s.ctx, psx_extract( s.ctx ), "psx_extract" );
             const double t3 = pnow();
             double tf = 0;
-            if( _proc_mode == popsift::Config::ExtractingMode ) f = collect_host( s, p.want_desc, &tf );
+            if( _proc_mode == popsift::Config::ExtractingMode ) {
+                f = collect_host( s, p.want_desc, &tf );
+                if( _config.getLogMode() == popsift::Config::All ) {      // popsift.cpp:330-338
+                    std::string why;
+                    if( !popsift::log_dump( s.ctx, static_cast<popsift::FeaturesHost*>( f ), _config.getUpscaleFactor(), "pyramid", &why ) )
+                        throw std::runtime_error( "log output failed:\n    " + why );
+                }
+            }
             else                                                f = collect_dev( s, _device );
             const double t4 = pnow();
             t_attach += t1 - t0; t_upload += t2 - t1; t_submit += t3 - t2; t_frame += tf; t_wrap += t4 - t3 - tf; n_done++;

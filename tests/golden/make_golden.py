@@ -36,12 +36,28 @@ CASES = {
                                                              grid_filter_mode=po.FILTER_LARGEST_FIRST)),
     "gridfilter_smallest_g3_160x120": (160, 120, 99, False, dict(octaves=3, filter_max_extrema=57, filter_grid_size=3,
                                                                  grid_filter_mode=po.FILTER_SMALLEST_FIRST)),
+    # BASELINE config 1 at full size: 640x480, 5 octaves, VLFeat mode (a few minutes in the fiber emulation)
+    "config1_vlfeat_640x480": (640, 480, 1000, False, dict(octaves=5, sift_mode=po.MODE_VLFEAT)),
+    # alternative pyramid / descriptor modes, tests/test_gpu_modes.py
+    "mode_relative_120x90": (120, 90, 201, False, dict(octaves=3, gauss_mode=po.GAUSS_VLFEAT_RELATIVE)),
+    "mode_relative_all_120x90": (120, 90, 202, False, dict(octaves=3, gauss_mode=po.GAUSS_VLFEAT_RELATIVE_ALL)),
+    "mode_fixed9_120x90": (120, 90, 203, False, dict(octaves=3, gauss_mode=po.GAUSS_FIXED9)),
+    "mode_fixed15_direct_120x90": (120, 90, 204, True, dict(octaves=3, gauss_mode=po.GAUSS_FIXED15, scaling_mode=po.SCALE_DIRECT)),
+    "mode_direct_relative_120x90": (120, 90, 205, False, dict(octaves=3, gauss_mode=po.GAUSS_VLFEAT_RELATIVE, scaling_mode=po.SCALE_DIRECT)),
+    "mode_iloop_120x90": (120, 90, 206, False, dict(octaves=3, desc_mode=po.DESC_ILOOP)),
+    "mode_grid_120x90": (120, 90, 207, False, dict(octaves=3, desc_mode=po.DESC_GRID)),
+    "mode_igrid_120x90": (120, 90, 208, False, dict(octaves=3, desc_mode=po.DESC_IGRID, norm_mode=po.NORM_CLASSIC, norm_multi=9)),
+    "mode_notile_120x90": (120, 90, 209, False, dict(octaves=3, desc_mode=po.DESC_NOTILE)),
 }
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    only = set(sys.argv[1:])
     for name, (w, h, seed, is_float, kw) in CASES.items():
+        path = os.path.join(out_dir, "ref_%s.npz" % name)
+        if (only and name not in only) or (not only and os.path.exists(path)):
+            continue                                   # existing fixtures are kept byte for byte; name them to redo
         img = synth_float(w, h, seed) if is_float else synth(w, h, seed)
         cfg = po.default_config(**kw)
         r = pr.run(cfg, img)
@@ -60,7 +76,7 @@ def main():
         # the public API path (PopSift::enqueue / SiftJob::get) must agree with the direct drive
         ra = pr.run(cfg, img, api=True)
         assert ra.ext_total == r.ext_total and ra.ori_total == r.ori_total
-        np.savez_compressed(os.path.join(out_dir, "ref_%s.npz" % name), **data)
+        np.savez_compressed(path, **data)
         print(name, "octaves", r.num_octaves, "features", r.ext_total, "descriptors", r.ori_total)
 
 

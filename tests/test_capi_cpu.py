@@ -68,10 +68,16 @@ def test_gauss_table_errors(capi):
         capi.gauss_tables(capi.default_config(levels=10))      # gauss_filter.cu:138-144
 
 
-def test_unsupported_modes_are_rejected_before_touching_a_device(capi):
-    for kw in (dict(desc_mode=capi.DESC_GRID), dict(gauss_mode=capi.GAUSS_FIXED9), dict(scaling_mode=capi.SCALE_DIRECT)):
-        with pytest.raises(capi.PopSiftError):
+def test_invalid_modes_are_rejected_before_touching_a_device(capi):
+    """Enum values outside popsift::Config's, and the one combination the reference itself refuses (Fixed9 / Fixed15
+    need levels = 3, s_pyramid_fixed.cu:270-292), fail in psx_create with the reference's message -- not with a
+    device error."""
+    for kw, msg in ((dict(desc_mode=7), "not yet"), (dict(gauss_mode=9), "Gauss filter"), (dict(scaling_mode=5), "scaling"),
+                    (dict(gauss_mode=capi.GAUSS_FIXED9, levels=4), "Unsupported number of levels"),
+                    (dict(sift_mode=3), "sift mode")):
+        with pytest.raises(capi.PopSiftError) as e:
             capi.Context(capi.default_config(**kw))
+        assert msg in str(e.value), (kw, str(e.value))
 
 
 def test_no_cpu_fallback_without_gpu(capi):

@@ -1,0 +1,136 @@
+"""GPU tests of the command line tools: popsift-demo reads PGM/PPM, writes output-features.txt in
+the reference's format (features.cu:310-330) and, with --log, the dir-octave / dir-dog / dir-desc dumps the reference's
+regression protocol compares (testScripts/testOxfordDataset.sh.in:65-154); popsift-match prints the matcher's lines."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from popsift_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "popsift_amd", "lib", "popsift-demo")
+MATCH = os.path.join(ROOT, "popsift_amd", "lib", "popsift-match")
+
+
+def _write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img.tobytes())
+
+
+def _run(cmd, cwd):
+    p = subprocess.run(cmd, cwd=str(cwd), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return p
+
+
+def _expected_rows(ref):
+    """One row per (keypoint, orientation): x y 1/s^2 0 1/s^2 d0..d127 (Feature::print, features.cu:310-330)."""
+    fa, da = ref.features(), ref.descriptors()
+    rows = []
+    for f in fa:
+        for k in range(f["num_ori"]):
+            s = 1.0 / (float(f["sigma"]) ** 2)
+            rows.append(np.concatenate([[f["xpos"], f["ypos"], s, 0.0, s], da[f["desc_idx"][k]]]))
+    return np.array(rows)
+
+
+def _sorted(rows):
+    return rows[np.lexsort((rows[:, 5], rows[:, 2], rows[:, 1], rows[:, 0]))]
+
+
+def test_demo_writes_reference_feature_format(oracle, tmp_path):
+    img = synth(320, 240, 66)
+    _write_pgm(tmp_path / "in.pgm", img)
+    ref = oracle.run(oracle.default_config(octaves=4, sift_mode=2, norm_multi=9), img)
+    exp = _sorted(_expected_rows(ref))
+    # float descriptors (3 significant digits)
+    p = _run([DEMO, "-i", "in.pgm", "--octaves", "4", "--vlfeat-mode", "--norm-multi=9", "--pgmread-loading"], tmp_path)
+    assert "Number of feature points: %d number of feature descriptors: %d" % (ref.ext_total, ref.ori_total) in p.stderr
+    got = _sorted(np.loadtxt(str(tmp_path / "output-features.txt"), ndmin=2))
+    assert got.shape == exp.shape == (ref.ori_total, 5 + 128)
+    assert np.all(got[:, 3] == 0.0)
+    assert np.abs(got[:, :2] - exp[:, :2]).max() <= 2e-3          # default 6 significant digits of the stream
+    assert np.allclose(got[:, 2], exp[:, 2], rtol=2e-5) and np.array_equal(got[:, 2], got[:, 4])
+    assert np.abs(got[:, 5:] - exp[:, 5:]).max() <= 0.5 + 2e-3 * 512  # setprecision(3) on values up to 512
+    # descriptors rounded to integers
+    _run([DEMO, "--input-file=in.pgm", "--octaves=4", "--vlfeat-mode", "--norm-multi", "9", "--write-as-uchar"], tmp_path)
+    got = _sorted(np.loadtxt(str(tmp_path / "output-features.txt"), ndmin=2))
+    assert np.array_equal(got[:, 5:], np.round(got[:, 5:]))
+    assert np.abs(got[:, 5:] - exp[:, 5:]).max() <= 0.5 + 0.51      # roundf of values within 1e-3 * 512
+    # --dont-write leaves the file alone
+    os.remove(str(tmp_path / "output-features.txt"))
+    _run([DEMO, "-i", "in.pgm", "--octaves", "4", "--dont-write"], tmp_path)
+    assert not os.path.exists(str(tmp_path / "output-features.txt"))
+
+
+def test_demo_float_mode_and_directory_input(oracle, tmp_path):
+    d = tmp_path / "imgs" / "sub"
+    d.mkdir(parents=True)
+    a, b = synth(200, 150, 1), synth(240, 160, 2)
+    _write_pgm(tmp_path / "imgs" / "a.pgm", a)
+    _write_pgm(d / "b.pgm", b)
+    p = _run([DEMO, "-i", "imgs", "--octaves", "3", "--float-mode"], tmp_path)
+    # float mode feeds v / 256 (main.cpp:241-245), not v / 255
+    counts = []
+    for im in (a, b):
+        r = oracle.run(oracle.default_config(octaves=3), (im.astype(np.float32) / np.float32(256.0)).astype(np.float32))
+        counts.append("Number of feature points: %d number of feature descriptors: %d" % (r.ext_total, r.ori_total))
+    assert [l for l in p.stderr.splitlines() if l.startswith("Number of feature points")] == counts
+    assert p.stdout.count("Loading ") == 2
+
+
+def _read_p2(path):
+    tok = open(path).read().split()
+    assert tok[0] == "P2" and tok[3] == "255"
+    w, h = int(tok[1]), int(tok[2])
+    return np.array(tok[4:], dtype=np.int64).reshape(h, w)
+
+
+def _read_dump(path):
+    with open(path, "rb") as f:
+        assert f.readline() == b"floats\n"
+        w, h = (int(v) for v in f.readline().split())
+        return np.frombuffer(f.read(), np.float32).reshape(h, w)
+
+
+def test_demo_log_dumps_match_the_reference_protocol(oracle, tmp_path):
+    """--log: the byte-comparable debug files.  Gaussian planes are bit-identical to the oracle's, so every derived file
+    must be EXACTLY what the reference's writers (write_plane_2d.cu:50-175) produce from the oracle's planes."""
+    img = synth(160, 120, 12)
+    _write_pgm(tmp_path / "in.pgm", img)
+    _run([DEMO, "-i", "in.pgm", "--octaves", "3", "--log"], tmp_path)
+    ref = oracle.run(oracle.default_config(octaves=3), img)
+    for o in range(ref.num_octaves):
+        for l in range(ref.num_levels):
+            g = ref.gauss(o, l)
+            assert np.array_equal(_read_p2(str(tmp_path / "dir-octave" / ("pyramid-o-%d-l-%d.pgm" % (o, l)))), g.astype(np.int64))
+            assert np.array_equal(_read_dump(str(tmp_path / "dir-octave-dump" / ("pyramid-o-%d-l-%d.dump" % (o, l)))), g)
+        for l in range(ref.num_levels - 1):
+            d = ref.dog(o, l)
+            assert np.array_equal(_read_dump(str(tmp_path / "dir-dog-dump" / ("d-pyramid-o-%d-l-%d.dump" % (o, l)))), d)
+            assert np.array_equal(_read_p2(str(tmp_path / "dir-dog-txt" / ("d-pyramid-o-%d-l-%d.txt" % (o, l)))), d.astype(np.int64) + 127)
+            mn, mx = np.float32(d.min()), np.float32(d.max())
+            scaled = ((d - mn) * (np.float32(255.0) / (mx - mn))).astype(np.uint8).astype(np.int64)
+            assert np.array_equal(_read_p2(str(tmp_path / "dir-dog" / ("d-pyramid-o-%d-l-%d.pgm" % (o, l)))), scaled)
+    desc = np.loadtxt(str(tmp_path / "dir-desc" / "desc-pyramid.txt"), ndmin=2)
+    fpt = np.loadtxt(str(tmp_path / "dir-fpt" / "desc-pyramid.txt"), ndmin=2)
+    assert desc.shape == (ref.ori_total, 4 + 128) and fpt.shape == (ref.ori_total, 4)
+    assert np.all((fpt[:, 3] >= 0) & (fpt[:, 3] < 360.0001))
+
+
+def test_match_tool(oracle, tmp_path):
+    base = synth(336, 256, 77)
+    a = np.ascontiguousarray(base[8:248, 8:328])
+    b = np.ascontiguousarray(base[5:245, 3:323])
+    _write_pgm(tmp_path / "l.pgm", a)
+    _write_pgm(tmp_path / "r.pgm", b)
+    p = _run([MATCH, "-l", "l.pgm", "-r", "r.pgm", "--octaves", "3"], tmp_path)
+    ra, rb = oracle.run(oracle.default_config(octaves=3), a), oracle.run(oracle.default_config(octaves=3), b)
+    assert "Number of descriptors: %d" % ra.ori_total in p.stdout and "Number of descriptors: %d" % rb.ori_total in p.stdout
+    lines = [l for l in p.stdout.splitlines() if l.startswith(("accept", "reject"))]
+    assert len(lines) == ra.ori_total
+    assert sum(l.startswith("accept") for l in lines) > 0.3 * len(lines)

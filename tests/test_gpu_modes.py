@@ -1,0 +1,111 @@
+"""GPU parity of the alternative pyramid and descriptor modes: Config::setGaussMode
+(VLFeat_Relative, VLFeat_Relative_All, Fixed9, Fixed15), setScalingMode(ScaleDirect), setDescMode(iloop, grid, igrid,
+notile).  Each mode is a different numerical result with its own oracle branch (pinned against the reference's own
+kernels in tests/test_ref_shim_cpu.py) and its own reference-generated fixture (tests/golden/ref_mode_*.npz)."""
+import numpy as np
+import pytest
+
+from popsift_amd.synth import synth, synth_float
+from tests import golden_util as gu
+from tests.parity import assert_parity, budget, match_features, sort_iext
+
+pytestmark = pytest.mark.gpu
+
+ALT_PYRAMIDS = [
+    dict(gauss_mode=1), dict(gauss_mode=2), dict(gauss_mode=4), dict(gauss_mode=5),
+    dict(scaling_mode=0), dict(scaling_mode=0, gauss_mode=1), dict(scaling_mode=0, gauss_mode=4),
+    dict(scaling_mode=0, gauss_mode=3, sift_mode=1), dict(scaling_mode=0, gauss_mode=2),
+    dict(gauss_mode=1, upscale_factor=0.0, sift_mode=1), dict(gauss_mode=2, upscale_factor=-1.0, sift_mode=2),
+    dict(gauss_mode=1, levels=4, sigma=1.4), dict(gauss_mode=5, upscale_factor=0.0),
+]
+
+
+@pytest.mark.parametrize("kw", ALT_PYRAMIDS)
+def test_alternative_pyramid_modes(oracle, capi, kw):
+    """Planes bit-exact, initial extrema identical, features within the mismatch budget, for every non-default branch
+    of build_pyramid; byte and float input."""
+    for is_float, (w, h) in ((False, (333, 251)), (True, (160, 120))):
+        img = synth_float(w, h, 21) if is_float else synth(w, h, 21)
+        cfg = dict(octaves=4, **kw)
+        ref = oracle.run(oracle.default_config(**cfg), img)
+        ctx = capi.Context(capi.default_config(**cfg))
+        ctx.upload(img)
+        ctx.extract()
+        assert ctx.num_octaves == ref.num_octaves and ctx.num_levels == ref.num_levels
+        for o in range(ref.num_octaves):
+            for l in range(ref.num_levels):
+                g = ctx.dump_plane(capi.PLANE_GAUSS, o, l)
+                assert np.array_equal(g.view(np.uint32), ref.gauss(o, l).view(np.uint32)), \
+                    "%s plane (%d,%d): max abs err %g" % (kw, o, l, np.abs(g - ref.gauss(o, l)).max())
+            a, b = sort_iext(ref.iext(o)), sort_iext(ctx.dump_iext(o))
+            assert len(a) == len(b)
+            for f in ("xpos", "ypos", "lpos"):
+                assert np.array_equal(a[f], b[f]), (kw, o, f)
+        fb, db = ctx.download()
+        assert len(fb) == ref.ext_total
+        if len(fb):
+            assert_parity(match_features(ref.features(), ref.descriptors(), fb, db), what=str(kw), **budget(len(fb)))
+        ctx.close()
+
+
+@pytest.mark.parametrize("desc_mode,name", [(1, "iloop"), (3, "igrid"), (4, "notile")])
+def test_interpolating_descriptor_modes(oracle, capi, desc_mode, name):
+    """iloop / igrid / notile: bilinear gradients in the keypoint frame; descriptors within 1e-3 of the oracle's
+    (both normalisations), and different from "loop"."""
+    img = synth(480, 360, 8)
+    for norm in (dict(), dict(norm_mode=1, norm_multi=9)):
+        cfg = dict(octaves=4, desc_mode=desc_mode, **norm)
+        ref = oracle.run(oracle.default_config(**cfg), img)
+        ctx = capi.Context(capi.default_config(**cfg))
+        ctx.upload(img)
+        ctx.extract()
+        fb, db = ctx.download()
+        assert len(fb) == ref.ext_total > 500
+        m = match_features(ref.features(), ref.descriptors(), fb, db, norm_scale=float(2 ** norm.get("norm_multi", 0)))
+        print(name, {k: v for k, v in m.items() if k != "misses"})
+        assert_parity(m, what=name, **budget(len(fb)))
+        ctx.close()
+    loop = oracle.run(oracle.default_config(octaves=4, norm_mode=1, norm_multi=9), img)
+    assert np.abs(loop.descriptors() - ref.descriptors()).max() > 1.0
+
+
+def test_grid_descriptor_mode(oracle, capi):
+    """grid: sample points are snapped to pixels through (int)(pt + (round(pt + pix) - pt)) (s_desc_grid.cu:72-78); for
+    |round| < |pt|/2 the sum can land one ulp below the integer and truncate to the neighbouring pixel, decided by the
+    last bit of sin / cos of the orientation (ocml on the GPU, glibc in the oracle).  Keypoint positions are bit-equal
+    here, so nearly every descriptor agrees; the few knife-edge ones stay below 0.05."""
+    img = synth(480, 360, 8)
+    cfg = dict(octaves=4, desc_mode=2)
+    ref = oracle.run(oracle.default_config(**cfg), img)
+    ctx = capi.Context(capi.default_config(**cfg))
+    ctx.upload(img)
+    ctx.extract()
+    fb, db = ctx.download()
+    assert len(fb) == ref.ext_total > 500
+    m = match_features(ref.features(), ref.descriptors(), fb, db)
+    print("grid", {k: v for k, v in m.items() if k != "misses"})
+    assert m["kp_miss"] == 0 and m["ori_miss"] <= budget(len(fb))["ori"]
+    assert m["desc_miss"] <= 0.06 * m["desc_compared"] and m["max_desc_dist"] < 0.05, m
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", [n for n in gu.cases() if n.startswith("mode_")])
+def test_alternative_modes_match_reference_golden(capi, name):
+    """HIP path vs fixtures produced by the reference's own kernels for the alternative modes."""
+    g = gu.load(name)
+    ctx = capi.Context(capi.default_config(**g["config"]))
+    ctx.upload(g["image"])
+    ctx.extract()
+    for o in range(ctx.num_octaves):
+        for l in range(ctx.num_levels):
+            assert gu.sha1(ctx.dump_plane(capi.PLANE_GAUSS, o, l)) == g["plane_sha1"]["g_%d_%d" % (o, l)], (o, l)
+    fb, db = ctx.download()
+    fa, da = g["features"], g["descriptors"]
+    assert len(fa) == len(fb) and len(da) == len(db)
+    m = match_features(fa, da, fb, db)
+    print(name, {k: v for k, v in m.items() if k != "misses"})
+    if g["config"].get("desc_mode", 0) == 2:
+        assert m["kp_miss"] == 0 and m["desc_miss"] <= 0.1 * max(1, m["desc_compared"]) and m["max_desc_dist"] < 0.05, m
+    else:
+        assert_parity(m, what=name, **budget(len(fa)))
+    ctx.close()
