@@ -25,6 +25,8 @@
 //     __fdividef/__expf for the descriptor).
 #include "psx_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int NT = 256;
@@ -442,8 +444,15 @@ __device__ __forceinline__ void normalize_store(const PsxParams* P, int j, int l
 // degree-13 odd minimax polynomial for atan (max error 3.3e-7 rad).
 // ---------------------------------------------------------------------------------------------
 
+#ifdef PSX_PHASE_TIMING
+__device__ int g_desc_dbg = 0;
+extern "C" void psx_debug_set_desc_dbg(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_desc_dbg), &v, sizeof(v)); }
+#endif
 __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt)
 {
+#ifdef PSX_PHASE_TIMING
+    const int dbg = g_desc_dbg;      // 1: no LDS atomics (values folded into one add), 2: no gradient loads
+#endif
     // Histogram layout per copy: tiles (iy, ix), iy, ix in -1..4, at index (iy+1)*5 + (ix+1), 8 bins
     // each.  Column 0 and rows 0 / 5 are never read: the trilinear scatter of a pixel near the window
     // border lands there instead of being range-checked (the kernel is VALU bound; the checks cost
@@ -527,10 +536,19 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
                     if (in) {
                         // uniform plane base + 32-bit byte offset: global_load with scalar base
                         const unsigned off = rowoff + (unsigned)jj * 4u;
+#ifdef PSX_PHASE_TIMING
+                        float gxp, gxm, gyp, gym;
+                        if (dbg & 2) { gxp = (float)(off & 255u); gxm = (float)lane; gyp = (float)(off & 63u); gym = 3.0f; }
+                        else {
+                            gxp = *(gfloat_p)(plane + off + 4u); gxm = *(gfloat_p)(plane + off - 4u);
+                            gyp = *(gfloat_p)(plane + (off + pitch4)); gym = *(gfloat_p)(plane + (off - pitch4));
+                        }
+#else
                         const float gxp = *(gfloat_p)(plane + off + 4u);
                         const float gxm = *(gfloat_p)(plane + off - 4u);
                         const float gyp = *(gfloat_p)(plane + (off + pitch4));
                         const float gym = *(gfloat_p)(plane + (off - pitch4));
+#endif
                         const float gdx = gxp - gxm;
                         const float gdy = gyp - gym;
                         const float mod = __builtin_amdgcn_sqrtf(fmaf(gdx, gdx, gdy * gdy));
@@ -559,6 +577,15 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
                         const unsigned tb = myacc + (unsigned)((iy0 + 1) * 5 + (ix0 + 1)) * 32u;
                         unsigned LDS_AS* t0 = (unsigned LDS_AS*)(tb + fo);
                         unsigned LDS_AS* t1 = (unsigned LDS_AS*)(tb + fo1);
+#ifdef PSX_PHASE_TIMING
+                        if (dbg & 1) {
+                            const unsigned sum = (unsigned)fmaf(wgt1, w00, 0.5f) + (unsigned)fmaf(wgt2, w00, 0.5f) + (unsigned)fmaf(wgt1, w01, 0.5f) +
+                                (unsigned)fmaf(wgt2, w01, 0.5f) + (unsigned)fmaf(wgt1, w10, 0.5f) + (unsigned)fmaf(wgt2, w10, 0.5f) +
+                                (unsigned)fmaf(wgt1, w11, 0.5f) + (unsigned)fmaf(wgt2, w11, 0.5f) + (unsigned)(uintptr_t)t0 + (unsigned)(uintptr_t)t1;
+                            if (sum == 0x12345678u) lds_add(t0, sum);
+                            continue;
+                        }
+#endif
                         // tile (iy0, ix0), (iy0, ix0+1), (iy0+1, ix0), (iy0+1, ix0+1): +0, +8, +40, +48 entries
                         lds_add(t0, (unsigned)fmaf(wgt1, w00, 0.5f)); lds_add(t1, (unsigned)fmaf(wgt2, w00, 0.5f));
                         lds_add(t0 + 8, (unsigned)fmaf(wgt1, w01, 0.5f)); lds_add(t1 + 8, (unsigned)fmaf(wgt2, w01, 0.5f));
