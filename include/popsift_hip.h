@@ -161,6 +161,10 @@ int psx_octave_dims(const psx_ctx* ctx, int octave, int* w, int* h);
 int psx_upload_u8(psx_ctx* ctx, const uint8_t* host, int w, int h);
 int psx_upload_f32(psx_ctx* ctx, const float* host, int w, int h);
 
+/* The same for an image that already lies in memory from psx_host_alloc (pinned): no pointer query, no staging
+ * copy; the DMA reads the buffer directly, so it must stay untouched until the extraction has been waited for. */
+int psx_upload_pinned(psx_ctx* ctx, const void* pinned_host, int w, int h, int is_float);
+
 /* Input already resident in HBM (tight w*h plane).  The pointer must stay valid until the
  * extraction that uses it has finished.  No copy is made. */
 int psx_set_input_dev(psx_ctx* ctx, const void* dev_ptr, int w, int h, int is_float);
@@ -214,6 +218,11 @@ int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity,
  * Pass NULL/0 to detach. */
 int psx_attach_export(psx_ctx* ctx, psx_feature* host_features, int feature_capacity,
                       float* host_descriptors, int descriptor_capacity);
+
+/* psx_attach_export for buffers from psx_host_alloc (already pinned and GPU-mapped): no registration and no
+ * pointer queries -- cheap enough to call once per frame when every result keeps its own descriptor buffer. */
+int psx_attach_export_mapped(psx_ctx* ctx, psx_feature* host_features, int feature_capacity,
+                             float* host_descriptors, int descriptor_capacity);
 
 /* Device-resident results (FeaturesDev, features.h:104-122): pointers valid until the next
  * extraction on this context. */

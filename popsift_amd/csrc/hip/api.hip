@@ -154,6 +154,16 @@ struct psx_ctx {
 
 namespace {
 
+PsxExport export_of(const psx_ctx* c)
+{
+    PsxExport x;
+    x.features = c->x_dev_feat; x.desc = c->x_dev_desc;
+    x.counts = (c->x_dev_feat || c->x_dev_desc) ? c->h_xcnt : nullptr;
+    x.feat_capacity = c->x_feat_cap; x.desc_capacity = c->x_desc_cap;
+    return x;
+}
+inline bool exporting(const psx_ctx* c) { return c->x_dev_feat != nullptr || c->x_dev_desc != nullptr; }
+
 int fail(psx_ctx* c, int code, const std::string& msg)
 {
     if (c) c->err = msg; else g_create_error = msg;
@@ -498,11 +508,6 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     P.desc = ctx->d_desc;
     P.feat_to_ext = ctx->d_feat_to_ext;
     P.ext_nori = ctx->d_ext_nori;
-    P.x_features = ctx->x_dev_feat;
-    P.x_desc = ctx->x_dev_desc;
-    P.x_counts = ctx->x_dev_feat || ctx->x_dev_desc ? ctx->h_xcnt : nullptr;
-    P.x_feat_capacity = ctx->x_feat_cap;
-    P.x_desc_capacity = ctx->x_desc_cap;
 
     PSX_HIP(hipMemcpy(ctx->d_params, &P, sizeof(P), hipMemcpyHostToDevice));
     ctx->in_w = w; ctx->in_h = h;
@@ -520,7 +525,7 @@ int psx_octave_dims(const psx_ctx* ctx, int o, int* w, int* h)
     return PSX_OK;
 }
 
-static int upload_common(psx_ctx* ctx, const void* host, int w, int h, int is_float)
+static int upload_common(psx_ctx* ctx, const void* host, int w, int h, int is_float, bool known_pinned = false)
 {
     if (!ctx || !host) return PSX_ERR_INVALID;
     int rc = psx_resize(ctx, w, h);
@@ -536,7 +541,9 @@ static int upload_common(psx_ctx* ctx, const void* host, int w, int h, int is_fl
     }
     const void* src = host;
     hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, host) != hipSuccess || attr.type == hipMemoryTypeUnregistered) {
+    // hipPointerGetAttributes costs ~0.2 ms per call in a process with many mappings: callers that KNOW their
+    // buffer is pinned (psx_host_alloc) say so
+    if (!known_pinned && (hipPointerGetAttributes(&attr, host) != hipSuccess || attr.type == hipMemoryTypeUnregistered)) {
         (void)hipGetLastError();
         if (!ctx->ev_upload) PSX_HIP(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
         else PSX_HIP(hipEventSynchronize(ctx->ev_upload));            // previous DMA out of the staging buffer
@@ -549,6 +556,8 @@ static int upload_common(psx_ctx* ctx, const void* host, int w, int h, int is_fl
         memcpy(ctx->h_stage, host, bytes);
         src = ctx->h_stage;
     }
+    // DMA engine, not a kernel: a copy kernel that reads the mapped host image over PCIe itself was measured
+    // (GPU-initiated reads are slow: +0.8 ms per frame in flight, -8 % end-to-end throughput)
     PSX_HIP(hipMemcpyAsync(ctx->d_input_own, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (src == ctx->h_stage) PSX_HIP(hipEventRecord(ctx->ev_upload, ctx->stream));
     ctx->d_input = ctx->d_input_own;
@@ -558,6 +567,10 @@ static int upload_common(psx_ctx* ctx, const void* host, int w, int h, int is_fl
 
 int psx_upload_u8(psx_ctx* ctx, const uint8_t* host, int w, int h) { return upload_common(ctx, host, w, h, 0); }
 int psx_upload_f32(psx_ctx* ctx, const float* host, int w, int h) { return upload_common(ctx, host, w, h, 1); }
+int psx_upload_pinned(psx_ctx* ctx, const void* pinned_host, int w, int h, int is_float)
+{
+    return upload_common(ctx, pinned_host, w, h, is_float ? 1 : 0, true);
+}
 
 int psx_set_input_dev(psx_ctx* ctx, const void* dev_ptr, int w, int h, int is_float)
 {
@@ -715,7 +728,7 @@ int psx_orientation(psx_ctx* ctx)
         if (rc != PSX_OK) return rc;
     }
     PSX_HIP(psx_launch_orientation(ctx->d_params, ctx->d_cnt, ctx->stream));
-    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, ctx->stream));
+    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, export_of(ctx), ctx->stream));
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     return PSX_OK;
 }
@@ -726,9 +739,9 @@ int psx_descriptors(psx_ctx* ctx)
     if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_descriptors: no pyramid");
     PSX_HIP(hipSetDevice(ctx->device));
     if (ctx->cfg.desc_mode == PSX_DESC_LOOP)
-        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->hp.x_desc != nullptr, ctx->stream));
+        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, export_of(ctx), ctx->stream));
     else
-        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, ctx->stream));
+        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, export_of(ctx), ctx->stream));
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     return PSX_OK;
 }
@@ -828,11 +841,11 @@ static int regrow_descriptors(psx_ctx* ctx, int ori_raw)
     *ctx->h_params_pin = P;
     PSX_HIP(hipMemcpyAsync(ctx->d_params, ctx->h_params_pin, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->graph) { (void)hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
-    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, ctx->stream));
+    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, export_of(ctx), ctx->stream));
     if (ctx->cfg.desc_mode == PSX_DESC_LOOP)
-        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->hp.x_desc != nullptr, ctx->stream));
+        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, export_of(ctx), ctx->stream));
     else
-        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, ctx->stream));
+        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, export_of(ctx), ctx->stream));
     return PSX_OK;
 }
 
@@ -842,7 +855,7 @@ static int fetch_counts(psx_ctx* ctx)
     PSX_HIP(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 2; attempt++) {
         int raw;
-        if (ctx->hp.x_counts != nullptr) {
+        if (exporting(ctx)) {
             // export attached: the scan kernel already deposited the counters in pinned memory
             { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
             ctx->h_cnt->ext_total = ctx->h_xcnt[0];
@@ -936,18 +949,24 @@ int psx_attach_export(psx_ctx* ctx, psx_feature* host_features, int feature_capa
         ctx->x_host_desc = host_descriptors; ctx->x_dev_desc = static_cast<float*>(d);
         ctx->x_desc_cap = descriptor_capacity;
     }
-    PsxParams& P = ctx->hp;
-    P.x_features = ctx->x_dev_feat;
-    P.x_desc = ctx->x_dev_desc;
-    P.x_counts = (ctx->x_dev_feat || ctx->x_dev_desc) ? ctx->h_xcnt : nullptr;
-    P.x_feat_capacity = ctx->x_feat_cap;
-    P.x_desc_capacity = ctx->x_desc_cap;
-    if (ctx->d_pyr) {
-        // stream ordered, no host wait: the stream was drained above, so the pinned mirror is not in use,
-        // and the next frame's kernels are queued behind this copy
-        *ctx->h_params_pin = P;
-        PSX_HIP(hipMemcpyAsync(ctx->d_params, ctx->h_params_pin, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
-    }
+    if (ctx->graph) { (void)hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }      // the targets are kernel arguments
+    return PSX_OK;
+}
+
+int psx_attach_export_mapped(psx_ctx* ctx, psx_feature* host_features, int feature_capacity,
+                             float* host_descriptors, int descriptor_capacity)
+{
+    if (!ctx) return PSX_ERR_INVALID;
+    // No HIP call: the targets travel as kernel arguments of the next extraction.  The frame in flight (if any)
+    // keeps the targets it was launched with.
+    if (ctx->x_registered_feat) { (void)hipHostUnregister(ctx->x_host_feat); ctx->x_registered_feat = false; }
+    if (ctx->x_registered_desc) { (void)hipHostUnregister(ctx->x_host_desc); ctx->x_registered_desc = false; }
+    // psx_host_alloc memory: mapped, and its device address is its host address (checked at allocation)
+    ctx->x_host_feat = ctx->x_dev_feat = (host_features && feature_capacity > 0) ? host_features : nullptr;
+    ctx->x_host_desc = ctx->x_dev_desc = (host_descriptors && descriptor_capacity > 0) ? host_descriptors : nullptr;
+    ctx->x_feat_cap = ctx->x_dev_feat ? feature_capacity : 0;
+    ctx->x_desc_cap = ctx->x_dev_desc ? descriptor_capacity : 0;
+    if (ctx->graph) { (void)hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
     return PSX_OK;
 }
 
@@ -966,6 +985,12 @@ int psx_host_alloc(size_t bytes, void** out)
     psx_ctx* ctx = nullptr;
     if (!out) return PSX_ERR_INVALID;
     PSX_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocPortable));
+    // psx_upload_pinned / psx_attach_export_mapped rely on "device address == host address" for this memory
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, *out, 0) != hipSuccess || dev != *out) {
+        (void)hipHostFree(*out); *out = nullptr;
+        return fail(nullptr, PSX_ERR_HIP, "psx_host_alloc: mapped host memory has a different device address on this system");
+    }
     return PSX_OK;
 }
 

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_NT = 1024;
 
-__device__ __forceinline__ void write_feature(const PsxParams* P, int i, const psx_extremum& ex, int excl, int limit)
+__device__ __forceinline__ void write_feature(const PsxParams* P, const PsxExport& X, int i, const psx_extremum& ex, int excl, int limit)
 {
     // prep_features, sift_pyramid.cu:250-280 (descriptor pointers become indices, -1 == nullptr)
     psx_feature f;
@@ -289,10 +289,10 @@ __device__ __forceinline__ void write_feature(const PsxParams* P, int i, const p
         f.desc_idx[k] = (on && excl + k < limit) ? excl + k : -1;
     }
     P->features[i] = f;
-    if (P->x_features != nullptr && i < P->x_feat_capacity) P->x_features[i] = f;
+    if (X.features != nullptr && i < X.feat_capacity) X.features[i] = f;
 }
 
-__global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ P, PsxCounters* cnt)
+__global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ P, PsxCounters* cnt, const PsxExport X)
 {
     __shared__ int s_wsum[SCAN_NT / PSX_WAVE];
     __shared__ int s_total;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
                 if (excl >= cap) {                 // no descriptor wave will visit this extremum
                     psx_extremum ex = P->extrema[i];
                     ex.idx_ori = excl;
-                    write_feature(P, i, ex, excl, cap);
+                    write_feature(P, X, i, ex, excl, cap);
                 }
                 excl += n;
             }
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
             cnt->ext_total = total;
             cnt->ori_total = ori_total;
             cnt->ori_raw = min(grand, rule);   // what the frame needs: the host grows the descriptor buffers up to it
-            if (P->x_counts != nullptr) { P->x_counts[0] = total; P->x_counts[1] = ori_total; P->x_counts[2] = min(grand, rule); }
+            if (X.counts != nullptr) { X.counts[0] = total; X.counts[1] = ori_total; X.counts[2] = min(grand, rule); }
         }
         // per-octave orientation counts (dct.ori_ct / ori_ps, s_orientation.cu:340-360), lane o = octave o
         int ps = ori_total;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
 
 // normalize_histogram (s_desc_norm_rs.h:42-77 / s_desc_norm_l2.h:86-135); the lane owns bins 2*lane, 2*lane+1 of
 // descriptor j and stores them (device array and, when attached, the zero-copy export)
-__device__ __forceinline__ void normalize_store(const PsxParams* P, int j, int lane, float a, float b)
+__device__ __forceinline__ void normalize_store(const PsxParams* P, const PsxExport& X, int j, int lane, float a, float b)
 {
     if (P->norm_mode == PSX_NORM_ROOTSIFT) {
         const float sum = wave_sum(a + b);
@@ -424,8 +424,8 @@ __device__ __forceinline__ void normalize_store(const PsxParams* P, int j, int l
         b = b * norm;
     }
     reinterpret_cast<float2*>(P->desc + (size_t)j * 128)[lane] = make_float2(a, b);
-    if (P->x_desc != nullptr && j < P->x_desc_capacity)
-        reinterpret_cast<float2*>(P->x_desc + (size_t)j * 128)[lane] = make_float2(a, b);
+    if (X.desc != nullptr && j < X.desc_capacity)
+        reinterpret_cast<float2*>(X.desc + (size_t)j * 128)[lane] = make_float2(a, b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -448,7 +448,7 @@ __device__ __forceinline__ void normalize_store(const PsxParams* P, int j, int l
 __device__ int g_desc_dbg = 0;
 extern "C" void psx_debug_set_desc_dbg(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_desc_dbg), &v, sizeof(v)); }
 #endif
-__global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt)
+__global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
 {
 #ifdef PSX_PHASE_TIMING
     const int dbg = g_desc_dbg;      // 1: no LDS atomics (values folded into one add), 2: no gradient loads
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
         const PsxOctave oc = P->oct[ex.octave];
         const int width = oc.w, height = oc.h;
 
-        if (ori_num == 0 && lane == 0) write_feature(P, ext_idx, ex, ex.idx_ori, total);
+        if (ori_num == 0 && lane == 0) write_feature(P, X, ext_idx, ex, ex.idx_ori, total);
 
         for (int i = lane; i < DCOPIES * DSTRIDE; i += PSX_WAVE) acc[i] = 0u;
         wave_fence();
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
             sa += acc[c * DSTRIDE + rbin];
             sb += acc[c * DSTRIDE + rbin + 1];
         }
-        normalize_store(P, j, lane, (float)sa * (1.0f / DFIX), (float)sb * (1.0f / DFIX));
+        normalize_store(P, X, j, lane, (float)sa * (1.0f / DFIX), (float)sb * (1.0f / DFIX));
         wave_fence();
     }
 }
@@ -675,7 +675,7 @@ constexpr int ALT_BINS = 9;
 __device__ __forceinline__ void alt_add(float* bins, int lane, int b, float v) { bins[b * PSX_WAVE + lane] += v; }
 
 template <int MODE>
-__global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restrict__ P, const PsxCounters* cnt)
+__global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
 {
     __shared__ float s_bins[WPB][ALT_BINS * PSX_WAVE];
     __shared__ float s_out[WPB][128];
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
         const float ang = ex.orientation[ori_num];
         const PsxOctave oc = P->oct[ex.octave];
         const int W = oc.w, H = oc.h, pitch = oc.pitch;
-        if (ori_num == 0 && lane == 0) write_feature(P, ext_idx, ex, ex.idx_ori, total);
+        if (ori_num == 0 && lane == 0) write_feature(P, X, ext_idx, ex, ex.idx_ori, total);
 
         const float x = ex.xpos, y = ex.ypos;
         const float* plane = oc.data + (size_t)psx_clampi(ex.lpos, 0, P->L - 1) * oc.plane;
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
             }
         }
         wave_fence();
-        normalize_store(P, j, lane, out[2 * lane], out[2 * lane + 1]);
+        normalize_store(P, X, j, lane, out[2 * lane], out[2 * lane + 1]);
         wave_fence();
     }
 }
@@ -872,31 +872,32 @@ hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt,
     return hipGetLastError();
 }
 
-hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s)
+hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, const PsxExport& x, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_NT), 0, s, d_params, d_cnt);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_NT), 0, s, d_params, d_cnt, x);
     return hipGetLastError();
 }
 
-hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, hipStream_t s)
+hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, const PsxExport& x, hipStream_t s)
 {
     const dim3 grid(2048), block(NT);
     switch (desc_mode) {
-    case PSX_DESC_ILOOP:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_ILOOP>, grid, block, 0, s, d_params, d_cnt); break;
-    case PSX_DESC_GRID:   hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_GRID>, grid, block, 0, s, d_params, d_cnt); break;
-    case PSX_DESC_IGRID:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_IGRID>, grid, block, 0, s, d_params, d_cnt); break;
-    case PSX_DESC_NOTILE: hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_NOTILE>, grid, block, 0, s, d_params, d_cnt); break;
+    case PSX_DESC_ILOOP:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_ILOOP>, grid, block, 0, s, d_params, d_cnt, x); break;
+    case PSX_DESC_GRID:   hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_GRID>, grid, block, 0, s, d_params, d_cnt, x); break;
+    case PSX_DESC_IGRID:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_IGRID>, grid, block, 0, s, d_params, d_cnt, x); break;
+    case PSX_DESC_NOTILE: hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_NOTILE>, grid, block, 0, s, d_params, d_cnt, x); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, bool exporting, hipStream_t s)
+hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, const PsxExport& x, hipStream_t s)
 {
+    const bool exporting = x.desc != nullptr;
     // 2048 workgroups = 8 waves/SIMD.  With the zero-copy export attached every wave ends in stores that
     // cross PCIe; fewer resident waves leave room for the other streams' kernels meanwhile: 768 workgroups
     // measured +11 % on the export leg of bench.py (4200 -> 4660 Mpix/s), 2048 is best without export.
     const int grid = exporting ? 768 : 2048;
-    hipLaunchKernelGGL(k_descriptors, dim3(grid), dim3(NT), 0, s, d_params, d_cnt);
+    hipLaunchKernelGGL(k_descriptors, dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
     return hipGetLastError();
 }

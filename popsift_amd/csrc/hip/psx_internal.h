@@ -58,12 +58,17 @@ struct PsxParams {
     float*        desc;                  // dbuf.desc, 128 floats each
     int*          feat_to_ext;           // dobuf.feat_to_ext_map
     int*          ext_nori;              // num_ori per extremum (SoA copy for the scan)
-    // zero-copy export into mapped host memory (nullptr when detached)
-    psx_feature*  x_features;
-    float*        x_desc;
-    int*          x_counts;              // [0]=ext_total [1]=ori_total [2]=ori_raw, pinned host memory
-    int           x_feat_capacity;
-    int           x_desc_capacity;
+};
+
+// Zero-copy export targets in mapped host memory (nullptr when detached).  Passed to the scan and descriptor
+// kernels BY VALUE as a kernel argument: attaching a fresh result buffer per frame then costs no HIP call at all
+// (a parameter-block update over PCIe per frame measured 0.9 ms of host time per worker).
+struct PsxExport {
+    psx_feature*  features;
+    float*        desc;
+    int*          counts;                // [0]=ext_total [1]=ori_total [2]=ori_raw, pinned host memory
+    int           feat_capacity;
+    int           desc_capacity;
 };
 
 // ExtremaCounters (sift_pyramid.h:21-33), kept in device memory of the context.
@@ -124,11 +129,11 @@ hipError_t psx_launch_gridfilter(const PsxParams* d_params, PsxCounters* d_cnt, 
                                  unsigned* vals_in, unsigned* vals_out, void* temp, size_t temp_bytes,
                                  int* scratch, hipStream_t s);
 hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
-hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s);
+hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, const PsxExport& x, hipStream_t s);
 hipError_t psx_launch_feature_ptrs(const psx_feature* in, psx_feature_dev* out, int n, float* desc_base, int num_desc,
                                    hipStream_t s);
-hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, bool exporting, hipStream_t s);
-hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, hipStream_t s);
+hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, const PsxExport& x, hipStream_t s);
+hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, const PsxExport& x, hipStream_t s);
 
 // ---- small device helpers --------------------------------------------------------------------
 __device__ __forceinline__ int psx_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

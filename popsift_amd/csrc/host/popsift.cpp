@@ -6,8 +6,9 @@
 //     and sleeps on a blocking event until that frame is done, so several frames overlap on the GPU;
 //   * the automatic octave count (Config::octaves < 0) is resolved ONCE per PopSift from the first image
 //     enqueued, as the reference does (popsift.cpp:118-122), and handed to every context explicitly;
-//   * results arrive by zero-copy export (psx_attach_export): no per-image pin/unpin
-//     (features.cu:86-111), no D2H copy commands;
+//   * the image is deep-copied into pinned pool memory at enqueue (one host copy, DMA straight from it);
+//     results are DMA-ed into pinned pool buffers that become the FeaturesHost's arrays: no per-image
+//     pin/unpin (features.cu:86-111) and no host copy of the descriptors;
 //   * every failure is caught, stored in the job and re-thrown from get(); a job is always
 //     fulfilled (the reference's extract loop has no try/catch and would std::terminate).
 #include "popsift/popsift.h"
@@ -77,6 +78,13 @@ int pipe_depth()
     return d < 1 ? 1 : ( d > 32 ? 32 : d );
 }
 
+// pinned bytes that jobs and result objects may hold before they fall back to pageable memory (POPSIFT_PINNED_LIMIT_MB)
+size_t pinned_limit()
+{
+    static const size_t lim = []{ const char* e = getenv( "POPSIFT_PINNED_LIMIT_MB" ); return (size_t)( e ? atol( e ) : 2048 ) << 20; }();
+    return lim;
+}
+
 // export capacities per context: larger results fall back to psx_download
 const int EXPORT_FEATURES    = 1 << 16;
 const int EXPORT_DESCRIPTORS = 1 << 17;
@@ -87,29 +95,39 @@ const int EXPORT_DESCRIPTORS = 1 << 17;
  * SiftJob
  *********************************************************************************/
 
+namespace {
+// The deep copy of the caller's image (popsift.cpp:392-395 in the reference: malloc + memcpy) goes straight into
+// pinned, GPU-mapped pool memory: the worker then DMAs from it without a second host copy through a staging buffer.
+unsigned char* job_image( const void* src, size_t bytes, size_t* pinned_cap )
+{
+    *pinned_cap = 0;
+    unsigned char* p = nullptr;
+    if( popsift::pool::pinned_in_use() <= pinned_limit() ) p = (unsigned char*)popsift::pool::get_pinned( bytes ? bytes : 1, pinned_cap );
+    if( p == nullptr ) { *pinned_cap = 0; p = (unsigned char*)malloc( bytes ? bytes : 1 ); }
+    if( p == nullptr ) POP_FATAL( "Memory limitation\nE    Failed to allocate memory for SiftJob" );
+    memcpy( p, src, bytes );
+    return p;
+}
+} // namespace
+
 SiftJob::SiftJob( int w, int h, const unsigned char* imageData )
-    : _w(w), _h(h), _imageData(nullptr), _is_float(false)
+    : _w(w), _h(h), _imageData(nullptr), _pinned_cap(0), _is_float(false)
 {
     _f = _p.get_future();
-    const size_t bytes = (size_t)w * h;
-    _imageData = (unsigned char*)malloc( bytes ? bytes : 1 );
-    if( _imageData == nullptr )
-        POP_FATAL( "Memory limitation\nE    Failed to allocate memory for SiftJob" );
-    memcpy( _imageData, imageData, bytes );
+    _imageData = job_image( imageData, (size_t)w * h, &_pinned_cap );
 }
 
 SiftJob::SiftJob( int w, int h, const float* imageData )
-    : _w(w), _h(h), _imageData(nullptr), _is_float(true)
+    : _w(w), _h(h), _imageData(nullptr), _pinned_cap(0), _is_float(true)
 {
     _f = _p.get_future();
-    const size_t bytes = (size_t)w * h * sizeof(float);
-    _imageData = (unsigned char*)malloc( bytes ? bytes : 1 );
-    if( _imageData == nullptr )
-        POP_FATAL( "Memory limitation\nE    Failed to allocate memory for SiftJob" );
-    memcpy( _imageData, imageData, bytes );
+    _imageData = job_image( imageData, (size_t)w * h * sizeof(float), &_pinned_cap );
 }
 
-SiftJob::~SiftJob( ) { free( _imageData ); }
+SiftJob::~SiftJob( )
+{
+    if( _pinned_cap ) popsift::pool::put_pinned( _imageData, _pinned_cap ); else free( _imageData );
+}
 
 void SiftJob::setFeatures( popsift::FeaturesBase* f ) { _p.set_value( f ); }
 void SiftJob::setError( std::exception_ptr ptr )      { _err = ptr; }
@@ -153,7 +171,7 @@ struct PopSift::Impl
     int                          octaves_resolved = -1;  // sticky automatic octave count (popsift.cpp:118-122); cfg_mutex
     // POPSIFT_PROFILE=1: seconds spent per phase (all workers), printed by uninit()
     std::mutex                   prof_mutex;
-    double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0;
+    double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0, t_pool = 0;
     int    n_done = 0;
 };
 
@@ -221,8 +239,8 @@ void PopSift::uninit( )
     }
     if( getenv( "POPSIFT_PROFILE" ) != nullptr && _impl->n_done > 0 ) {
         const double k = 1e3 / _impl->n_done;
-        fprintf( stderr, "[popsift profile] %d frames, host ms per frame (per worker thread): attach %.3f upload %.3f launch %.3f "
-                         "wait-for-frame %.3f wrap %.3f\n", _impl->n_done, _impl->t_attach * k, _impl->t_upload * k,
+        fprintf( stderr, "[popsift profile] %d frames, host ms per frame (per worker thread): attach %.3f (pool %.3f) upload %.3f launch %.3f "
+                         "wait-for-frame %.3f wrap %.3f\n", _impl->n_done, _impl->t_attach * k, _impl->t_pool * k, _impl->t_upload * k,
                  _impl->t_submit * k, _impl->t_frame * k, _impl->t_wrap * k );
     }
     _impl->contexts_exist = false;
@@ -309,13 +327,6 @@ void check( psx_ctx* ctx, int rc, const char* what )
     throw std::runtime_error( msg );
 }
 
-// pinned bytes that result objects may hold before results fall back to pageable copies (POPSIFT_PINNED_LIMIT_MB)
-size_t pinned_limit()
-{
-    static const size_t lim = []{ const char* e = getenv( "POPSIFT_PINNED_LIMIT_MB" ); return (size_t)( e ? atol( e ) : 2048 ) << 20; }();
-    return lim;
-}
-
 inline double pnow() { return std::chrono::duration<double>( std::chrono::steady_clock::now().time_since_epoch() ).count(); }
 
 popsift::FeaturesHost* collect_host( Slot& s, std::atomic<int>& want_desc, double* t_frame )
@@ -341,9 +352,10 @@ popsift::FeaturesHost* collect_host( Slot& s, std::atomic<int>& want_desc, doubl
         base = (popsift::Descriptor*)popsift::pool::get_pinned( (size_t)std::max( no, 1 ) * sizeof(popsift::Descriptor), &cap );
         if( base == nullptr ) { popsift::pool::put_plain( dst, ext_cap ); delete f; throw std::runtime_error( "out of host memory for descriptors" ); }
         f->adopt( ne, no, dst, ext_cap, base, cap );
-        tmp.resize( ne );
-        check( s.ctx, psx_download( s.ctx, tmp.data(), ne, (float*)base, no ), "psx_download" );
-        src = tmp.data();
+        psx_feature* ftarget = s.xfeat;                       // pinned: the D2H copy stays asynchronous
+        if( ftarget == nullptr || ne > EXPORT_FEATURES ) { tmp.resize( ne ); ftarget = tmp.data(); }
+        check( s.ctx, psx_download( s.ctx, ftarget, ne, (float*)base, no ), "psx_download" );
+        src = ftarget;
     } else if( popsift::pool::pinned_in_use() > pinned_limit() ) {
         // a caller that hoards results must not exhaust pinned memory: beyond the limit the result gets an
         // ordinary page-aligned copy (what the reference hands out) and the context keeps its pinned buffer
@@ -425,7 +437,7 @@ void PopSift::dispatchLoop( )
     Impl& p = *_impl;
     Slot s;
     pin_to_device_numa_node( _device );
-    double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0; int n_done = 0;
+    double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0, t_pool = 0; int n_done = 0;
 
     for( ;; ) {
         SiftJob* job = p.queue.pull();
@@ -453,16 +465,25 @@ void PopSift::dispatchLoop( )
                 }
             }
             const double t0 = pnow();
-            if( _proc_mode == popsift::Config::ExtractingMode && s.xdesc == nullptr ) {
+            // Results reach the host by DMA after the frame (psx_download into pinned pool buffers that the
+            // FeaturesHost then owns).  The alternative, POPSIFT_EXPORT=1, lets the descriptor kernel store them
+            // straight into mapped host memory (psx_attach_export_mapped): no second wait, but the PCIe stores slow
+            // the kernel down -- measured 4750 vs 5340 Mpix/s end to end on MI355X, so it is opt-in.
+            static const bool use_export = []{ const char* e = getenv( "POPSIFT_EXPORT" ); return e != nullptr && e[0] == '1'; }();
+            if( _proc_mode == popsift::Config::ExtractingMode && s.xdesc == nullptr && use_export ) {
                 // the previous result took this context's descriptor buffer with it: attach a fresh one
                 const int want = p.want_desc;
+                const double tp0 = pnow();
                 s.xdesc = (float*)popsift::pool::get_pinned( (size_t)want * sizeof(popsift::Descriptor), &s.xdesc_cap );
+                t_pool += pnow() - tp0;
                 if( s.xdesc == nullptr ) throw std::runtime_error( "out of host memory for export buffers" );
                 s.desc_cap = (int)std::min<size_t>( s.xdesc_cap / sizeof(popsift::Descriptor), (size_t)1 << 30 );
-                check( s.ctx, psx_attach_export( s.ctx, s.xfeat, EXPORT_FEATURES, s.xdesc, s.desc_cap ), "psx_attach_export" );
+                check( s.ctx, psx_attach_export_mapped( s.ctx, s.xfeat, EXPORT_FEATURES, s.xdesc, s.desc_cap ), "psx_attach_export_mapped" );
             }
             const double t1 = pnow();
-            if( job->isFloat() )
+            if( job->isPinned() )
+                check( s.ctx, psx_upload_pinned( s.ctx, job->getData(), job->getWidth(), job->getHeight(), job->isFloat() ? 1 : 0 ), "psx_upload_pinned" );
+            else if( job->isFloat() )
                 check( s.ctx, psx_upload_f32( s.ctx, (const float*)job->getData(), job->getWidth(), job->getHeight() ), "psx_upload_f32" );
             else
                 check( s.ctx, psx_upload_u8( s.ctx, job->getData(), job->getWidth(), job->getHeight() ), "psx_upload_u8" );
@@ -493,7 +514,7 @@ void PopSift::dispatchLoop( )
     popsift::pool::put_pinned( s.xdesc, s.xdesc_cap );
     {
         std::lock_guard<std::mutex> g( p.prof_mutex );
-        p.t_attach += t_attach; p.t_upload += t_upload; p.t_submit += t_submit; p.t_frame += t_frame; p.t_wrap += t_wrap;
+        p.t_pool += t_pool; p.t_attach += t_attach; p.t_upload += t_upload; p.t_submit += t_submit; p.t_frame += t_frame; p.t_wrap += t_wrap;
         p.n_done += n_done;
     }
 }

@@ -18,6 +18,7 @@
 #include "sift_config.h"
 #include "sift_extremum.h"
 
+#include <cstddef>
 #include <exception>
 #include <future>
 #include <memory>
@@ -40,6 +41,7 @@ class SiftJob
     int                 _w;
     int                 _h;
     unsigned char*      _imageData;
+    size_t              _pinned_cap;   ///< > 0: _imageData is pinned, GPU-mapped pool memory (direct DMA source)
     bool                _is_float;
     std::exception_ptr  _err;
 
@@ -65,6 +67,7 @@ public:
     int  getHeight() const { return _h; }
     bool isFloat() const   { return _is_float; }
     const unsigned char* getData() const { return _imageData; }
+    bool isPinned() const  { return _pinned_cap != 0; }
 };
 
 class PopSift
