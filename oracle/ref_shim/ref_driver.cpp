@@ -169,6 +169,7 @@ int ref_gauss_tables(const osift_config* c, osift_tables* t)
 {
     Config conf = make_config(c);
     conf.levels = std::max(2, conf.levels);
+    memset((void*)&h_gauss, 0, sizeof(h_gauss));      // the tables are process-global: rows of an earlier, deeper configuration would linger
     try { init_filter(conf, conf.sigma, conf.levels); } catch (const std::exception&) { return -1; }
     memset(t, 0, sizeof(*t));
     memcpy(t->inc_filter, h_gauss.inc.filter, sizeof(t->inc_filter));

@@ -435,7 +435,7 @@ __device__ __forceinline__ void normalize_store(const PsxParams* P, const PsxExp
 // 16x4-pixel tiles (lane = (x&15, y&3)); tiles with no pixel inside the window are skipped with
 // one ballot.  Every pixel inside is visited once: gradient magnitude / angle once, Gaussian
 // weight once, then the classic trilinear scatter into <= 2x2 spatial tiles x 2 orientation bins
-// with ds_add_f32.  This is the same sum the reference forms by scanning the window from each of
+// with integer LDS atomics (fixed-point bins, below).  This is the same sum the reference forms by scanning the window from each of
 // its 16 tile warps (s_desc_loop.cu:60-124): a pixel contributes to tile (ix,iy) with weight
 // (1-|u-ix|)(1-|v-iy|) iff |u-ix|<1 and |v-iy|<1, where (u,v) are the pixel's coordinates in
 // tile units; only rounding differs (<= 1e-6 relative per sample; the test tolerance on the
@@ -444,38 +444,51 @@ __device__ __forceinline__ void normalize_store(const PsxParams* P, const PsxExp
 // degree-13 odd minimax polynomial for atan (max error 3.3e-7 rad).
 // ---------------------------------------------------------------------------------------------
 
-#ifdef PSX_PHASE_TIMING
-__device__ int g_desc_dbg = 0;
-extern "C" void psx_debug_set_desc_dbg(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_desc_dbg), &v, sizeof(v)); }
-#endif
-__global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
+// ---------------------------------------------------------------------------------------------
+// k_descriptors.  Round 1's kernel (one pixel per lane, eight ds_add_u32 per pixel) was measured with PMC and with
+// its atomics / its loads compiled out (profiles/r02_descriptor_experiments.txt): 85 M wave-level VALU instructions
+// and an LDS atomic pipe with 70 % conflict cycles and 30 % of all wave cycles stalled on LDS issue; removing the
+// atomics alone or the loads alone did not shorten it.  Both instruction streams are cut here:
+//   * a lane owns the pixel PAIR (2c, 2c+1): gfx950 runs v_pk_{add,mul,fma}_f32 on two floats per lane at the
+//     single-float rate, the pair shares its row terms and its gradient loads (one 16-byte load per row, rows are
+//     256-byte aligned and 2c is even); a step covers 16 x 8 pixels (lane = (c 0..7, row 0..7));
+//   * the two orientation bins of a contribution (fo, fo+1) go out as ONE ds_add_u64: bins are 32-bit fixed point
+//     with head-room (below), so the low word never carries into the high word.  A tile keeps its 8
+//     bins twice: as pairs (0,1)(2,3)(4,5)(6,7) for even fo and (1,2)(3,4)(5,6)(7,0) for odd fo; the epilogue adds
+//     the two views;
+//   * the angle lives in bin units (0..8 = 0..2 pi) from the atan polynomial on and is not wrapped into [0, 8):
+//     floor() and "& 7" wrap the bin index, the fractional part is the same.
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) v2f* gv2f_p;
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
+
+__global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
 {
-#ifdef PSX_PHASE_TIMING
-    const int dbg = g_desc_dbg;      // 1: no LDS atomics (values folded into one add), 2: no gradient loads
-#endif
-    // Histogram layout per copy: tiles (iy, ix), iy, ix in -1..4, at index (iy+1)*5 + (ix+1), 8 bins
-    // each.  Column 0 and rows 0 / 5 are never read: the trilinear scatter of a pixel near the window
-    // border lands there instead of being range-checked (the kernel is VALU bound; the checks cost
-    // more than the wasted atomics).  ix = 4 of row iy aliases ix = -1 of row iy+1: both are dump slots.
-    // 4 private copies per wave (lane & 3): neighbouring pixels of a row fall into the same tile and
-    // orientation bin, and same-address atomics serialise.
-    // Bins are 18.14 unsigned fixed point, accumulated with ds_add_u32 (round to nearest per contribution):
-    // a bin collects at most (2*SBP)^2 pixels x |gradient| <= 360.7; SBP = 3*sigma <= ~15 for any legal
-    // Config (sigma <= 2, sift_conf.h) gives < 3.3e5 in total, i.e. < 8.2e4 per copy (the 4 copies take
-    // every 4th column) against 2^18 = 2.6e5.
-    constexpr int DCOPIES = 4, DTILES = 31, DSTRIDE = DTILES * 8 + 1;
+    // Histogram layout per copy: tiles (iy, ix), iy, ix in -1..4, at index (iy+1)*5 + (ix+1) (31 slots), 16 words
+    // each (two views of 8 bins).  Column 0 and rows 0 / 5 are never read: the trilinear scatter of a pixel near
+    // the window border lands there instead of being range-checked; ix = 4 of row iy aliases ix = -1 of row iy+1,
+    // both are dump slots.  4 private copies per wave keyed by the pixel pair's column and row parity:
+    // neighbouring pixels fall into the same tile and orientation bin, and same-address atomics serialise.
+    // Bins are 18.14 unsigned fixed point (round to nearest per contribution): a bin collects at most (2*SBP)^2
+    // pixels x |gradient| <= 360.7.  SBP = 3*sigma, and sigma <= 2 * 2^((levels+1.5)/levels) <= 6.73 for any legal
+    // Config (sigma0 <= 2, gauss_filter.cu:131; levels >= 2, popsift.cpp:86) gives SBP <= 20.2, < 5.9e5 in total
+    // and < 1.5e5 per copy (each copy takes a quarter of the pixels) against 2^18 = 2.6e5
+    // (tests/test_gpu_configs.py::test_descriptor_bins_do_not_overflow_at_large_sigma).
+    constexpr int DCOPIES = 4, DTILES = 31, DSTRIDE = DTILES * 16 + 2;         // even: 8-byte aligned copies
     constexpr float DFIX = 16384.0f;
-    __shared__ unsigned s_desc[WPB][DCOPIES * DSTRIDE];
+    __shared__ __attribute__((aligned(8))) unsigned s_desc[WPB][DCOPIES * DSTRIDE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned* acc = s_desc[wave];
-    const int lx = lane & 15, ly = lane >> 4;
-    // LDS byte address of tile (-1,-1) of this lane's copy
-    const unsigned myacc = (unsigned)(uintptr_t)(acc + (lane & (DCOPIES - 1)) * DSTRIDE);
+    const int lx = lane & 7, ly = lane >> 3;
+    const int copy = (lane & 1) | (((lane >> 3) & 1) << 1);                    // neighbours in x and in y use different copies
+    const unsigned myacc = (unsigned)(uintptr_t)(acc + copy * DSTRIDE);
 
     const int total = cnt->ori_total;
     const int nwaves = gridDim.x * WPB;
     for (int jv = blockIdx.x * WPB + wave; jv < total; jv += nwaves) {
-        const int j = __builtin_amdgcn_readfirstlane(jv);          // wave uniform: scalar loads below
+        const int j = __builtin_amdgcn_readfirstlane(jv);
         const int ext_idx = P->feat_to_ext[j];
         const psx_extremum ex = P->extrema[ext_idx];
         const int ori_num = psx_clampi(j - ex.idx_ori, 0, PSX_ORI_MAX - 1);
@@ -491,7 +504,10 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
         const float x = ex.xpos, y = ex.ypos;
         const int   level = psx_clampi(ex.lpos, 0, P->L - 1);
         const float SBP = fabsf(DESC_MAGNIFY * ex.sigma);
-        const char* plane = reinterpret_cast<const char*>(oc.data + (size_t)level * oc.plane);
+        const unsigned long long pb = (unsigned long long)(uintptr_t)(oc.data + (size_t)level * oc.plane);
+        const unsigned pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb);
+        const unsigned pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+        const char* plane = reinterpret_cast<const char*>((uintptr_t)(((unsigned long long)pb_hi << 32) | pb_lo));
         const unsigned pitch4 = (unsigned)oc.pitch * 4u;
 
         if (SBP != 0.0f) {
@@ -502,8 +518,8 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
             const float crsbp = cos_t / SBP;
             const float srsbp = sin_t / SBP;
             const float bsz   = fabsf(csbp) + fabsf(ssbp);
+            const float ang_bins = ang * M_4RPI_F;
 
-            // union of the 16 tile bounding boxes (s_desc_loop.cu:66-70): extremes at the corner tiles
             int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -0x7fffffff, ymax = -0x7fffffff;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -518,92 +534,108 @@ __global__ __launch_bounds__(NT, 8) void k_descriptors(const PsxParams* __restri
             }
             xmin = max(1, xmin); ymin = max(1, ymin);
             xmax = min(width - 2, xmax); ymax = min(height - 2, ymax);
+            const int xs = xmin & ~1;                         // even: aligned pixel pairs
 
-            for (int ty = ymin; ty <= ymax; ty += 4) {
+            for (int ty = ymin; ty <= ymax; ty += 8) {
                 const int ii = ty + ly;
                 const float dyk = ii - y;
                 const float ub = fmaf(srsbp, dyk, 1.5f);      // u = crsbp*dx + srsbp*dy + 1.5
                 const float vb = fmaf(crsbp, dyk, 1.5f);      // v = crsbp*dy - srsbp*dx + 1.5
                 const unsigned rowoff = (unsigned)ii * pitch4;
-                for (int tx = xmin; tx <= xmax; tx += 16) {
-                    const int jj = tx + lx;
-                    const float dxk = jj - x;
-                    const float u = fmaf(crsbp, dxk, ub);
-                    const float v = fmaf(-srsbp, dxk, vb);
-                    const bool in = (ii <= ymax) && (jj <= xmax) &&
-                                    (u > -1.0f) && (u < 4.0f) && (v > -1.0f) && (v < 4.0f);
-                    if (__ballot(in) == 0ull) continue;
-                    if (in) {
-                        // uniform plane base + 32-bit byte offset: global_load with scalar base
+                const bool rowok = ii <= ymax;
+                for (int tx = xs; tx <= xmax; tx += 16) {
+                    const int jj = tx + 2 * lx;
+                    const float dx0 = jj - x;
+                    const v2f dxk = (v2f){dx0, dx0 + 1.0f};
+                    const v2f u = pk_fma(splat(crsbp), dxk, splat(ub));
+                    const v2f v = pk_fma(splat(-srsbp), dxk, splat(vb));
+                    const bool in0 = rowok && (jj >= xmin) && (jj <= xmax) &&
+                                     (u.x > -1.0f) && (u.x < 4.0f) && (v.x > -1.0f) && (v.x < 4.0f);
+                    const bool in1 = rowok && (jj + 1 <= xmax) &&
+                                     (u.y > -1.0f) && (u.y < 4.0f) && (v.y > -1.0f) && (v.y < 4.0f);
+                    if (__ballot(in0 || in1) == 0ull) continue;
+                    // (a software pipeline that issues the next step's loads before this step's arithmetic was
+                    // measured: the compiler's conservative s_waitcnt across the loop edge undoes it, +12 %)
+                    if (in0 || in1) {
                         const unsigned off = rowoff + (unsigned)jj * 4u;
-#ifdef PSX_PHASE_TIMING
-                        float gxp, gxm, gyp, gym;
-                        if (dbg & 2) { gxp = (float)(off & 255u); gxm = (float)lane; gyp = (float)(off & 63u); gym = 3.0f; }
-                        else {
-                            gxp = *(gfloat_p)(plane + off + 4u); gxm = *(gfloat_p)(plane + off - 4u);
-                            gyp = *(gfloat_p)(plane + (off + pitch4)); gym = *(gfloat_p)(plane + (off - pitch4));
-                        }
-#else
-                        const float gxp = *(gfloat_p)(plane + off + 4u);
-                        const float gxm = *(gfloat_p)(plane + off - 4u);
-                        const float gyp = *(gfloat_p)(plane + (off + pitch4));
-                        const float gym = *(gfloat_p)(plane + (off - pitch4));
-#endif
-                        const float gdx = gxp - gxm;
-                        const float gdy = gyp - gym;
-                        const float mod = __builtin_amdgcn_sqrtf(fmaf(gdx, gdx, gdy * gdy));
-                        float th = fast_atan2(gdy, gdx) - ang;
-                        th += (th <  0.0f  ? PI2_F : 0.0f);
-                        th -= (th >= PI2_F ? PI2_F : 0.0f);
-                        const float tth  = th * M_4RPI_F;
-                        const float ffo  = floorf(tth);
-                        const int   fo0  = (int)ffo;
-                        const float wgt2 = tth - ffo;
-                        const float wgt1 = 1.0f - wgt2;
-                        const unsigned fo  = (unsigned)(fo0 & 7) * 4u;
-                        const unsigned fo1 = (unsigned)((fo0 + 1) & 7) * 4u;
+                        const v2f  ctr = *(gv2f_p)(plane + off);                  // p[jj], p[jj+1]
+                        const float lft = *(gfloat_p)(plane + off - 4u);          // p[jj-1]
+                        const float rgt = *(gfloat_p)(plane + off + 8u);          // p[jj+2]
+                        const v2f  dwn = *(gv2f_p)(plane + (off + pitch4));
+                        const v2f  upp = *(gv2f_p)(plane + (off - pitch4));
+                        const v2f gdx = (v2f){ctr.y - lft, rgt - ctr.x};
+                        const v2f gdy = dwn - upp;
+                        const v2f m2 = pk_fma(gdx, gdx, gdy * gdy);
+                        const v2f mod = (v2f){__builtin_amdgcn_sqrtf(m2.x), __builtin_amdgcn_sqrtf(m2.y)};
+                        // atan2 in bin units: (4/pi) atan(min/max) by the degree-13 odd polynomial, then the octant
+                        const v2f ax = (v2f){fabsf(gdx.x), fabsf(gdx.y)}, ay = (v2f){fabsf(gdy.x), fabsf(gdy.y)};
+                        const v2f mx = (v2f){fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)};
+                        const v2f mn = (v2f){fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
+                        const v2f rc = (v2f){__builtin_amdgcn_rcpf(fmaxf(mx.x, 1e-30f)), __builtin_amdgcn_rcpf(fmaxf(mx.y, 1e-30f))};
+                        const v2f a = mn * rc;
+                        const v2f s2 = a * a;
+                        v2f r = splat(0.006811792496591806f * M_4RPI_F);
+                        r = pk_fma(r, s2, splat(-0.0336042195558548f * M_4RPI_F));
+                        r = pk_fma(r, s2, splat(0.07962366938591003f * M_4RPI_F));
+                        r = pk_fma(r, s2, splat(-0.1323334127664566f * M_4RPI_F));
+                        r = pk_fma(r, s2, splat(0.19807815551757812f * M_4RPI_F));
+                        r = pk_fma(r, s2, splat(-0.3331736922264099f * M_4RPI_F));
+                        r = pk_fma(r, s2, splat(0.9999961256980896f * M_4RPI_F));
+                        r = r * a;
+                        float r0 = r.x, r1 = r.y;
+                        r0 = (ay.x > ax.x) ? 2.0f - r0 : r0;   r1 = (ay.y > ax.y) ? 2.0f - r1 : r1;
+                        r0 = (gdx.x < 0.0f) ? 4.0f - r0 : r0;  r1 = (gdx.y < 0.0f) ? 4.0f - r1 : r1;
+                        r0 = (gdy.x < 0.0f) ? -r0 : r0;        r1 = (gdy.y < 0.0f) ? -r1 : r1;
+                        const v2f tth = (v2f){r0, r1} - splat(ang_bins);          // in (-12, 12): not wrapped
+                        const v2f ffo = (v2f){floorf(tth.x), floorf(tth.y)};
+                        const v2f wgt2 = tth - ffo;
+                        const v2f wgt1 = splat(1.0f) - wgt2;
 
-                        // Gaussian window exp(-d^2/8) as one exp2; the fixed-point scale is folded in here
-                        // (a power of two commutes exactly with the products below)
-                        const float un = u - 1.5f, vn = v - 1.5f;
-                        const float ww = __builtin_amdgcn_exp2f(fmaf(un, un, vn * vn) * (-0.125f * 1.4426950408889634f))
-                                         * (mod * DFIX);
-                        const float fu = floorf(u), fv = floorf(v);
-                        const int   ix0 = (int)fu, iy0 = (int)fv;        // -1..3
-                        const float ax1 = u - fu, ay1 = v - fv;          // weight of tile ix0+1 / iy0+1
-                        const float ax0 = 1.0f - ax1, ay0 = 1.0f - ay1;
-                        const float wy0 = ay0 * ww, wy1 = ay1 * ww;
-                        const float w00 = wy0 * ax0, w01 = wy0 * ax1, w10 = wy1 * ax0, w11 = wy1 * ax1;
-                        const unsigned tb = myacc + (unsigned)((iy0 + 1) * 5 + (ix0 + 1)) * 32u;
-                        unsigned LDS_AS* t0 = (unsigned LDS_AS*)(tb + fo);
-                        unsigned LDS_AS* t1 = (unsigned LDS_AS*)(tb + fo1);
-#ifdef PSX_PHASE_TIMING
-                        if (dbg & 1) {
-                            const unsigned sum = (unsigned)fmaf(wgt1, w00, 0.5f) + (unsigned)fmaf(wgt2, w00, 0.5f) + (unsigned)fmaf(wgt1, w01, 0.5f) +
-                                (unsigned)fmaf(wgt2, w01, 0.5f) + (unsigned)fmaf(wgt1, w10, 0.5f) + (unsigned)fmaf(wgt2, w10, 0.5f) +
-                                (unsigned)fmaf(wgt1, w11, 0.5f) + (unsigned)fmaf(wgt2, w11, 0.5f) + (unsigned)(uintptr_t)t0 + (unsigned)(uintptr_t)t1;
-                            if (sum == 0x12345678u) lds_add(t0, sum);
-                            continue;
+                        const v2f un = u - splat(1.5f), vn = v - splat(1.5f);
+                        const v2f d2 = pk_fma(un, un, vn * vn) * splat(-0.125f * 1.4426950408889634f);
+                        const v2f ww = (v2f){__builtin_amdgcn_exp2f(d2.x), __builtin_amdgcn_exp2f(d2.y)} * (mod * splat(DFIX));
+                        const v2f fu = (v2f){floorf(u.x), floorf(u.y)}, fv = (v2f){floorf(v.x), floorf(v.y)};
+                        const v2f ax1 = u - fu, ay1 = v - fv;
+                        const v2f ax0 = splat(1.0f) - ax1, ay0 = splat(1.0f) - ay1;
+                        const v2f wy0 = ay0 * ww, wy1 = ay1 * ww;
+                        const v2f w00 = wy0 * ax0, w01 = wy0 * ax1, w10 = wy1 * ax0, w11 = wy1 * ax1;
+                        const v2f h = splat(0.5f);
+                        const v2f a00 = pk_fma(wgt1, w00, h), b00 = pk_fma(wgt2, w00, h);
+                        const v2f a01 = pk_fma(wgt1, w01, h), b01 = pk_fma(wgt2, w01, h);
+                        const v2f a10 = pk_fma(wgt1, w10, h), b10 = pk_fma(wgt2, w10, h);
+                        const v2f a11 = pk_fma(wgt1, w11, h), b11 = pk_fma(wgt2, w11, h);
+                        auto pack = [](float lo, float hi) { return (fix64)(unsigned)lo | ((fix64)(unsigned)hi << 32); };
+                        if (in0) {
+                            const unsigned fo = (unsigned)((int)ffo.x & 7);
+                            // tile (iy0, ix0) at 64-byte granules; pair view: even fo -> word fo, odd fo -> word 8 + fo - 1
+                            const unsigned tb = myacc + (unsigned)(((int)fv.x + 1) * 5 + ((int)fu.x + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                            fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
+                            lds_add(t, pack(a00.x, b00.x));      lds_add(t + 8, pack(a01.x, b01.x));       // +1 tile = 16 words = 8 u64
+                            lds_add(t + 40, pack(a10.x, b10.x)); lds_add(t + 48, pack(a11.x, b11.x));      // +5 / +6 tiles
                         }
-#endif
-                        // tile (iy0, ix0), (iy0, ix0+1), (iy0+1, ix0), (iy0+1, ix0+1): +0, +8, +40, +48 entries
-                        lds_add(t0, (unsigned)fmaf(wgt1, w00, 0.5f)); lds_add(t1, (unsigned)fmaf(wgt2, w00, 0.5f));
-                        lds_add(t0 + 8, (unsigned)fmaf(wgt1, w01, 0.5f)); lds_add(t1 + 8, (unsigned)fmaf(wgt2, w01, 0.5f));
-                        lds_add(t0 + 40, (unsigned)fmaf(wgt1, w10, 0.5f)); lds_add(t1 + 40, (unsigned)fmaf(wgt2, w10, 0.5f));
-                        lds_add(t0 + 48, (unsigned)fmaf(wgt1, w11, 0.5f)); lds_add(t1 + 48, (unsigned)fmaf(wgt2, w11, 0.5f));
+                        if (in1) {
+                            const unsigned fo = (unsigned)((int)ffo.y & 7);
+                            const unsigned tb = myacc + (unsigned)(((int)fv.y + 1) * 5 + ((int)fu.y + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                            fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
+                            lds_add(t, pack(a00.y, b00.y));      lds_add(t + 8, pack(a01.y, b01.y));
+                            lds_add(t + 40, pack(a10.y, b10.y)); lds_add(t + 48, pack(a11.y, b11.y));
+                        }
                     }
                 }
             }
         }
         wave_fence();
 
-        // normalize_histogram (s_desc_norm_rs.h:42-77 / s_desc_norm_l2.h:86-135); lane owns 2 bins
+        // the lane owns bins b0 = 2 (lane & 3) and b0 + 1 of tile lane >> 2 (iy = lane >> 4, ix = (lane >> 2) & 3):
+        //   bin b0   = evenview[b0] + oddview[(b0 - 1) & 7 pair].hi,   bin b0+1 = evenview[b0 + 1] + oddview[b0 pair].lo
         unsigned sa = 0u, sb = 0u;
-        const int rbin = (((lane >> 4) + 1) * 5 + ((lane >> 2) & 3) + 1) * 8 + (lane & 3) * 2;   // bins 2*lane, 2*lane+1
+        const int p2 = (lane & 3) * 2;
+        const int tbase = (((lane >> 4) + 1) * 5 + ((lane >> 2) & 3) + 1) * 16;
 #pragma unroll
         for (int c = 0; c < DCOPIES; c++) {
-            sa += acc[c * DSTRIDE + rbin];
-            sb += acc[c * DSTRIDE + rbin + 1];
+            const unsigned* tp = acc + c * DSTRIDE + tbase;
+            sa += tp[p2] + tp[8 + ((p2 + 6) & 7) + 1];
+            sb += tp[p2 + 1] + tp[8 + p2];
         }
         normalize_store(P, X, j, lane, (float)sa * (1.0f / DFIX), (float)sb * (1.0f / DFIX));
         wave_fence();
