@@ -35,44 +35,37 @@ __device__ __forceinline__ float rdog(const PsxOctave& oc, int NL, int x, int y,
     return p[oc.plane] - p[0];
 }
 
-// s_solve.h:25-86 (closed-form inverse); compiled without contraction
-__device__ __forceinline__ bool solve3(float i[3][3], float b[3])
+// Second-order Taylor model of the DoG around a sample: gradient g and the symmetric Hessian H in (x, y, s).
+struct Taylor
 {
-    float det0b = -i[1][2] * i[1][2];
-    float det0a =  i[1][1] * i[2][2];
-    float det0  = det0b + det0a;
-    float det1b = -i[0][1] * i[2][2];
-    float det1a =  i[1][2] * i[0][2];
-    float det1  = det1b + det1a;
-    float det2b = -i[1][1] * i[0][2];
-    float det2a =  i[0][1] * i[1][2];
-    float det2  = det2b + det2a;
-    float det3b = -i[0][2] * i[0][2];
-    float det3a =  i[0][0] * i[2][2];
-    float det3  = det3b + det3a;
-    float det4b = -i[0][0] * i[1][2];
-    float det4a =  i[0][1] * i[0][2];
-    float det4  = det4b + det4a;
-    float det5b = -i[0][1] * i[0][1];
-    float det5a =  i[0][0] * i[1][1];
-    float det5  = det5b + det5a;
+    float gx, gy, gs;             // central differences
+    float hxx, hyy, hss;          // second differences
+    float hxy, hxs, hys;          // mixed differences
+};
 
-    float det;
-    det  = (i[0][0] * det0);
-    det += (i[0][1] * det1);
-    det += (i[0][2] * det2);
-    if (det == 0) return false;
-    const float rsd = 1.0f / det;
+// Newton offset  off = -H^-1 g  through the adjugate of the symmetric H (what solve() of s_solve.h:25-86 computes).
+// The parenthesisation is part of the parity contract (every product rounded, sums left to right; the file is built
+// with -ffp-contract=off): cofactor = (-(p*p')) + (q*q'), det = ((hxx*Cxx) + (hxy*Cxy)) + (hxs*Cxs).
+// Returns false for a singular H.
+__device__ __forceinline__ bool newton_offset(const Taylor& t, float off[3])
+{
+    const float Cxx = (-(t.hys * t.hys)) + (t.hyy * t.hss);
+    const float Cxy = (-(t.hxy * t.hss)) + (t.hys * t.hxs);
+    const float Cxs = (-(t.hyy * t.hxs)) + (t.hxy * t.hys);
+    const float Cyy = (-(t.hxs * t.hxs)) + (t.hxx * t.hss);
+    const float Cys = (-(t.hxx * t.hys)) + (t.hxy * t.hxs);
+    const float Css = (-(t.hxy * t.hxy)) + (t.hxx * t.hyy);
 
-    const float m00 = det0 * rsd, m10 = det1 * rsd, m20 = det2 * rsd;
-    const float m11 = det3 * rsd, m12 = det4 * rsd, m22 = det5 * rsd;
-    const float m01 = m10, m02 = m20, m21 = m12;
+    const float det = ((t.hxx * Cxx) + (t.hxy * Cxy)) + (t.hxs * Cxs);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const float Ixx = Cxx * inv, Ixy = Cxy * inv, Ixs = Cxs * inv;
+    const float Iyy = Cyy * inv, Iys = Cys * inv, Iss = Css * inv;
 
-    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
-    v0 += (m00 * b[0]); v0 += (m01 * b[1]); v0 += (m02 * b[2]);
-    v1 += (m10 * b[0]); v1 += (m11 * b[1]); v1 += (m12 * b[2]);
-    v2 += (m20 * b[0]); v2 += (m21 * b[1]); v2 += (m22 * b[2]);
-    b[0] = v0; b[1] = v1; b[2] = v2;
+    const float rx = -t.gx, ry = -t.gy, rs = -t.gs;
+    off[0] = ((0.0f + Ixx * rx) + Ixy * ry) + Ixs * rs;
+    off[1] = ((0.0f + Ixy * rx) + Iyy * ry) + Iys * rs;
+    off[2] = ((0.0f + Ixs * rx) + Iys * ry) + Iss * rs;
     return true;
 }
 
@@ -128,58 +121,34 @@ __device__ bool refine(const PsxParams* P, const DogView& dv, int octave, int x,
     const int maxlevel = P->L - 1;
     const float thr = P->threshold;
 
-    float D[3], DD[3], DX[3], d[3] = {0.0f, 0.0f, 0.0f};
+    Taylor t;
+    float d[3] = {0.0f, 0.0f, 0.0f};
     const float v = val;
     int n[3] = {x, y, level};
     int iter = 0;
     constexpr int MAX_ITERATIONS = 5;
     do {
         iter++;
-        // x,y +- 1 inside the haloed tile [tx0-1, tx0+ETW] x [ty0-1, ty0+ETH]
+        // the 19 DoG samples of the 3x3x3 cross / edge stencil around n (corners are not needed); x,y +- 1 lie
+        // inside the haloed tile [tx0-1, tx0+ETW] x [ty0-1, ty0+ETH] when n is inside the tile
         const bool in_tile = (n[0] >= dv.tx0 && n[0] < dv.tx0 + ETW && n[1] >= dv.ty0 && n[1] < dv.ty0 + ETH);
-        const float x2y1z1 = dv.at(n[0] + 1, n[1], n[2], in_tile);
-        const float x0y1z1 = dv.at(n[0] - 1, n[1], n[2], in_tile);
-        const float x1y2z1 = dv.at(n[0], n[1] + 1, n[2], in_tile);
-        const float x1y0z1 = dv.at(n[0], n[1] - 1, n[2], in_tile);
-        const float x1y1z2 = dv.at(n[0], n[1], n[2] + 1, in_tile);
-        const float x1y1z0 = dv.at(n[0], n[1], n[2] - 1, in_tile);
-        D[0] = 0.5f * (x2y1z1 - x0y1z1);
-        D[1] = 0.5f * (x1y2z1 - x1y0z1);
-        D[2] = 0.5f * (x1y1z2 - x1y1z0);
+        auto S = [&](int dx, int dy, int ds) { return dv.at(n[0] + dx, n[1] + dy, n[2] + ds, in_tile); };
+        const float c  = S(0, 0, 0);
+        const float xp = S(+1, 0, 0), xm = S(-1, 0, 0);
+        const float yp = S(0, +1, 0), ym = S(0, -1, 0);
+        const float sp = S(0, 0, +1), sm = S(0, 0, -1);
+        t.gx = 0.5f * (xp - xm);
+        t.gy = 0.5f * (yp - ym);
+        t.gs = 0.5f * (sp - sm);
+        t.hxx = xp + xm - 2.0f * c;
+        t.hyy = yp + ym - 2.0f * c;
+        t.hss = sp + sm - 2.0f * c;
+        // mixed terms: (++) + (--) - (-+) - (+-), summed in that order
+        t.hxy = 0.25f * (S(+1, +1, 0) + S(-1, -1, 0) - S(-1, +1, 0) - S(+1, -1, 0));
+        t.hxs = 0.25f * (S(+1, 0, +1) + S(-1, 0, -1) - S(-1, 0, +1) - S(+1, 0, -1));
+        t.hys = 0.25f * (S(0, +1, +1) + S(0, -1, -1) - S(0, +1, -1) - S(0, -1, +1));
 
-        const float x1y1z1 = dv.at(n[0], n[1], n[2], in_tile);
-        DD[0] = x2y1z1 + x0y1z1 - 2.0f * x1y1z1;
-        DD[1] = x1y2z1 + x1y0z1 - 2.0f * x1y1z1;
-        DD[2] = x1y1z2 + x1y1z0 - 2.0f * x1y1z1;
-
-        const float x0y0z1 = dv.at(n[0] - 1, n[1] - 1, n[2], in_tile);
-        const float x0y1z0 = dv.at(n[0] - 1, n[1], n[2] - 1, in_tile);
-        const float x0y1z2 = dv.at(n[0] - 1, n[1], n[2] + 1, in_tile);
-        const float x0y2z1 = dv.at(n[0] - 1, n[1] + 1, n[2], in_tile);
-        const float x1y0z0 = dv.at(n[0], n[1] - 1, n[2] - 1, in_tile);
-        const float x1y0z2 = dv.at(n[0], n[1] - 1, n[2] + 1, in_tile);
-        const float x1y2z0 = dv.at(n[0], n[1] + 1, n[2] - 1, in_tile);
-        const float x1y2z2 = dv.at(n[0], n[1] + 1, n[2] + 1, in_tile);
-        const float x2y0z1 = dv.at(n[0] + 1, n[1] - 1, n[2], in_tile);
-        const float x2y1z0 = dv.at(n[0] + 1, n[1], n[2] - 1, in_tile);
-        const float x2y1z2 = dv.at(n[0] + 1, n[1], n[2] + 1, in_tile);
-        const float x2y2z1 = dv.at(n[0] + 1, n[1] + 1, n[2], in_tile);
-        DX[0] = 0.25f * (x2y2z1 + x0y0z1 - x0y2z1 - x2y0z1);
-        DX[1] = 0.25f * (x2y1z2 + x0y1z0 - x0y1z2 - x2y1z0);
-        DX[2] = 0.25f * (x1y2z2 + x1y0z0 - x1y2z0 - x1y0z2);
-
-        float b[3];
-        float A[3][3];
-        A[0][0] = DD[0];
-        A[1][1] = DD[1];
-        A[2][2] = DD[2];
-        A[1][0] = A[0][1] = DX[0];
-        A[2][0] = A[0][2] = DX[1];
-        A[2][1] = A[1][2] = DX[2];
-        b[0] = -D[0]; b[1] = -D[1]; b[2] = -D[2];
-
-        if (!solve3(A, b)) { d[0] = d[1] = d[2] = 0.0f; break; }
-        d[0] = b[0]; d[1] = b[1]; d[2] = b[2];
+        if (!newton_offset(t, d)) { d[0] = d[1] = d[2] = 0.0f; break; }
 
         const int retval = refine_step<MODE>(d, n, width, height, maxlevel, iter == MAX_ITERATIONS);
         if (retval == -1) return false;
@@ -199,9 +168,9 @@ __device__ bool refine(const PsxParams* P, const DogView& dv, int octave, int x,
             sn < 0.0f || sn > maxlevel) return false;
     }
 
-    const float contr   = v + 0.5f * (D[0] * d[0] + D[1] * d[1] + D[2] * d[2]);
-    const float tr      = DD[0] + DD[1];
-    const float det     = DD[0] * DD[1] - DX[0] * DX[0];
+    const float contr   = v + 0.5f * (t.gx * d[0] + t.gy * d[1] + t.gs * d[2]);
+    const float tr      = t.hxx + t.hyy;
+    const float det     = t.hxx * t.hyy - t.hxy * t.hxy;
     const float edgeval = tr * tr / det;
 
     if (det <= 0.0f) return false;

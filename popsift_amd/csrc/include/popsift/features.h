@@ -72,7 +72,7 @@ public:
     inline F_const_iterator end() const   { return &_ext[size()]; }
 
     void reset( int num_ext, int num_ori );
-    /// kept for source compatibility; result memory is filled by zero-copy export, nothing to pin
+    /// kept for source compatibility: results arrive in pooled pinned buffers (DMA download or zero-copy export), nothing to pin per image
     void pin( );
     void unpin( );
 
