@@ -291,7 +291,8 @@ int psx_time_blur(psx_ctx* ctx, int octave, int level, int reps, float* avg_ms, 
  * dispatch (hipExtLaunchKernel: the kernel's start / end timestamps, the quantity rocprofv3 --kernel-trace
  * reports); the launches run back to back with their real producers and consumers, not replayed in isolation.
  * psx_blur_probe_times synchronises and returns the n = L-1 durations (ms) of the last extraction plus the
- * algorithmic bytes of one launch (8 B per octave-0 pixel). */
+ * algorithmic bytes of one launch, averaged over the n launches (8 B per pixel of every plane a launch blurs:
+ * octave 0, and from level 4 on also the level of octave 1 that shares the launch). */
 int psx_enable_blur_probe(psx_ctx* ctx, int on);
 int psx_blur_probe_times(psx_ctx* ctx, float* ms, int capacity, int* n, double* bytes_per_launch);
 

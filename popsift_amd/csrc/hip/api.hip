@@ -150,6 +150,9 @@ struct psx_ctx {
     bool blur_probe = false;
     hipEvent_t ev_blur[2 * PSX_GAUSS_LEVELS] = {};     // [2l], [2l+1]: begin / end of the level-(l+1) kernel
     int  blur_probe_n = 0;             // levels timed in the last extraction
+    double blur_probe_bytes = 0.0;     // algorithmic bytes per timed launch (8 B per pixel of every plane the launch blurs), averaged
+    int  resident_blocks = 1024;       // 4 x compute units
+    bool batch_octaves = true;         // diagonal schedule: two octaves' levels in one launch (POPSIFT_BATCH_OCTAVES=0: one plane per launch)
 };
 
 namespace {
@@ -343,6 +346,7 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     // opt-in: measured on MI355X / ROCm 7.2 the replayed graph is not faster than the 36 stream launches
     // (single frame 0.63 vs 0.63 ms, throughput equal): kernel-to-kernel dependencies cost the same either way
     { const char* g = getenv("POPSIFT_HIP_GRAPH"); n->graph_off = !(g != nullptr && g[0] == '1'); }
+    { const char* g = getenv("POPSIFT_BATCH_OCTAVES"); n->batch_octaves = !(g != nullptr && g[0] == '0'); }
     std::string why;
     int rc = compute_tables(&n->cfg, n->inc_filter, n->inc_span, n->inc_sigma, n->dd_filter, n->dd_span,
                             n->dd_sigma, &why);
@@ -361,6 +365,7 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
         }                                                                                       \
     } while (0)
     PSX_HIPC(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) n->resident_blocks = 4 * cus; }
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_params), sizeof(PsxParams)));
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_params_pin), sizeof(PsxParams), hipHostMallocDefault));
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), sizeof(PsxCounters)));
@@ -582,18 +587,28 @@ int psx_set_input_dev(psx_ctx* ctx, const void* dev_ptr, int w, int h, int is_fl
     return PSX_OK;
 }
 
-static int launch_blur_level(psx_ctx* ctx, int o, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+static PsxBlurJob blur_job(const psx_ctx* ctx, int o, int level)
 {
     const PsxParams& P = ctx->hp;
     const PsxOctave& oc = P.oct[o];
-    float* half_dst = nullptr; int half_pitch = 0;
+    PsxBlurJob j;
+    j.src = oc.data + (size_t)(level - 1) * oc.plane;
+    j.dst = oc.data + (size_t)level * oc.plane;
+    j.half_dst = nullptr; j.half_pitch = 0;
     if (level == P.L - 3 && o + 1 < P.num_octaves) {      // PREV_LEVEL 3, s_pyramid_build.cu:21,228
-        half_dst = P.oct[o + 1].data;
-        half_pitch = P.oct[o + 1].pitch;
+        j.half_dst = P.oct[o + 1].data;
+        j.half_pitch = P.oct[o + 1].pitch;
     }
-    PSX_HIP(psx_launch_blur(oc.data + (size_t)(level - 1) * oc.plane, oc.data + (size_t)level * oc.plane,
-                            oc.w, oc.h, oc.pitch, taps_from(ctx->inc_filter + level * PSX_GAUSS_ALIGN),
-                            ctx->inc_span[level], half_dst, half_pitch, ctx->stream, ev0, ev1));
+    j.W = oc.w; j.H = oc.h; j.pitch = oc.pitch;
+    j.taps = taps_from(ctx->inc_filter + level * PSX_GAUSS_ALIGN);
+    j.span = ctx->inc_span[level];
+    return j;
+}
+
+static int launch_blur_level(psx_ctx* ctx, int o, int level, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+{
+    const PsxBlurJob j = blur_job(ctx, o, level);
+    PSX_HIP(psx_launch_blur(j.src, j.dst, j.W, j.H, j.pitch, j.taps, j.span, j.half_dst, j.half_pitch, ctx->stream, ev0, ev1));
     return PSX_OK;
 }
 
@@ -647,17 +662,50 @@ int psx_build_pyramid(psx_ctx* ctx)
 
     ctx->ext_launched = false;
     const bool probe = ctx->blur_probe;
-    for (int o = 0; o < P.num_octaves; o++) {
-        for (int level = 1; level < P.L; level++) {
-            const bool pl = probe && o == 0;
-            int rc = launch_blur_level(ctx, o, level, pl ? ctx->ev_blur[2 * (level - 1)] : nullptr,
-                                       pl ? ctx->ev_blur[2 * (level - 1) + 1] : nullptr);
-            if (rc != PSX_OK) return rc;
+    // Diagonal schedule.  Level l of octave o only needs level l-1 of the same octave, and level 0 of octave o+1
+    // is written by the launch of level D = L-3 of octave o; so (o, l) can run in launch t = D*o + l, next to
+    // (o-1, l+D).  The small octaves (chains of ~5 us launches when run on their own) ride along with the
+    // launches of the octave above: 17 blur launches instead of 25 for 5 octaves x 6 planes.
+    const int D = P.L - 3, T = D * (P.num_octaves - 1) + P.L - 1;
+    double probe_bytes = 0.0;
+    for (int t = 1; t <= T; t++) {
+        int jo[4], nj = 0;
+        for (int o = 0; o < P.num_octaves && nj < 4; o++) {
+            const int l = t - D * o;
+            if (l >= 1 && l <= P.L - 1) jo[nj++] = o;
         }
-        if (probe && o == 0) ctx->blur_probe_n = P.L - 1;
-        // the six planes of this octave are as cache-resident now as they will ever be
-        if (ctx->interleave) PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+        for (int q = 0; q < nj; q += 2) {
+            const int o = jo[q], level = t - D * o;
+            const bool pl = probe && o == 0;
+            hipEvent_t e0 = pl ? ctx->ev_blur[2 * (level - 1)] : nullptr, e1 = pl ? ctx->ev_blur[2 * (level - 1) + 1] : nullptr;
+            // only when both fit into one round of resident workgroups (4 per CU): behind a launch that fills the
+            // chip the second plane would just queue, and it would run on the larger radius' kernel for nothing
+            bool pair = q + 1 < nj && ctx->batch_octaves;
+            if (pair) {
+                const int o2 = jo[q + 1], level2 = t - D * o2;
+                const int span = ctx->inc_span[level] > ctx->inc_span[level2] ? ctx->inc_span[level] : ctx->inc_span[level2];
+                pair = psx_blur_grid(P.oct[o].w, P.oct[o].h, span) + psx_blur_grid(P.oct[o2].w, P.oct[o2].h, span) <= ctx->resident_blocks;
+            }
+            if (pair) {
+                const int o2 = jo[q + 1], level2 = t - D * o2;
+                PSX_HIP(psx_launch_blur2(blur_job(ctx, o, level), blur_job(ctx, o2, level2), ctx->stream, e0, e1));
+                if (pl) probe_bytes += 8.0 * ((double)P.oct[o].w * P.oct[o].h + (double)P.oct[o2].w * P.oct[o2].h);
+            } else {
+                int rc = launch_blur_level(ctx, o, level, e0, e1);
+                if (rc != PSX_OK) return rc;
+                if (pl) probe_bytes += 8.0 * (double)P.oct[o].w * P.oct[o].h;
+                if (q + 1 < nj) {
+                    rc = launch_blur_level(ctx, jo[q + 1], t - D * jo[q + 1]);
+                    if (rc != PSX_OK) return rc;
+                }
+            }
+        }
+        // an octave's scan right behind its last level: its planes are as cache-resident now as they will ever be
+        for (int q = 0; q < nj; q++)
+            if (t - D * jo[q] == P.L - 1 && ctx->interleave)
+                PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, jo[q], ctx->stream));
     }
+    if (probe) { ctx->blur_probe_n = P.L - 1; ctx->blur_probe_bytes = probe_bytes / (P.L - 1); }
     ctx->ext_launched = ctx->interleave;
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     return PSX_OK;
@@ -1222,7 +1270,7 @@ int psx_blur_probe_times(psx_ctx* ctx, float* ms, int capacity, int* n, double* 
     *n = ctx->blur_probe_n;
     for (int i = 0; i < ctx->blur_probe_n && i < capacity; i++)
         PSX_HIP(hipEventElapsedTime(&ms[i], ctx->ev_blur[2 * i], ctx->ev_blur[2 * i + 1]));
-    if (bytes_per_launch) *bytes_per_launch = 8.0 * (double)ctx->hp.oct[0].w * (double)ctx->hp.oct[0].h;
+    if (bytes_per_launch) *bytes_per_launch = ctx->blur_probe_bytes;
     return PSX_OK;
 }
 

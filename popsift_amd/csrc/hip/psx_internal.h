@@ -103,6 +103,15 @@ hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch
                            const PsxTaps& taps, int span,
                            float* half_dst, int half_pitch, hipStream_t s,
                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// one plane-to-plane blur (levels >= 1); psx_launch_blur2 runs two independent ones in a single launch
+struct PsxBlurJob {
+    const float* src; float* dst; float* half_dst;
+    int W, H, pitch, half_pitch;
+    PsxTaps taps; int span;
+};
+int psx_blur_grid(int W, int H, int span);
+hipError_t psx_launch_blur2(const PsxBlurJob& a, const PsxBlurJob& b, hipStream_t s,
+                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // every non-default branch of Pyramid::build_pyramid (pyramid_alt.hip)
 struct PsxAltArgs {
     const PsxParams* hp;

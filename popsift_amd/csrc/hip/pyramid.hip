@@ -136,8 +136,8 @@ __device__ __forceinline__ void vfilter2x4_km(const v2f* v, const PsxTaps& tp, v
     for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i], tp.g[0], o[i]);
 }
 
-template <int R, bool LEVEL0, bool DEFER = true>
-__global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur(BlurArgs a)
+template <int R, bool LEVEL0, bool DEFER>
+__device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
 {
     using G = Geom2<R>;
     constexpr int HALO = G::HALO, SW4 = G::SW4, NLD = G::NLD, SWA = G::SWA, RING = G::RING;
@@ -147,7 +147,6 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
     __shared__ __attribute__((aligned(16))) float s_ring[(RING + MIRROR) * RS];
 
     const int t     = threadIdx.x;
-    const int lid   = xcd_remap(blockIdx.x, gridDim.x);
     const int strip = lid % a.nstrips;
     const int chunk = lid / a.nstrips;
     const int x0    = strip * TW;
@@ -343,6 +342,23 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
 #endif
 }
 
+template <int R, bool LEVEL0, bool DEFER = true>
+__global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur(BlurArgs a)
+{
+    blur_body<R, LEVEL0, DEFER>(a, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Two independent planes in one launch (the diagonal schedule of psx_build_pyramid: level l of octave o
+// together with level l-3 of octave o+1): the first na logical blocks belong to job a, the rest to job b.
+// Small octaves are latency chains of ~5 us launches; riding along with a larger octave's launch hides them.
+template <int R>
+__global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur2(BlurArgs a, BlurArgs b, int na)
+{
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const bool first = lid < na;
+    blur_body<R, false, true>(first ? a : b, first ? lid : lid - na);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Octave 0, level 0: the reference filters a normalised, clamped, bilinear texture of the input image
 // (s_image.cu:138-167, s_pyramid_build_ra.cu).  Tap k of output (x, y) reads U(x-k, y) and U(x+k, y)
@@ -506,23 +522,44 @@ inline void chunking(int W, int H, int R, int& chunk_rows, int& nchunks)
     nchunks = (H + cr - 1) / cr;
 }
 
+// fills the arguments of one plane-to-plane blur; returns its number of workgroups
+template <int R>
+int fill_job(BlurArgs& a, const PsxBlurJob& j)
+{
+    a.src = j.src; a.dst = j.dst; a.half_dst = j.half_dst;
+    a.W = j.W; a.H = j.H; a.pitch = j.pitch; a.half_pitch = j.half_pitch;
+    a.src_pitch = j.pitch; a.src_xoff = 0; a.src_width = j.W;
+    a.nstrips = (j.W + TW - 1) / TW;
+    int nchunks;
+    chunking(j.W, j.H, R, a.chunk_rows, nchunks);
+    a.taps = j.taps; a.taps_v = j.taps;
+    a.wt = blur_tuning().wt;
+#ifdef PSX_PHASE_TIMING
+    { const char* e = getenv("POPSIFT_BLUR_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
+    return a.nstrips * nchunks;
+}
+
+template <int R>
+hipError_t launch_blur2_r(const PsxBlurJob& ja, const PsxBlurJob& jb, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    BlurArgs a, b;
+    const int na = fill_job<R>(a, ja), nb = fill_job<R>(b, jb);
+    const dim3 grid(na + nb), block(NT);
+    if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((k_blur2<R>), grid, block, 0, s, ev0, ev1, 0, a, b, na);
+    else                                  hipLaunchKernelGGL((k_blur2<R>), grid, block, 0, s, a, b, na);
+    return hipGetLastError();
+}
+
 template <int R>
 hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, const PsxTaps& taps,
                          float* half_dst, int half_pitch, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     BlurArgs a;
-    a.src = src; a.dst = dst; a.half_dst = half_dst;
-    a.W = W; a.H = H; a.pitch = pitch; a.half_pitch = half_pitch;
-    a.src_pitch = pitch; a.src_xoff = 0; a.src_width = W;
-    a.nstrips = (W + TW - 1) / TW;
-    int nchunks;
-    chunking(W, H, R, a.chunk_rows, nchunks);
-    a.taps = taps; a.taps_v = taps;
-    a.wt = blur_tuning().wt;
-#ifdef PSX_PHASE_TIMING
-    { const char* e = getenv("POPSIFT_BLUR_DBG"); a.dbg = e ? atoi(e) : 0; }
-#endif
-    const dim3 grid(a.nstrips * nchunks), block(NT);
+    PsxBlurJob j;
+    j.src = src; j.dst = dst; j.half_dst = half_dst; j.W = W; j.H = H; j.pitch = pitch; j.half_pitch = half_pitch;
+    j.taps = taps; j.span = R + 1;
+    const dim3 grid(fill_job<R>(a, j)), block(NT);
     const bool ext = ev0 != nullptr || ev1 != nullptr;       // kernel begin / end timestamps of THIS dispatch (what rocprofv3 --kernel-trace reports)
     if (blur_tuning().defer) {
         if (ext) hipExtLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, ev0, ev1, 0, a);
@@ -580,6 +617,29 @@ hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch
     if (R <= 16) return launch_blur_r<16>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
     if (R <= 22) return launch_blur_r<22>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
     if (R <= 30) return launch_blur_r<30>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
+    return hipErrorInvalidValue;
+}
+
+// workgroups a blur of a W x H plane is launched with
+int psx_blur_grid(int W, int H, int span)
+{
+    int cr, nchunks;
+    chunking(W, H, span - 1, cr, nchunks);
+    return ((W + TW - 1) / TW) * nchunks;
+}
+
+// two independent blurs in one launch; the kernel is instantiated for the larger radius (zero taps for the other)
+hipError_t psx_launch_blur2(const PsxBlurJob& a, const PsxBlurJob& b, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const int R = (a.span > b.span ? a.span : b.span) - 1;
+    if (R <= 5)  return launch_blur2_r<5>(a, b, s, ev0, ev1);
+    if (R <= 7)  return launch_blur2_r<7>(a, b, s, ev0, ev1);
+    if (R <= 8)  return launch_blur2_r<8>(a, b, s, ev0, ev1);
+    if (R <= 10) return launch_blur2_r<10>(a, b, s, ev0, ev1);
+    if (R <= 13) return launch_blur2_r<13>(a, b, s, ev0, ev1);
+    if (R <= 16) return launch_blur2_r<16>(a, b, s, ev0, ev1);
+    if (R <= 22) return launch_blur2_r<22>(a, b, s, ev0, ev1);
+    if (R <= 30) return launch_blur2_r<30>(a, b, s, ev0, ev1);
     return hipErrorInvalidValue;
 }
 
