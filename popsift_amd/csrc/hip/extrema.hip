@@ -16,6 +16,7 @@ namespace {
 
 constexpr int ETW = 64, ETH = 16;          // tile
 constexpr int TWP = ETW + 2, THP = ETH + 2;
+constexpr int QCAP = 2 * (ETW / 2) * (ETH / 2);   // most strict 3x3 extrema (maxima + minima) one DoG level of a tile can hold
 constexpr int NT = 256;
 
 __device__ __forceinline__ int xcd_remap(int b, int n)
@@ -202,14 +203,17 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     const PsxOctave oc = P->oct[octave];
     const int L = P->L, NL = L - 1, NZ = L - 3;
     float* sD = smem;                                    // [NL][THP][TWP]
-    int*   sQ = reinterpret_cast<int*>(smem + NL * THP * TWP);   // [NZ*ETH*ETW]
-    __shared__ int sCount;
+    // two queues of packed (kind, z, y, x) codes.  A strict extremum of its own 3x3 neighbourhood cannot be
+    // 8-adjacent to another one of the same kind, so a level of the 64x16 tile holds at most QCAP = 2 * 32 * 8.
+    unsigned short* sQ1 = reinterpret_cast<unsigned short*>(smem + NL * THP * TWP);   // in-plane extrema, [NZ*QCAP]
+    unsigned short* sQ  = sQ1 + NZ * QCAP;                                            // 26-neighbour extrema, [NZ*QCAP]
+    __shared__ int sCount, sCount1;
 
     const int t = threadIdx.x;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tx0 = (lid % tiles_x) * ETW;
     const int ty0 = (lid / tiles_x) * ETH;
-    if (t == 0) sCount = 0;
+    if (t == 0) { sCount = 0; sCount1 = 0; }
     STAMP(1);
 
     // ---- stage DoG tile: every thread owns <= NE elements; all their loads are issued before the
@@ -258,11 +262,13 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     const float thr = P->threshold;
     const float thr1 = (MODE == PSX_MODE_OPENCV) ? floorf(thr)
                      : (MODE == PSX_MODE_VLFEAT) ? 0.8f * 2.0f * thr : 1.6f * thr;
-    // Register-tiled: a thread owns 4 vertically adjacent pixels of one column.  Per DoG level it
-    // pulls the 6x3 window of each of the 3 levels (54 LDS reads in flight, one latency), reduces
-    // rows with max3/min3 and tests the 4 pixels against the max / min of their 26 neighbours
-    // (strict, same predicate as is_extremum, s_extrema.cu:56-120).  A wave skips a level when none
-    // of its 256 pixels passes the contrast pre-test.
+    // Two passes.  Pass 1, register-tiled: a thread owns 4 vertically adjacent pixels of one column and per DoG
+    // level pulls the 6x3 window of THAT level only (18 LDS reads in flight), reduces rows with max3/min3 and
+    // queues the pixels that pass the contrast pre-test and are a strict maximum / minimum of their own 3x3
+    // neighbourhood (a few per cent of the tile).  Pass 2, one queued pixel per lane: the 2 x 9 neighbours in the
+    // levels below and above.  Together: the predicate of is_extremum (s_extrema.cu:56-120), strict against all
+    // 26 neighbours.  (Testing all three levels for every pixel, as round 1 did, cost 150 VALU instructions and
+    // 54 LDS reads per thread and level; the kernel's 14 M wave instructions were a tenth of a frame's total.)
     const int lx = t & (ETW - 1);
     const int ly0 = (t >> 6) * 4;
     const int x = tx0 + lx;
@@ -280,33 +286,49 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
         }
         if (__ballot(anyp) == 0ull) continue;
 
-        float mx[3][6], mn[3][6], lft[4], rgt[4], ctr[4];
+        float mx[6], mn[6], lft[4], rgt[4], ctr[4];
 #pragma unroll
-        for (int dz = 0; dz < 3; dz++) {
-#pragma unroll
-            for (int rr = 0; rr < 6; rr++) {
-                const float* q = &sD[((z + dz - 1) * THP + ly0 + rr) * TWP + lx];
-                const float a = q[0], b = q[1], c = q[2];
-                if (dz == 1 && rr >= 1 && rr <= 4) {
-                    // own level: the centre is excluded from its own row
-                    lft[rr - 1] = a; rgt[rr - 1] = c; ctr[rr - 1] = b;
-                }
-                mx[dz][rr] = fmaxf(fmaxf(a, b), c);
-                mn[dz][rr] = fminf(fminf(a, b), c);
-            }
+        for (int rr = 0; rr < 6; rr++) {
+            const float* q = &sD[(z * THP + ly0 + rr) * TWP + lx];
+            const float a = q[0], b = q[1], c = q[2];
+            if (rr >= 1 && rr <= 4) { lft[rr - 1] = a; rgt[rr - 1] = c; ctr[rr - 1] = b; }
+            mx[rr] = fmaxf(fmaxf(a, b), c);
+            mn[rr] = fminf(fminf(a, b), c);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const float v = ctr[r];
-            float M = fmaxf(fmaxf(mx[0][r], mx[0][r + 1]), mx[0][r + 2]);
-            M = fmaxf(M, fmaxf(fmaxf(mx[2][r], mx[2][r + 1]), mx[2][r + 2]));
-            M = fmaxf(M, fmaxf(fmaxf(mx[1][r], mx[1][r + 2]), fmaxf(lft[r], rgt[r])));
-            float N = fminf(fminf(mn[0][r], mn[0][r + 1]), mn[0][r + 2]);
-            N = fminf(N, fminf(fminf(mn[2][r], mn[2][r + 1]), mn[2][r + 2]));
-            N = fminf(N, fminf(fminf(mn[1][r], mn[1][r + 2]), fminf(lft[r], rgt[r])));
-            if (pre[r] && (v > M || v < N)) {
+            const float M = fmaxf(fmaxf(mx[r], mx[r + 2]), fmaxf(lft[r], rgt[r]));     // the centre is excluded from its own row
+            const float N = fminf(fminf(mn[r], mn[r + 2]), fminf(lft[r], rgt[r]));
+            const bool is_max = v > M, is_min = v < N;
+            if (pre[r] && (is_max || is_min)) {
+                const int slot = atomicAdd(&sCount1, 1);
+                sQ1[slot] = (unsigned short)((is_max ? 0x8000 : 0) | (z << 10) | ((ly0 + r) << 6) | lx);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int n1 = sCount1;
+        for (int q = t; q < n1; q += NT) {
+            const int code = sQ1[q];
+            const bool is_max = (code & 0x8000) != 0;
+            const int z = (code >> 10) & 31, ly = (code >> 6) & 15, cx = code & 63;
+            const float v = sD[(z * THP + ly + 1) * TWP + cx + 1];
+            float M = -INFINITY, N = INFINITY;
+#pragma unroll
+            for (int dz = -1; dz <= 1; dz += 2) {
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) {
+                    const float* p = &sD[((z + dz) * THP + ly + rr) * TWP + cx];
+                    const float a = p[0], b = p[1], c = p[2];
+                    M = fmaxf(M, fmaxf(fmaxf(a, b), c));
+                    N = fminf(N, fminf(fminf(a, b), c));
+                }
+            }
+            if (is_max ? (v > M) : (v < N)) {
                 const int slot = atomicAdd(&sCount, 1);
-                sQ[slot] = (z << 16) | ((ly0 + r) << 8) | lx;
+                sQ[slot] = (unsigned short)(code & 0x7fff);
             }
         }
     }
@@ -325,7 +347,7 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
         int cx = 0, ly = 0, z = 0;
         if (have) {
             const int code = sQ[q];
-            z = code >> 16; ly = (code >> 8) & 0xff; cx = code & 0xff;
+            z = (code >> 10) & 31; ly = (code >> 6) & 15; cx = code & 63;
         }
         const unsigned long long mask = __ballot(have);
         if (mask == 0ull) continue;
@@ -417,7 +439,7 @@ hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& hp, Ps
     const int tiles_y = (oc.h + ETH - 1) / ETH;
     const int NL = hp.L - 1, NZ = hp.L - 3;
     if (NZ < 1) return hipSuccess;
-    const size_t smem = sizeof(float) * (size_t)NL * THP * TWP + sizeof(int) * (size_t)NZ * ETH * ETW;
+    const size_t smem = sizeof(float) * (size_t)NL * THP * TWP + 2 * sizeof(unsigned short) * (size_t)NZ * QCAP;
     const dim3 grid(tiles_x * tiles_y), block(NT);
     // levels >= 7 need more than the 64 KiB of dynamic LDS a kernel gets by default (72..107 KB of the 160 KB per CU)
     if (smem > 64 * 1024) {
