@@ -534,7 +534,14 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
             }
             xmin = max(1, xmin); ymin = max(1, ymin);
             xmax = min(width - 2, xmax); ymax = min(height - 2, ymax);
-            const int xs = xmin & ~1;                         // even: aligned pixel pairs
+            // Row spans.  The window is the rotated square -1 < u, v < 4; in a row (dy fixed) that is an interval of
+            // dx from each of the two constraints.  A step covers 8 rows x 8 pixel pairs and every row starts at ITS
+            // span (the bounding box of the rotated square is up to twice its area; walking the box in common
+            // columns left about half of the lanes outside the window).  The spans are conservative by a pixel,
+            // the exact predicate below decides.
+            const bool use_c = fabsf(crsbp) > 1e-6f, use_s = fabsf(srsbp) > 1e-6f;
+            const float rcc = use_c ? 1.0f / crsbp : 0.0f, rcs = use_s ? 1.0f / srsbp : 0.0f;
+            const float fxmin = (float)xmin - x, fxmax = (float)xmax - x;
 
             for (int ty = ymin; ty <= ymax; ty += 8) {
                 const int ii = ty + ly;
@@ -542,9 +549,14 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                 const float ub = fmaf(srsbp, dyk, 1.5f);      // u = crsbp*dx + srsbp*dy + 1.5
                 const float vb = fmaf(crsbp, dyk, 1.5f);      // v = crsbp*dy - srsbp*dx + 1.5
                 const unsigned rowoff = (unsigned)ii * pitch4;
-                const bool rowok = ii <= ymax;
-                for (int tx = xs; tx <= xmax; tx += 16) {
-                    const int jj = tx + 2 * lx;
+                // -1 < u < 4  <=>  crsbp*dx in (-1 - ub, 4 - ub);   -1 < v < 4  <=>  srsbp*dx in (vb - 4, vb + 1)
+                float lo = fxmin, hi = fxmax;
+                if (use_c) { const float t1 = (-1.0f - ub) * rcc, t2 = (4.0f - ub) * rcc; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
+                if (use_s) { const float t1 = (vb - 4.0f) * rcs, t2 = (vb + 1.0f) * rcs; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
+                const int xa = max(xmin, (int)floorf(x + lo) - 1) & ~1;           // even: aligned pixel pairs
+                const int xb = min(xmax, (int)floorf(x + hi) + 2);
+                const bool rowok = ii <= ymax && lo <= hi;
+                for (int jj = xa + 2 * lx; __ballot(rowok && jj <= xb) != 0ull; jj += 16) {
                     const float dx0 = jj - x;
                     const v2f dxk = (v2f){dx0, dx0 + 1.0f};
                     const v2f u = pk_fma(splat(crsbp), dxk, splat(ub));
