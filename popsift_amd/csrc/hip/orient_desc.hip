@@ -478,7 +478,7 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
     // (tests/test_gpu_configs.py::test_descriptor_bins_do_not_overflow_at_large_sigma).
     constexpr int DCOPIES = 4, DTILES = 31, DSTRIDE = DTILES * 16 + 2;         // even: 8-byte aligned copies
     constexpr float DFIX = 16384.0f;
-    __shared__ __attribute__((aligned(8))) unsigned s_desc[WPB][DCOPIES * DSTRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned s_desc[WPB][DCOPIES * DSTRIDE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned* acc = s_desc[wave];
     const int lx = lane & 7, ly = lane >> 3;
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
 
         if (ori_num == 0 && lane == 0) write_feature(P, X, ext_idx, ex, ex.idx_ori, total);
 
-        for (int i = lane; i < DCOPIES * DSTRIDE; i += PSX_WAVE) acc[i] = 0u;
+        static_assert((DCOPIES * DSTRIDE) % 4 == 0, "the accumulators are cleared 16 bytes at a time");
+        for (int i = lane; i < DCOPIES * DSTRIDE / 4; i += PSX_WAVE) reinterpret_cast<uint4*>(acc)[i] = make_uint4(0u, 0u, 0u, 0u);
         wave_fence();
 
         const float x = ex.xpos, y = ex.ypos;
@@ -511,8 +512,10 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
         const unsigned pitch4 = (unsigned)oc.pitch * 4u;
 
         if (SBP != 0.0f) {
-            const float cos_t = cosf(ang);
-            const float sin_t = sinf(ang);
+            // the reference takes __sincosf here (s_desc_loop.cu:38); v_sin_f32 / v_cos_f32 work in revolutions
+            const float rev   = ang * 0.15915494309189535f;
+            const float cos_t = __builtin_amdgcn_cosf(rev);
+            const float sin_t = __builtin_amdgcn_sinf(rev);
             const float csbp  = cos_t * SBP;
             const float ssbp  = sin_t * SBP;
             const float crsbp = cos_t / SBP;
