@@ -19,7 +19,8 @@ def test_copy_bench_and_blur_probe(capi):
     ctx.extract()
     ctx.extract()
     ms_l, by = ctx.blur_probe_times()
-    assert len(ms_l) == ctx.num_levels - 1 and by == 8.0 * 2048 * 1536
+    # 8 B per octave-0 pixel; launches that also carry a level of octave 1 (a quarter of the pixels) count those too
+    assert len(ms_l) == ctx.num_levels - 1 and 8.0 * 2048 * 1536 <= by <= 1.1001 * 8.0 * 2048 * 1536
     assert all(0.0 < m < 5.0 for m in ms_l), ms_l
     # same launches replayed in isolation: same order of magnitude
     iso = [ctx.time_blur(0, l, 10)[0] for l in range(1, ctx.num_levels)]
