@@ -54,7 +54,6 @@ struct BlurArgs {
     int nstrips, chunk_rows;
     PsxTaps taps;               // horizontal taps (and vertical, unless LEVEL0)
     PsxTaps taps_v;             // LEVEL0 only: vertical taps
-    int wt;                     // store scope: 0 plain, 1 agent (write through the XCD's L2), 2 system
 #ifdef PSX_PHASE_TIMING
     int dbg;                    // measurement build only: 1 = all loads from 64 cache-resident rows, 2 = no stores
 #endif
@@ -143,6 +142,7 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
     constexpr int HALO = G::HALO, SW4 = G::SW4, NLD = G::NLD, SWA = G::SWA, RING = G::RING;
     constexpr int VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS;
     constexpr bool LAST_PARTIAL = (BR * SW4) % NT != 0;     // only the last staging slot can be empty
+    constexpr bool FAST_ROWS = R < 13;
     __shared__ __attribute__((aligned(16))) float s_stage[BR * SWA];
     __shared__ __attribute__((aligned(16))) float s_ring[(RING + MIRROR) * RS];
 
@@ -158,6 +158,7 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
 
     // ---- staging geometry of this thread (step invariant) ----
     int st_row[NLD], st_x[NLD], st_lds[NLD];
+    unsigned st_off[NLD];                               // byte offset from the first staged row of a step
 #pragma unroll
     for (int j = 0; j < NLD; j++) {
         const int idx = t + j * NT;
@@ -165,6 +166,7 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
         st_row[j] = row;
         st_x[j]   = x0 - HALO + c4 * 4 + a.src_xoff;
         st_lds[j] = row * SWA + c4 * 4;
+        st_off[j] = FAST_ROWS ? (unsigned)(row * a.src_pitch + st_x[j]) * 4u : 0u;
     }
     const bool last_on = !LAST_PARTIAL || (t + (NLD - 1) * NT < BR * SW4);
 
@@ -199,6 +201,10 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
         v4f pre[NLD];
         auto issue = [&](int k) {
             const int ybase = Y0 - R + k * BR;
+            // workgroup uniform: every staged row of this step exists (all but the first / last chunk of a plane).
+            // Not at R >= 13: the extra per-thread offsets do not fit into 128 VGPRs there.
+            const bool rows_exist = FAST_ROWS && ybase >= 0 && ybase + BR <= a.H;
+            const char* step_base = reinterpret_cast<const char*>(a.src + (ptrdiff_t)ybase * a.src_pitch);
 #pragma unroll
             for (int j = 0; j < NLD; j++) {
                 if (j < NLD - 1 || last_on) {
@@ -207,8 +213,13 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
                     if (a.dbg & 1) y &= 63;
 #endif
                     if (INTERIOR) {
-                        const unsigned off = (unsigned)(y * a.src_pitch + st_x[j]) * 4u;
-                        pre[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.src) + off);
+                        if (rows_exist) {
+                            // no clamp: uniform row base (scalar) + the thread's step-invariant byte offset
+                            pre[j] = *reinterpret_cast<const v4f*>(step_base + st_off[j]);
+                        } else {
+                            const unsigned off = (unsigned)(y * a.src_pitch + st_x[j]) * 4u;
+                            pre[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.src) + off);
+                        }
                     } else {
                         const float* rp = a.src + (size_t)y * a.src_pitch;
                         const int x = st_x[j];
@@ -232,16 +243,15 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
         // registers and are stored at the top of step k+1, behind the commit; by the next wait they are a
         // whole step old.
         v2f pend[4];
-        int pend_k = -1;                                   // step whose results are pending (thread uniform per wave group)
-        auto flush = [&]() {
-            if (pend_k < 0) return;
+        // kk = the step whose results are pending: workgroup uniform, so the row base stays in scalar registers;
+        // threads that skipped the vertical pass of step kk hold rows outside [Y0, Y1) and store nothing, and for
+        // kk = -1 (before the first step) every row lies above Y0
+        auto flush = [&](const int kk) {
 #ifdef PSX_PHASE_TIMING
-            if (a.dbg & 2) { pend_k = -1; return; }
+            if (a.dbg & 2) return;
 #endif
-            const int rel0 = pend_k * BR - 2 * R + v_rg * 4;
-            const int r_out0 = Y0 + rel0;
-            // uniform row base of the step; thread offsets are step invariant
-            char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + pend_k * BR) * a.pitch);
+            const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
+            char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
 #ifdef PSX_PHASE_TIMING
             if (a.dbg & 4) drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(64 + (blockIdx.x & 7) * 40) * a.pitch);   // stores stay in L2
 #endif
@@ -249,28 +259,26 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
             for (int i = 0; i < 4; i++) {
                 const int r_out = r_out0 + i;
                 if (r_out >= Y0 && r_out < Y1 && v_xok) {
-                    char* di = drow + (size_t)i * a.pitch * 4 + v_doff;
-                    // plain stores: non-temporal ones measured 4 % slower in the pipeline (the next level reads these rows)
+                    char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
                     if (v_pair) {
-                        if (a.wt == 0) *reinterpret_cast<v2f*>(di) = pend[i];
-                        else {
-                            unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
-                            if (a.wt == 1) __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            else           __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        }
+                        // system-scope store (sc0 sc1): written through the XCD's L2 while the kernel runs.  Plain
+                        // stores left ~33 MB of dirty lines to be written back after the last wave, inside the
+                        // kernel's duration (17.6 -> 16.9 us per octave-0 launch); agent scope measured the same,
+                        // non-temporal stores 4 % slower (the next level reads these rows).
+                        unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     } else *reinterpret_cast<float*>(di) = pend[i].x;
                     // get_by_2_pick_every_second: rows and columns 0,2,4,.. (v_x is even)
                     if (a.half_dst != nullptr && (r_out & 1) == 0)
                         a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
                 }
             }
-            pend_k = -1;
         };
 
         issue(0);
         for (int k = 0; k < nsteps; k++) {
             commit();
-            flush();
+            if (DEFER) flush(k - 1);
             BSTAMP(0);
             __syncthreads();
             BSTAMP(1);
@@ -317,21 +325,14 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
                     // pin the four results here: otherwise each chain is sunk into its own predicated
                     // store block and runs alone, dependent v_pk_fma_f32 back to back
                     asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-                    if (DEFER) {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) pend[i] = o[i];
-                        pend_k = k;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) pend[i] = o[i];
-                        pend_k = k;
-                        flush();
-                    }
+                    for (int i = 0; i < 4; i++) pend[i] = o[i];
                 }
             }
+            if (!DEFER) flush(k);
             BSTAMP(4);
         }
-        flush();
+        if (DEFER) flush(nsteps - 1);
     };
     if (interior) run(std::true_type{}); else run(std::false_type{});
 #ifdef PSX_PHASE_TIMING
@@ -355,8 +356,10 @@ template <int R>
 __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur2(BlurArgs a, BlurArgs b, int na)
 {
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const bool first = lid < na;
-    blur_body<R, false, true>(first ? a : b, first ? lid : lid - na);
+    // two inlined copies: selecting the arguments through a pointer moves the taps out of the preloaded
+    // kernel-argument SGPRs (120 bytes of VGPR spills at R = 13)
+    if (lid < na) blur_body<R, false, true>(a, lid);
+    else          blur_body<R, false, true>(b, lid - na);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -487,18 +490,14 @@ __global__ void k_dog(const float* a, const float* b, float* d, int W, int H, in
 }
 
 // Tuning switches for A/B measurements on the GPU (read once): POPSIFT_BLUR_STEPS = marching steps per chunk
-// on large planes (default 5), POPSIFT_BLUR_DEFER=0 stores the vertical results at once (the round-1 kernel),
-// POPSIFT_BLUR_WT = scope of the plane stores (0 plain, 1 agent, 2 system; default 2).  Scoped stores write
-// through the XCD's L2 while the kernel runs; plain stores leave ~33 MB of dirty lines that are written back
-// when the kernel ends, after the last wave (measured: 17.6 -> 16.9 us per octave-0 launch).
-struct BlurTuning { int steps; bool defer; int wt; };
+// on large planes (default 5), POPSIFT_BLUR_DEFER=0 stores the vertical results at once (the round-1 kernel).
+struct BlurTuning { int steps; bool defer; };
 inline const BlurTuning& blur_tuning()
 {
     static const BlurTuning t = [] {
-        BlurTuning v{5, true, 2};
+        BlurTuning v{5, true};
         if (const char* e = getenv("POPSIFT_BLUR_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_DEFER")) v.defer = e[0] != '0';
-        if (const char* e = getenv("POPSIFT_BLUR_WT")) v.wt = atoi(e);
         return v;
     }();
     return t;
@@ -533,7 +532,6 @@ int fill_job(BlurArgs& a, const PsxBlurJob& j)
     int nchunks;
     chunking(j.W, j.H, R, a.chunk_rows, nchunks);
     a.taps = j.taps; a.taps_v = j.taps;
-    a.wt = blur_tuning().wt;
 #ifdef PSX_PHASE_TIMING
     { const char* e = getenv("POPSIFT_BLUR_DBG"); a.dbg = e ? atoi(e) : 0; }
 #endif
@@ -592,7 +590,6 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
     int nchunks;
     chunking(h.W, h.H, R, a.chunk_rows, nchunks);
     a.taps = h.taps_h; a.taps_v = h.taps_v;
-    a.wt = blur_tuning().wt;
 #ifdef PSX_PHASE_TIMING
     a.dbg = 0;
 #endif
