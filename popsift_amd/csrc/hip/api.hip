@@ -663,31 +663,43 @@ int psx_build_pyramid(psx_ctx* ctx)
     ctx->ext_launched = false;
     const bool probe = ctx->blur_probe;
     // Diagonal schedule.  Level l of octave o only needs level l-1 of the same octave, and level 0 of octave o+1
-    // is written by the launch of level D = L-3 of octave o; so (o, l) can run in launch t = D*o + l, next to
-    // (o-1, l+D).  The small octaves (chains of ~5 us launches when run on their own) ride along with the
-    // launches of the octave above: 17 blur launches instead of 25 for 5 octaves x 6 planes.
-    const int D = P.L - 3, T = D * (P.num_octaves - 1) + P.L - 1;
+    // is written by the launch of level D = L-3 of octave o; so octave o+1 may start D launch slots after octave
+    // o, and (o+1, l) then shares ONE launch with (o, l+D) -- if the two planes fit one round of resident
+    // workgroups (4 per CU).  The small octaves, chains of ~5 us launches on their own, ride along with the octave
+    // above.  Where the pair does not fit (octave 0 / 1 of a 1080p frame) the smaller plane would only queue behind
+    // a full chip, run on the larger radius' kernel for nothing and push the larger octave's planes out of L2
+    // between its own levels: there octave o+1 starts after octave o's last level.
+    const int D = P.L - 3;
+    int t0[PSX_MAX_OCTAVES];                       // level l of octave o runs in launch slot t0[o] + l
+    t0[0] = 0;
+    for (int o = 0; o + 1 < P.num_octaves; o++) {
+        const int span = ctx->inc_span[P.L - 1];
+        const bool fits = ctx->batch_octaves &&
+            psx_blur_grid(P.oct[o].w, P.oct[o].h, span) + psx_blur_grid(P.oct[o + 1].w, P.oct[o + 1].h, span) <= ctx->resident_blocks;
+        t0[o + 1] = t0[o] + (fits ? D : P.L - 1);
+    }
+    const int T = t0[P.num_octaves - 1] + P.L - 1;
     double probe_bytes = 0.0;
     for (int t = 1; t <= T; t++) {
         int jo[4], nj = 0;
         for (int o = 0; o < P.num_octaves && nj < 4; o++) {
-            const int l = t - D * o;
+            const int l = t - t0[o];
             if (l >= 1 && l <= P.L - 1) jo[nj++] = o;
         }
         for (int q = 0; q < nj; q += 2) {
-            const int o = jo[q], level = t - D * o;
+            const int o = jo[q], level = t - t0[o];
             const bool pl = probe && o == 0;
             hipEvent_t e0 = pl ? ctx->ev_blur[2 * (level - 1)] : nullptr, e1 = pl ? ctx->ev_blur[2 * (level - 1) + 1] : nullptr;
             // only when both fit into one round of resident workgroups (4 per CU): behind a launch that fills the
             // chip the second plane would just queue, and it would run on the larger radius' kernel for nothing
             bool pair = q + 1 < nj && ctx->batch_octaves;
             if (pair) {
-                const int o2 = jo[q + 1], level2 = t - D * o2;
+                const int o2 = jo[q + 1], level2 = t - t0[o2];
                 const int span = ctx->inc_span[level] > ctx->inc_span[level2] ? ctx->inc_span[level] : ctx->inc_span[level2];
                 pair = psx_blur_grid(P.oct[o].w, P.oct[o].h, span) + psx_blur_grid(P.oct[o2].w, P.oct[o2].h, span) <= ctx->resident_blocks;
             }
             if (pair) {
-                const int o2 = jo[q + 1], level2 = t - D * o2;
+                const int o2 = jo[q + 1], level2 = t - t0[o2];
                 PSX_HIP(psx_launch_blur2(blur_job(ctx, o, level), blur_job(ctx, o2, level2), ctx->stream, e0, e1));
                 if (pl) probe_bytes += 8.0 * ((double)P.oct[o].w * P.oct[o].h + (double)P.oct[o2].w * P.oct[o2].h);
             } else {
@@ -695,14 +707,14 @@ int psx_build_pyramid(psx_ctx* ctx)
                 if (rc != PSX_OK) return rc;
                 if (pl) probe_bytes += 8.0 * (double)P.oct[o].w * P.oct[o].h;
                 if (q + 1 < nj) {
-                    rc = launch_blur_level(ctx, jo[q + 1], t - D * jo[q + 1]);
+                    rc = launch_blur_level(ctx, jo[q + 1], t - t0[jo[q + 1]]);
                     if (rc != PSX_OK) return rc;
                 }
             }
         }
         // an octave's scan right behind its last level: its planes are as cache-resident now as they will ever be
         for (int q = 0; q < nj; q++)
-            if (t - D * jo[q] == P.L - 1 && ctx->interleave)
+            if (t - t0[jo[q]] == P.L - 1 && ctx->interleave)
                 PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, jo[q], ctx->stream));
     }
     if (probe) { ctx->blur_probe_n = P.L - 1; ctx->blur_probe_bytes = probe_bytes / (P.L - 1); }
