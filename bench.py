@@ -167,7 +167,10 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if backend_cls.dist_backend == "nccl":
+                dist.barrier(device_ids=[local_rank])      # RCCL: name the rank's device explicitly
+            else:
+                dist.barrier()
         be.sync()
 
     def reduce_max_sum(dt, kps):
@@ -279,7 +282,7 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
 
     be.abi_close()
     if dist is not None:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     return result
 
