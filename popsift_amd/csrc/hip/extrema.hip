@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
 // candidate per lane, DoG values read from the Gaussian planes (L2 resident: the tile kernels have just
 // streamed them).  Survivors are compacted with a 64-bit wave ballot and one atomicAdd per wave
 // (wave64 re-design of extrema_count, s_extrema.cu:22-44).
-constexpr int REFINE_SPLIT = 4;
+constexpr int REFINE_SPLIT = 2;       // waves per (octave, sub-list): 1, 2, 4, 8, 16 measured, extrema stage 0.112 / 0.106 / 0.109 / 0.128 / 0.133 ms
 
 template <int MODE>
 __global__ __launch_bounds__(64) void k_refine(const PsxParams* __restrict__ P, PsxCounters* cnt)
