@@ -612,6 +612,16 @@ static int launch_blur_level(psx_ctx* ctx, int o, int level, hipEvent_t ev0 = nu
     return PSX_OK;
 }
 
+// extrema scans of a set of octaves, PSX_EXT_BATCH per launch
+static int launch_extrema_set(psx_ctx* ctx, const int* octaves, int n)
+{
+    for (int i = 0; i < n; i += PSX_EXT_BATCH) {
+        const int m = n - i < PSX_EXT_BATCH ? n - i : PSX_EXT_BATCH;
+        PSX_HIP(psx_launch_extrema_batch(ctx->d_params, ctx->hp, ctx->d_cnt, octaves + i, m, ctx->stream));
+    }
+    return PSX_OK;
+}
+
 int psx_build_pyramid(psx_ctx* ctx)
 {
     if (!ctx) return PSX_ERR_INVALID;
@@ -680,6 +690,7 @@ int psx_build_pyramid(psx_ctx* ctx)
     }
     const int T = t0[P.num_octaves - 1] + P.L - 1;
     double probe_bytes = 0.0;
+    int deferred[PSX_MAX_OCTAVES], ndef = 0;
     for (int t = 1; t <= T; t++) {
         int jo[4], nj = 0;
         for (int o = 0; o < P.num_octaves && nj < 4; o++) {
@@ -712,11 +723,17 @@ int psx_build_pyramid(psx_ctx* ctx)
                 }
             }
         }
-        // an octave's scan right behind its last level: its planes are as cache-resident now as they will ever be
+        // a large octave's scan right behind its last level: its planes are as cache-resident now as they will ever
+        // be.  The small octaves' scans (a few hundred tiles each, latency-bound launches) wait and share one launch.
         for (int q = 0; q < nj; q++)
-            if (t - t0[jo[q]] == P.L - 1 && ctx->interleave)
-                PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, jo[q], ctx->stream));
+            if (t - t0[jo[q]] == P.L - 1 && ctx->interleave) {
+                if (psx_extrema_tiles(P, jo[q]) >= ctx->resident_blocks)
+                    PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, jo[q], ctx->stream));
+                else
+                    deferred[ndef++] = jo[q];
+            }
     }
+    if (ndef > 0) { int rc = launch_extrema_set(ctx, deferred, ndef); if (rc != PSX_OK) return rc; }
     if (probe) { ctx->blur_probe_n = P.L - 1; ctx->blur_probe_bytes = probe_bytes / (P.L - 1); }
     ctx->ext_launched = ctx->interleave;
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -768,9 +785,16 @@ int psx_find_extrema(psx_ctx* ctx)
     if (!ctx) return PSX_ERR_INVALID;
     if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_find_extrema: no pyramid");
     PSX_HIP(hipSetDevice(ctx->device));
-    if (!ctx->ext_launched)
-        for (int o = 0; o < ctx->hp.num_octaves; o++)
-            PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+    if (!ctx->ext_launched) {
+        int small[PSX_MAX_OCTAVES], ns = 0;
+        for (int o = 0; o < ctx->hp.num_octaves; o++) {
+            if (psx_extrema_tiles(ctx->hp, o) >= ctx->resident_blocks)
+                PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+            else
+                small[ns++] = o;
+        }
+        if (ns > 0) { int rc = launch_extrema_set(ctx, small, ns); if (rc != PSX_OK) return rc; }
+    }
     ctx->ext_launched = false;
     PSX_HIP(psx_launch_refine(ctx->d_params, ctx->hp, ctx->d_cnt, ctx->stream));
     ctx->filtered = false;

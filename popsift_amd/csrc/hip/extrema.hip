@@ -195,10 +195,16 @@ __device__ long long* g_dbg = nullptr;
 #endif
 
 template <int MODE>
-__global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P, PsxCounters* cnt, int octave,
-                                                int tiles_x)
+__global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P, PsxCounters* cnt, const PsxExtBatch b)
 {
     STAMP(0);
+    // the tiles of up to PSX_EXT_BATCH octaves share the launch (the small octaves: 36 .. 510 tiles each would be
+    // three latency-bound launches); logical tile ids are octave-major
+    const int glid = xcd_remap(blockIdx.x, gridDim.x);
+    int bk = 0;
+    while (bk + 1 < b.n && glid >= b.tile_end[bk]) bk++;
+    const int octave = b.octave[bk], tiles_x = b.tiles_x[bk];
+    const int lid = glid - (bk > 0 ? b.tile_end[bk - 1] : 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const PsxOctave oc = P->oct[octave];
     const int L = P->L, NL = L - 1, NZ = L - 3;
@@ -210,7 +216,6 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     __shared__ int sCount, sCount1;
 
     const int t = threadIdx.x;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tx0 = (lid % tiles_x) * ETW;
     const int ty0 = (lid / tiles_x) * ETH;
     if (t == 0) { sCount = 0; sCount1 = 0; }
@@ -431,16 +436,25 @@ __global__ __launch_bounds__(64) void k_refine(const PsxParams* __restrict__ P, 
 extern "C" void psx_debug_set_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &d, sizeof(d)); }
 #endif
 
-hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& hp, PsxCounters* d_cnt,
-                              int octave, hipStream_t s)
+hipError_t psx_launch_extrema_batch(const PsxParams* d_params, const PsxParams& hp, PsxCounters* d_cnt,
+                                    const int* octaves, int n, hipStream_t s)
 {
-    const PsxOctave& oc = hp.oct[octave];
-    const int tiles_x = (oc.w + ETW - 1) / ETW;
-    const int tiles_y = (oc.h + ETH - 1) / ETH;
     const int NL = hp.L - 1, NZ = hp.L - 3;
-    if (NZ < 1) return hipSuccess;
+    if (NZ < 1 || n < 1) return hipSuccess;
+    if (n > PSX_EXT_BATCH) return hipErrorInvalidValue;
+    PsxExtBatch b;
+    b.n = n;
+    int tiles = 0;
+    for (int k = 0; k < PSX_EXT_BATCH; k++) {
+        const int o = octaves[k < n ? k : n - 1];
+        const PsxOctave& oc = hp.oct[o];
+        b.octave[k] = o;
+        b.tiles_x[k] = (oc.w + ETW - 1) / ETW;
+        if (k < n) tiles += b.tiles_x[k] * ((oc.h + ETH - 1) / ETH);
+        b.tile_end[k] = tiles;
+    }
     const size_t smem = sizeof(float) * (size_t)NL * THP * TWP + 2 * sizeof(unsigned short) * (size_t)NZ * QCAP;
-    const dim3 grid(tiles_x * tiles_y), block(NT);
+    const dim3 grid(tiles), block(NT);
     // levels >= 7 need more than the 64 KiB of dynamic LDS a kernel gets by default (72..107 KB of the 160 KB per CU)
     if (smem > 64 * 1024) {
         hipError_t e = hipSuccess;
@@ -452,17 +466,24 @@ hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& hp, Ps
         if (e != hipSuccess) return e;
     }
     switch (hp.sift_mode) {
-    case PSX_MODE_VLFEAT:
-        hipLaunchKernelGGL(k_extrema<PSX_MODE_VLFEAT>, grid, block, smem, s, d_params, d_cnt, octave, tiles_x);
-        break;
-    case PSX_MODE_OPENCV:
-        hipLaunchKernelGGL(k_extrema<PSX_MODE_OPENCV>, grid, block, smem, s, d_params, d_cnt, octave, tiles_x);
-        break;
-    default:
-        hipLaunchKernelGGL(k_extrema<PSX_MODE_POPSIFT>, grid, block, smem, s, d_params, d_cnt, octave, tiles_x);
-        break;
+    case PSX_MODE_VLFEAT: hipLaunchKernelGGL(k_extrema<PSX_MODE_VLFEAT>, grid, block, smem, s, d_params, d_cnt, b); break;
+    case PSX_MODE_OPENCV: hipLaunchKernelGGL(k_extrema<PSX_MODE_OPENCV>, grid, block, smem, s, d_params, d_cnt, b); break;
+    default:              hipLaunchKernelGGL(k_extrema<PSX_MODE_POPSIFT>, grid, block, smem, s, d_params, d_cnt, b); break;
     }
     return hipGetLastError();
+}
+
+hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& hp, PsxCounters* d_cnt,
+                              int octave, hipStream_t s)
+{
+    return psx_launch_extrema_batch(d_params, hp, d_cnt, &octave, 1, s);
+}
+
+// tiles of one octave (what decides whether its scan is worth a launch of its own)
+int psx_extrema_tiles(const PsxParams& hp, int octave)
+{
+    const PsxOctave& oc = hp.oct[octave];
+    return ((oc.w + ETW - 1) / ETW) * ((oc.h + ETH - 1) / ETH);
 }
 
 hipError_t psx_launch_refine(const PsxParams* d_params, const PsxParams& hp, PsxCounters* d_cnt, hipStream_t s)

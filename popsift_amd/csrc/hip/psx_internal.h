@@ -127,6 +127,12 @@ struct PsxAltArgs {
 };
 hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s);
 hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s);
+// k_extrema scans the tiles of up to PSX_EXT_BATCH octaves in one launch
+#define PSX_EXT_BATCH 4
+struct PsxExtBatch { int n; int octave[PSX_EXT_BATCH]; int tiles_x[PSX_EXT_BATCH]; int tile_end[PSX_EXT_BATCH]; };
+hipError_t psx_launch_extrema_batch(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt,
+                                    const int* octaves, int n, hipStream_t s);
+int psx_extrema_tiles(const PsxParams& h_params, int octave);
 hipError_t psx_launch_extrema(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt,
                               int octave, hipStream_t s);
 hipError_t psx_launch_refine(const PsxParams* d_params, const PsxParams& h_params, PsxCounters* d_cnt, hipStream_t s);
