@@ -265,12 +265,14 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // Exclusive scan of num_ori over all extrema (octave-major) -> idx_ori, feat_to_ext map, counters.
-// One 1024-thread workgroup; every thread owns a contiguous run of K = ceil(total/1024) extrema
-// (sequential partial sum), one block-level scan of the 1024 partial sums (wave __shfl_up + 16
-// wave totals), then a second sequential pass writes the results.  Replaces the reference's
-// 32x32-thread ExclusivePrefixSum::Block (excl_blk_prefix_sum.h:34-145).
+// SCAN_WGS workgroups of 1024 threads; workgroup b owns the b-th contiguous segment of the extrema.  It first
+// sums num_ori of everything in front of its segment (a few int4 loads per thread, L2 resident), then scans its
+// own segment (4 extrema per thread and pass: wave __shfl_up + 16 wave totals) and writes the results.  No
+// workgroup waits for another one; the last workgroup also knows the grand total and writes the frame counters.
+// (One workgroup for the whole list, round 1, was a 22 us chain of dependent passes and ~1 MB of writes from one CU.)
+// Replaces the reference's 32x32-thread ExclusivePrefixSum::Block (excl_blk_prefix_sum.h:34-145).
 // ---------------------------------------------------------------------------------------------
-constexpr int SCAN_NT = 1024;
+constexpr int SCAN_NT = 1024, SCAN_WGS = 16;
 
 __device__ __forceinline__ void write_feature(const PsxParams* P, const PsxExport& X, int i, const psx_extremum& ex, int excl, int limit)
 {
@@ -295,11 +297,12 @@ __device__ __forceinline__ void write_feature(const PsxParams* P, const PsxExpor
 __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ P, PsxCounters* cnt, const PsxExport X)
 {
     __shared__ int s_wsum[SCAN_NT / PSX_WAVE];
-    __shared__ int s_total;
+    __shared__ int s_total, s_base;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x;
+    const bool last_wg = b == SCAN_WGS - 1;
 
-    // per-octave prefix sums: lane o of the first wave owns octave o (a serial loop of dependent global
-    // loads in one thread cost ~10 us here and ~20 us in the epilogue)
+    // per-octave prefix sums of the extrema counts: lane o of the first wave owns octave o
     if (wave == 0) {
         const int c = (lane < P->num_octaves) ? ext_count(P, cnt, lane) : 0;
         int v = c;
@@ -308,12 +311,12 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
             const int u = __shfl_up(v, off);
             if (lane >= off) v += u;
         }
-        if (lane < PSX_MAX_OCTAVES) cnt->ext_ps[lane] = v - c;
         const int ps = __shfl(v, PSX_MAX_OCTAVES - 1);
-        if (lane == 0) {
-            cnt->ext_ps[PSX_MAX_OCTAVES] = ps;
-            s_total = min(ps, P->ext_capacity);
+        if (b == 0) {
+            if (lane < PSX_MAX_OCTAVES) cnt->ext_ps[lane] = v - c;
+            if (lane == 0) cnt->ext_ps[PSX_MAX_OCTAVES] = ps;
         }
+        if (lane == 0) s_total = min(ps, P->ext_capacity);
     }
     __syncthreads();
     const int total = s_total;
@@ -325,22 +328,45 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
     int rule = max(2 * P->max_extrema, P->max_extrema + P->max_extrema / 4);
     if (total > P->max_extrema) rule = max(rule, 2 * ((total + 1024) & ~1023));
     const int cap = min(P->ori_capacity, rule);
-    const int* nori = P->ext_nori;
-    // every thread owns SCAN_K consecutive extrema per pass; all 4 int4 loads are in flight at once
-    constexpr int SCAN_K = 16;
-    int carry = 0;
-    for (int base = 0; base < total; base += SCAN_NT * SCAN_K) {
-        const int i0 = base + t * SCAN_K;
-        int nv[SCAN_K];
-#pragma unroll
-        for (int q = 0; q < SCAN_K / 4; q++) {
-            int4 v4 = make_int4(0, 0, 0, 0);
-            if (i0 + 4 * q < total) v4 = reinterpret_cast<const int4*>(nori + i0)[q];   // buffer padded to x16
-            nv[4 * q + 0] = v4.x; nv[4 * q + 1] = v4.y; nv[4 * q + 2] = v4.z; nv[4 * q + 3] = v4.w;
+    const int* nori = P->ext_nori;                 // padded to a multiple of 16 entries
+
+    // segment of this workgroup: multiples of 16 extrema, so that int4 loads never straddle a boundary
+    const int seg_len = (((total + SCAN_WGS - 1) / SCAN_WGS) + 15) & ~15;
+    const int seg_start = b * seg_len;
+    const int seg_end = min(seg_start + seg_len, total);
+    if (seg_start >= total && !last_wg) return;
+
+    // ---- everything in front of the segment ----
+    {
+        const int lim = min(seg_start, total);
+        int acc = 0;
+        for (int i = t * 4; i < lim; i += SCAN_NT * 4) {
+            const int4 v4 = *reinterpret_cast<const int4*>(nori + i);
+            acc += v4.x + ((i + 1 < lim) ? v4.y : 0) + ((i + 2 < lim) ? v4.z : 0) + ((i + 3 < lim) ? v4.w : 0);
         }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) s_wsum[wave] = acc;
+        __syncthreads();
+        if (t == 0) {
+            int sum = 0;
+            for (int w = 0; w < SCAN_NT / PSX_WAVE; w++) sum += s_wsum[w];
+            s_base = sum;
+        }
+        __syncthreads();
+    }
+
+    // ---- the segment: SCAN_K consecutive extrema per thread and pass ----
+    constexpr int SCAN_K = 4;
+    int carry = s_base;
+    for (int pbase = seg_start; pbase < seg_end; pbase += SCAN_NT * SCAN_K) {
+        const int i0 = pbase + t * SCAN_K;
+        int4 v4 = make_int4(0, 0, 0, 0);
+        if (i0 < seg_end) v4 = *reinterpret_cast<const int4*>(nori + i0);
+        int nv[SCAN_K] = {v4.x, v4.y, v4.z, v4.w};
         int local = 0;
 #pragma unroll
-        for (int k = 0; k < SCAN_K; k++) { if (i0 + k >= total) nv[k] = 0; local += nv[k]; }
+        for (int k = 0; k < SCAN_K; k++) { if (i0 + k >= seg_end) nv[k] = 0; local += nv[k]; }
 
         int v = local;
 #pragma unroll
@@ -348,7 +374,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
             const int u = __shfl_up(v, off);
             if (lane >= off) v += u;
         }
-        __syncthreads();                      // s_wsum free (previous pass finished reading)
+        __syncthreads();                      // s_wsum free (previous pass / the prologue finished reading)
         if (lane == PSX_WAVE - 1) s_wsum[wave] = v;
         __syncthreads();
         if (wave == 0) {
@@ -366,7 +392,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
 #pragma unroll
         for (int k = 0; k < SCAN_K; k++) {
             const int i = i0 + k;
-            if (i < total) {
+            if (i < seg_end) {
                 const int n = nv[k];
                 P->extrema[i].idx_ori = excl;
                 for (int q = 0; q < n; q++)
@@ -380,28 +406,13 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
             }
         }
     }
-    const int grand = carry;
-    __syncthreads();
-    if (wave == 0) {
+    if (last_wg && t == 0) {
+        const int grand = carry;                   // everything in front + the last segment
         const int ori_total = min(grand, cap);
-        if (lane == 0) {
-            cnt->ext_total = total;
-            cnt->ori_total = ori_total;
-            cnt->ori_raw = min(grand, rule);   // what the frame needs: the host grows the descriptor buffers up to it
-            if (X.counts != nullptr) { X.counts[0] = total; X.counts[1] = ori_total; X.counts[2] = min(grand, rule); }
-        }
-        // per-octave orientation counts (dct.ori_ct / ori_ps, s_orientation.cu:340-360), lane o = octave o
-        int ps = ori_total;
-        if (lane < PSX_MAX_OCTAVES) {
-            const int fe = cnt->ext_ps[lane];          // written by this lane above
-            ps = (fe < total) ? min(P->extrema[fe].idx_ori, ori_total) : ori_total;
-        }
-        const int nxt = __shfl_down(ps, 1);
-        if (lane < PSX_MAX_OCTAVES) {
-            cnt->ori_ps[lane] = ps;
-            cnt->ori_ct[lane] = ((lane == PSX_MAX_OCTAVES - 1) ? ori_total : nxt) - ps;
-        }
-        if (lane == 0) cnt->ori_ps[PSX_MAX_OCTAVES] = ori_total;
+        cnt->ext_total = total;
+        cnt->ori_total = ori_total;
+        cnt->ori_raw = min(grand, rule);           // what the frame needs: the host grows the descriptor buffers up to it
+        if (X.counts != nullptr) { X.counts[0] = total; X.counts[1] = ori_total; X.counts[2] = min(grand, rule); }
     }
 }
 
@@ -921,7 +932,7 @@ hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt,
 
 hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, const PsxExport& x, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_NT), 0, s, d_params, d_cnt, x);
+    hipLaunchKernelGGL(k_scan, dim3(SCAN_WGS), dim3(SCAN_NT), 0, s, d_params, d_cnt, x);
     return hipGetLastError();
 }
 

@@ -75,8 +75,6 @@ struct PsxExport {
 struct PsxCounters {
     int ext_ct[PSX_MAX_OCTAVES];   // raw atomic counters (may exceed max_extrema)
     int ext_ps[PSX_MAX_OCTAVES + 1];
-    int ori_ct[PSX_MAX_OCTAVES];
-    int ori_ps[PSX_MAX_OCTAVES + 1];
     int ext_total;
     int ori_total;
     int ori_raw;                   // orientations before the clamp to ori_capacity
