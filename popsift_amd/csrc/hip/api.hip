@@ -70,6 +70,8 @@ void blur_table(int mode, int nlev, const float* sigma, int* span, float* filter
 
 } // namespace
 
+constexpr size_t CNT_BLOCK = 512;      // bytes reserved for PsxCounters in front of the candidate counters
+
 struct psx_ctx {
     int         device = 0;
     psx_config  cfg{};
@@ -113,7 +115,7 @@ struct psx_ctx {
     psx_iext* d_iext = nullptr;        size_t iext_cap = 0;
     int* d_iext_off = nullptr;         size_t iext_off_cap = 0;
     unsigned long long* d_cand = nullptr; size_t cand_cap = 0;
-    int* d_cand_ct = nullptr;          size_t cand_ct_cap = 0;
+    int* d_cand_ct = nullptr;          // behind d_cnt in the same allocation
     psx_extremum* d_extrema = nullptr; size_t extrema_cap = 0;
     psx_feature* d_features = nullptr; size_t features_cap = 0;
     float* d_desc = nullptr;           size_t desc_cap = 0;       // floats
@@ -368,9 +370,12 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) n->resident_blocks = 4 * cus; }
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_params), sizeof(PsxParams)));
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_params_pin), sizeof(PsxParams), hipHostMallocDefault));
-    PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), sizeof(PsxCounters)));
+    // frame counters and the candidate sub-list counters in ONE allocation: one fill kernel clears both per frame
+    static_assert(sizeof(PsxCounters) <= CNT_BLOCK, "PsxCounters outgrew its slot");
+    PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), CNT_BLOCK + sizeof(int) * (size_t)PSX_MAX_OCTAVES * PSX_CAND_SUB * 32));
+    n->d_cand_ct = reinterpret_cast<int*>(reinterpret_cast<char*>(n->d_cnt) + CNT_BLOCK);
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_cnt), sizeof(PsxCounters), hipHostMallocDefault));
-    PSX_HIPC(hipMemset(n->d_cnt, 0, sizeof(PsxCounters)));
+    PSX_HIPC(hipMemset(n->d_cnt, 0, CNT_BLOCK + sizeof(int) * (size_t)PSX_MAX_OCTAVES * PSX_CAND_SUB * 32));
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_xcnt), 4 * sizeof(int), hipHostMallocDefault));
     n->h_xcnt[0] = n->h_xcnt[1] = n->h_xcnt[2] = n->h_xcnt[3] = 0;
     for (int i = 0; i < 5; i++) PSX_HIPC(hipEventCreate(&n->ev[i]));
@@ -396,7 +401,7 @@ int psx_destroy(psx_ctx* ctx)
     (void)hipFree(ctx->d_intm); (void)hipFree(ctx->d_vbuf);
     (void)hipFree(ctx->d_gf_keys); (void)hipFree(ctx->d_gf_vals); (void)hipFree(ctx->d_gf_temp);
     (void)hipFree(ctx->d_gf_scratch);
-    (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off); (void)hipFree(ctx->d_cand); (void)hipFree(ctx->d_cand_ct);
+    (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off); (void)hipFree(ctx->d_cand);
     (void)hipFree(ctx->d_extrema); (void)hipFree(ctx->d_features);
     (void)hipFree(ctx->d_desc); (void)hipFree(ctx->d_feat_to_ext); (void)hipFree(ctx->d_ext_nori);
     for (int i = 0; i < 5; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -494,7 +499,6 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     // split over PSX_CAND_SUB sub-lists; a candidate that finds its sub-list full is refined in place
     P.cand_capacity = (4 * c.max_extrema + PSX_CAND_SUB - 1) / PSX_CAND_SUB;
     if ((rc = grow(ctx, &ctx->d_cand, &ctx->cand_cap, (size_t)P.num_octaves * PSX_CAND_SUB * P.cand_capacity)) != PSX_OK) return rc;
-    if ((rc = grow(ctx, &ctx->d_cand_ct, &ctx->cand_ct_cap, (size_t)P.num_octaves * PSX_CAND_SUB * 32)) != PSX_OK) return rc;
     P.cand_ct = ctx->d_cand_ct;
     if ((rc = grow(ctx, &ctx->d_extrema, &ctx->extrema_cap, iext_need)) != PSX_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_features, &ctx->features_cap, iext_need)) != PSX_OK) return rc;
@@ -632,8 +636,7 @@ int psx_build_pyramid(psx_ctx* ctx)
     ctx->counts_valid = false;
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     // Pyramid::reset_extrema_mgmt, sift_pyramid.cu:364-371
-    PSX_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(PsxCounters), ctx->stream));
-    PSX_HIP(hipMemsetAsync(ctx->d_cand_ct, 0, sizeof(int) * (size_t)P.num_octaves * PSX_CAND_SUB * 32, ctx->stream));
+    PSX_HIP(hipMemsetAsync(ctx->d_cnt, 0, CNT_BLOCK + sizeof(int) * (size_t)P.num_octaves * PSX_CAND_SUB * 32, ctx->stream));
 
     if (ctx->alt_pyramid) {
         PsxAltArgs q;
