@@ -105,6 +105,10 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
 }
 
 typedef const __attribute__((address_space(1))) float* gfloat_p;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) v2f* gv2f_p;
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
 // clamped per-octave extrema count (find_extrema_in_dog's atomicMin, s_extrema.cu:553)
 __device__ __forceinline__ int ext_count(const PsxParams* P, const PsxCounters* cnt, int o)
@@ -166,37 +170,77 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         const int loops = (wx > 0 && hy > 0) ? wx * hy : 0;
 
         fix64* myhist = hist + (lane & (HCOPIES - 1)) * ORI_NBINS;
-        const float rcp_wx = 1.0f / (float)max(wx, 1);
-        for (int i = lane; i < loops; i += PSX_WAVE) {
-            // i / wx without integer division: (i+0.5)/wx is >= 0.5/wx away from an integer
-            const int q = (int)(((float)i + 0.5f) * rcp_wx);
+        // a lane owns the pixel pair (xx, xx+1), xx even: packed f32 math for everything that is the same
+        // operation on both pixels (gradient, squared distance, the atan polynomial), one 8-byte load per row.
+        // Per-sample values are those of the one-pixel-per-lane loop, and the histogram adds are integer, so
+        // the result is bit-identical.
+        const int xs = xmin & ~1;
+        const int pw = (wx > 0) ? ((xmax - xs) >> 1) + 1 : 0;              // pairs per row
+        const int loops2 = (pw > 0 && hy > 0) ? pw * hy : 0;
+        const float rcp_pw = 1.0f / (float)max(pw, 1);
+        for (int i = lane; i < loops2; i += PSX_WAVE) {
+            // i / pw without integer division: (i+0.5)/pw is >= 0.5/pw away from an integer
+            const int q = (int)(((float)i + 0.5f) * rcp_pw);
             const int yy = q + ymin;
-            const int xx = i - q * wx + xmin;
+            const int xx = 2 * (i - q * pw) + xs;
             // uniform plane base + 32-bit byte offset: global_load with scalar base
             const unsigned off = (unsigned)yy * pitch4 + (unsigned)xx * 4u;
-            const float gdx = *(gfloat_p)(plane + off + 4u) - *(gfloat_p)(plane + off - 4u);
-            const float gdy = *(gfloat_p)(plane + (off + pitch4)) - *(gfloat_p)(plane + (off - pitch4));
+            const v2f  ctr = *(gv2f_p)(plane + off);                  // p[xx], p[xx+1]
+            const float lft = *(gfloat_p)(plane + off - 4u);          // p[xx-1]
+            const float rgt = *(gfloat_p)(plane + off + 8u);          // p[xx+2]
+            const v2f  dwn = *(gv2f_p)(plane + (off + pitch4));
+            const v2f  upp = *(gv2f_p)(plane + (off - pitch4));
+            const v2f gdx = (v2f){ctr.y - lft, rgt - ctr.x};
+            const v2f gdy = dwn - upp;
             // the reference uses hypotf / atan2f here (s_gradiant.h:56-69).  The magnitude only scales a weight
             // (v_sqrt_f32 is enough); the angle picks the histogram bin and must round exactly like the CPU restatement's
             // (oracle/sift_oracle.c) roundf(36 (atan2f + pi) / 2pi) -- see the bin computation below.
-            const float grad  = __builtin_amdgcn_sqrtf(fmaf(gdx, gdx, gdy * gdy));
-            const float dx = xx - x;
+            const v2f m2 = pk_fma(gdx, gdx, gdy * gdy);
             const float dy = yy - y;
-            const int sq_dist = (int)(dx * dx + dy * dy);
-            if (sq_dist <= sq_thres) {
-                const float weight = grad * __builtin_amdgcn_exp2f((float)sq_dist * factor2);
-                // Bin = roundf(36 (atan2f(gdy,gdx) + pi) / 2pi) with accurate atan2f and IEEE division, as in the
-                // CPU restatement: gradients along exact bin boundaries (gdx == gdy gives 45 deg = bin 22.5) are common in
-                // smooth images and one heavy sample in the wrong bin moves the interpolated peak by ~6e-3 rad.
-                // The 3.3e-7 rad polynomial (2e-6 bins) decides every sample that is not within 1e-3 bins of a
-                // boundary; only those (about 0.2 % of the samples) take the exact, ~50-instruction form.
-                const float bfast = (float)ORI_NBINS * (fast_atan2(gdy, gdx) + PI_F) * (1.0f / PI2_F);
-                const float bfl = floorf(bfast);
-                int bidx = (int)bfl + ((bfast - bfl) >= 0.5f ? 1 : 0);
-                if (fabsf((bfast - bfl) - 0.5f) < 1e-3f)
-                    bidx = (int)roundf((float)ORI_NBINS * (atan2f(gdy, gdx) + PI_F) / PI2_F);
-                bidx = (bidx == ORI_NBINS) ? 0 : bidx;
-                atomicAdd(&myhist[bidx], (fix64)(weight * OFIX));
+            const v2f dxv = (v2f){(float)xx, (float)(xx + 1)} - splat(x);      // each column converted, then - x: as the CPU restatement
+            const v2f d2 = dxv * dxv + splat(dy * dy);
+            const int sq0 = (int)d2.x, sq1 = (int)d2.y;
+            const bool on0 = xx >= xmin && sq0 <= sq_thres;
+            const bool on1 = xx + 1 <= xmax && sq1 <= sq_thres;
+            if (on0 || on1) {
+                // fast_atan2 on both pixels (same operations per component)
+                const v2f ax = (v2f){fabsf(gdx.x), fabsf(gdx.y)}, ay = (v2f){fabsf(gdy.x), fabsf(gdy.y)};
+                const v2f mx = (v2f){fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)};
+                const v2f mn = (v2f){fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
+                const v2f rc = (v2f){__builtin_amdgcn_rcpf(fmaxf(mx.x, 1e-30f)), __builtin_amdgcn_rcpf(fmaxf(mx.y, 1e-30f))};
+                const v2f a = mn * rc;
+                const v2f s2 = a * a;
+                v2f r = splat(0.006811792496591806f);
+                r = pk_fma(r, s2, splat(-0.0336042195558548f));
+                r = pk_fma(r, s2, splat(0.07962366938591003f));
+                r = pk_fma(r, s2, splat(-0.1323334127664566f));
+                r = pk_fma(r, s2, splat(0.19807815551757812f));
+                r = pk_fma(r, s2, splat(-0.3331736922264099f));
+                r = pk_fma(r, s2, splat(0.9999961256980896f));
+                r = r * a;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    if (!(e == 0 ? on0 : on1)) continue;
+                    const float gx = e == 0 ? gdx.x : gdx.y, gy = e == 0 ? gdy.x : gdy.y;
+                    float at = e == 0 ? r.x : r.y;
+                    if ((e == 0 ? ay.x : ay.y) > (e == 0 ? ax.x : ax.y)) at = 1.57079632679489662f - at;
+                    if (gx < 0.0f) at = PI_F - at;
+                    at = (gy < 0.0f) ? -at : at;
+                    const float grad = __builtin_amdgcn_sqrtf(e == 0 ? m2.x : m2.y);
+                    const float weight = grad * __builtin_amdgcn_exp2f((float)(e == 0 ? sq0 : sq1) * factor2);
+                    // Bin = roundf(36 (atan2f(gdy,gdx) + pi) / 2pi) with accurate atan2f and IEEE division, as in the
+                    // CPU restatement: gradients along exact bin boundaries (gdx == gdy gives 45 deg = bin 22.5) are common in
+                    // smooth images and one heavy sample in the wrong bin moves the interpolated peak by ~6e-3 rad.
+                    // The 3.3e-7 rad polynomial (2e-6 bins) decides every sample that is not within 1e-3 bins of a
+                    // boundary; only those (about 0.2 % of the samples) take the exact, ~50-instruction form.
+                    const float bfast = (float)ORI_NBINS * (at + PI_F) * (1.0f / PI2_F);
+                    const float bfl = floorf(bfast);
+                    int bidx = (int)bfl + ((bfast - bfl) >= 0.5f ? 1 : 0);
+                    if (fabsf((bfast - bfl) - 0.5f) < 1e-3f)
+                        bidx = (int)roundf((float)ORI_NBINS * (atan2f(gy, gx) + PI_F) / PI2_F);
+                    bidx = (bidx == ORI_NBINS) ? 0 : bidx;
+                    atomicAdd(&myhist[bidx], (fix64)(weight * OFIX));
+                }
             }
         }
         wave_fence();
@@ -470,10 +514,6 @@ __device__ __forceinline__ void normalize_store(const PsxParams* P, const PsxExp
 //   * the angle lives in bin units (0..8 = 0..2 pi) from the atan polynomial on and is not wrapped into [0, 8):
 //     floor() and "& 7" wrap the bin index, the fractional part is the same.
 // ---------------------------------------------------------------------------------------------
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) v2f* gv2f_p;
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f splat(float a) { return (v2f){a, a}; }
 
 __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
 {
