@@ -378,8 +378,20 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
             c3.extract()
         n3 = c3.counts()
         d3 = (time.perf_counter() - t1) / reps
+        # the dominant kernel on THIS configuration's octave 0 (8192 x 8192 planes, 537 MB algorithmic per launch):
+        # the same in-pipeline timing as `roofline`, on planes large enough to amortise a launch's ramp
+        c3.enable_blur_probe(True)
+        acc3, by3 = None, 0.0
+        for _ in range(3):
+            c3.extract()
+            ms3, by3 = c3.blur_probe_times()
+            acc3 = ms3 if acc3 is None else [a + b for a, b in zip(acc3, ms3)]
+        avg3 = sum(acc3) / 3.0 / len(acc3)
         ex["config3"] = {"value": round(4096 * 4096 / d3 / 1e6, 1), "unit": "Mpix/s", "ms_per_frame": round(d3 * 1e3, 3),
                          "keypoints": n3[0], "descriptors": n3[1],
+                         "k_blur_octave0": {"avg_launch_ms": round(avg3, 5), "bytes_per_launch": by3,
+                                            "achieved_GBs": round(by3 / (avg3 * 1e-3) / 1e9, 1),
+                                            "frac_of_8TBs": round(by3 / (avg3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                          "what": "4096x4096 u8 (tiled synthetic frame), octaves=6, upscale x2 (octave 0 = 8192x8192), "
                                  "one context, frames back to back, device resident"}
         c3.close()
