@@ -104,6 +104,17 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
     return (y < 0.0f) ? -r : r;
 }
 
+// x / 3.0f, correctly rounded, in three instructions: q = RN(x * RN(1/3)), r = x - 3q (exact in an fma), q + r * RN(1/3).
+// (Markstein: with a correctly rounded reciprocal one such correction step gives the correctly rounded quotient;
+// checked against x / 3.0f on 2e7 random floats over nine decades.)  The IEEE division sequence costs ~10.
+__device__ __forceinline__ float div3(float x)
+{
+    const float y = 0.3333333432674407958984375f;
+    const float q = x * y;
+    const float r = fmaf(-3.0f, q, x);
+    return fmaf(r, y, q);
+}
+
 typedef const __attribute__((address_space(1))) float* gfloat_p;
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) v2f* gv2f_p;
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         for (int it = 0; it < 6; it++) {   // 3 x (hist->sm_hist->hist), s_orientation.cu:166-174
             const float pv = __shfl(hval, prev_l);
             const float nv = __shfl(hval, next_l);
-            hval = (pv + hval + nv) / 3.0f;
+            hval = div3(pv + hval + nv);
         }
         const float hp = __shfl(hval, prev_l);
         const float hn = __shfl(hval, next_l);
@@ -272,17 +283,24 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         const float refined = predicate ? (float)prev_l + newbin : -1.0f;
         const float yval    = predicate ? -(num * num) / (4.0f * denB) + hp : -INFINITY;
 
-        // top-4 by value (BitonicSort::Warp32::sort64 + lanes 0..3, s_orientation.cu:224-247)
-        bool alive = true;
+        // top-4 by value (BitonicSort::Warp32::sort64 + lanes 0..3, s_orientation.cu:224-247): equal values keep
+        // their lane order, missing entries are (-inf, -1).  The peaks are few (<= 18, typically 3..5): a wave-uniform
+        // insertion over the set bits of the peak mask instead of four 64-lane max reductions.
         float sel_val[PSX_ORI_MAX], sel_bin[PSX_ORI_MAX];
 #pragma unroll
-        for (int k = 0; k < PSX_ORI_MAX; k++) {
-            const float m = wave_max(alive ? yval : -INFINITY);
-            const unsigned long long cand = __ballot(alive && yval == m);
-            const int pick = cand ? (__ffsll((long long)cand) - 1) : 0;
-            sel_val[k] = m;
-            sel_bin[k] = __shfl(refined, pick);
-            if (lane == pick) alive = false;
+        for (int k = 0; k < PSX_ORI_MAX; k++) { sel_val[k] = -INFINITY; sel_bin[k] = -1.0f; }
+        for (unsigned long long pm = __ballot(predicate); pm != 0ull; pm &= pm - 1ull) {
+            const int pl = __ffsll((long long)pm) - 1;
+            float cv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yval), pl));
+            float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(refined), pl));
+#pragma unroll
+            for (int k = 0; k < PSX_ORI_MAX; k++) {
+                if (cv > sel_val[k]) {                   // strict: an earlier lane stays in front of an equal later one
+                    const float tv = sel_val[k], tb = sel_bin[k];
+                    sel_val[k] = cv; sel_bin[k] = cb;
+                    cv = tv; cb = tb;
+                }
+            }
         }
         if (lane == 0) {
             psx_extremum ex;
