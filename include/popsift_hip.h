@@ -254,6 +254,9 @@ int psx_clone_results(psx_ctx* ctx, void* d_features, void* d_descriptors, int* 
  * [2*i..2*i+1] = the two squared distances (what show_distance prints).  Synchronous. */
 int psx_match(int device, const float* d_left, int l_len, const float* d_right, int r_len,
               int* host_match, float* host_dist);
+/* Frees the calling thread's matcher scratch (a private stream and device buffers that psx_match keeps between
+ * calls); optional -- the scratch is also released when the thread exits. */
+int psx_match_release(void);
 
 /* device_prop_t (common/device_prop.h:23-108): enumeration only; there are no texture limits. */
 int psx_device_count(int* count);

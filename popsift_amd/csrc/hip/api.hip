@@ -142,6 +142,11 @@ struct psx_ctx {
     int x_feat_cap = 0, x_desc_cap = 0;
     bool x_registered_feat = false, x_registered_desc = false;
     int* h_xcnt = nullptr;             // pinned [4]: ext_total, ori_total, ori_raw
+    // the export targets the frame in flight was LAUNCHED with (psx_orientation): the attach calls may change the
+    // targets of the next frame before this one's counters and results have been fetched
+    PsxExport fx{};
+    psx_feature* fx_host_feat = nullptr; float* fx_host_desc = nullptr;
+    bool fx_on = false;
 
     bool timers = false;
     bool blocking_wait = false;        // psx_set_wait_mode: sleep on an event instead of spinning in hipStreamSynchronize
@@ -168,6 +173,12 @@ PsxExport export_of(const psx_ctx* c)
     return x;
 }
 inline bool exporting(const psx_ctx* c) { return c->x_dev_feat != nullptr || c->x_dev_desc != nullptr; }
+inline void snapshot_export(psx_ctx* c)
+{
+    c->fx = export_of(c);
+    c->fx_host_feat = c->x_host_feat; c->fx_host_desc = c->x_host_desc;
+    c->fx_on = exporting(c);
+}
 
 int fail(psx_ctx* c, int code, const std::string& msg)
 {
@@ -815,7 +826,8 @@ int psx_orientation(psx_ctx* ctx)
         if (rc != PSX_OK) return rc;
     }
     PSX_HIP(psx_launch_orientation(ctx->d_params, ctx->d_cnt, ctx->stream));
-    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, export_of(ctx), ctx->stream));
+    snapshot_export(ctx);
+    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, ctx->fx, ctx->stream));
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     return PSX_OK;
 }
@@ -826,9 +838,9 @@ int psx_descriptors(psx_ctx* ctx)
     if (!ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_descriptors: no pyramid");
     PSX_HIP(hipSetDevice(ctx->device));
     if (ctx->cfg.desc_mode == PSX_DESC_LOOP)
-        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, export_of(ctx), ctx->stream));
+        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->fx, ctx->resident_blocks / 4, ctx->stream));
     else
-        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, export_of(ctx), ctx->stream));
+        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, ctx->fx, ctx->resident_blocks / 4, ctx->stream));
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     return PSX_OK;
 }
@@ -884,6 +896,7 @@ int psx_extract(psx_ctx* ctx)
     }
     ctx->counts_valid = false;
     ctx->filtered = false;
+    snapshot_export(ctx);             // the captured kernels carry the targets attached at capture time; attach drops the graph
     PSX_HIP(hipGraphLaunch(ctx->graph, ctx->stream));
     return PSX_OK;
 }
@@ -928,11 +941,12 @@ static int regrow_descriptors(psx_ctx* ctx, int ori_raw)
     *ctx->h_params_pin = P;
     PSX_HIP(hipMemcpyAsync(ctx->d_params, ctx->h_params_pin, sizeof(P), hipMemcpyHostToDevice, ctx->stream));
     if (ctx->graph) { (void)hipGraphExecDestroy(ctx->graph); ctx->graph = nullptr; }
-    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, export_of(ctx), ctx->stream));
+    // same targets as the launch being repeated
+    PSX_HIP(psx_launch_scan(ctx->d_params, ctx->d_cnt, ctx->fx, ctx->stream));
     if (ctx->cfg.desc_mode == PSX_DESC_LOOP)
-        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, export_of(ctx), ctx->stream));
+        PSX_HIP(psx_launch_descriptors(ctx->d_params, ctx->d_cnt, ctx->fx, ctx->resident_blocks / 4, ctx->stream));
     else
-        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, export_of(ctx), ctx->stream));
+        PSX_HIP(psx_launch_descriptors_alt(ctx->d_params, ctx->d_cnt, ctx->cfg.desc_mode, ctx->fx, ctx->resident_blocks / 4, ctx->stream));
     return PSX_OK;
 }
 
@@ -942,8 +956,8 @@ static int fetch_counts(psx_ctx* ctx)
     PSX_HIP(hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 2; attempt++) {
         int raw;
-        if (exporting(ctx)) {
-            // export attached: the scan kernel already deposited the counters in pinned memory
+        if (ctx->fx_on) {
+            // the frame was launched with export targets: its scan kernel deposited the counters in pinned memory
             { int wrc = wait_stream(ctx); if (wrc != PSX_OK) return wrc; }
             ctx->h_cnt->ext_total = ctx->h_xcnt[0];
             ctx->h_cnt->ori_total = ctx->h_xcnt[1];
@@ -984,8 +998,8 @@ int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity, floa
         return fail(ctx, PSX_ERR_INVALID, "psx_download: output capacity too small");
     if (ne > 0 && !features) return fail(ctx, PSX_ERR_INVALID, "psx_download: null feature buffer");
     if (no > 0 && !descriptors) return fail(ctx, PSX_ERR_INVALID, "psx_download: null descriptor buffer");
-    const bool feat_exported = (features == ctx->x_host_feat && ne <= ctx->x_feat_cap);
-    const bool desc_exported = (descriptors == ctx->x_host_desc && no <= ctx->x_desc_cap);
+    const bool feat_exported = (ctx->fx_on && features == ctx->fx_host_feat && ne <= ctx->fx.feat_capacity);
+    const bool desc_exported = (ctx->fx_on && descriptors == ctx->fx_host_desc && no <= ctx->fx.desc_capacity);
     if (ne > 0 && !feat_exported)
         PSX_HIP(hipMemcpyAsync(features, ctx->d_features, (size_t)ne * sizeof(psx_feature),
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -1044,8 +1058,14 @@ int psx_attach_export_mapped(psx_ctx* ctx, psx_feature* host_features, int featu
                              float* host_descriptors, int descriptor_capacity)
 {
     if (!ctx) return PSX_ERR_INVALID;
-    // No HIP call: the targets travel as kernel arguments of the next extraction.  The frame in flight (if any)
-    // keeps the targets it was launched with.
+    // Normally no HIP call: the targets travel as kernel arguments of the NEXT extraction; the frame in flight (if
+    // any) keeps the targets it was launched with, and its counters / results are still fetched from those
+    // (psx_ctx::fx).  Only buffers an earlier psx_attach_export had to register are a reason to wait: the frame
+    // in flight may still be storing into them.
+    if (ctx->x_registered_feat || ctx->x_registered_desc) {
+        PSX_HIP(hipSetDevice(ctx->device));
+        PSX_HIP(hipStreamSynchronize(ctx->stream));
+    }
     if (ctx->x_registered_feat) { (void)hipHostUnregister(ctx->x_host_feat); ctx->x_registered_feat = false; }
     if (ctx->x_registered_desc) { (void)hipHostUnregister(ctx->x_host_desc); ctx->x_registered_desc = false; }
     // psx_host_alloc memory: mapped, and its device address is its host address (checked at allocation)

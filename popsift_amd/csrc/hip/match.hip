@@ -146,10 +146,19 @@ struct MatchScratch {
         cap[i] = bytes;
         return true;
     }
-    ~MatchScratch() { release(); }
+    // Thread exit.  For the main thread that is process teardown, where the HIP runtime may already be gone: ask it
+    // first (a finalised runtime answers with an error) and then leave the buffers to the process exit.
+    ~MatchScratch() { int n = 0; if (device >= 0 && hipGetDeviceCount(&n) == hipSuccess && n > 0) release(); }
 };
 thread_local MatchScratch t_scratch;
 } // namespace
+
+// frees the calling thread's matcher scratch (stream + up to 4 device buffers); PopSift::uninit calls it
+extern "C" int psx_match_release(void)
+{
+    t_scratch.release();
+    return PSX_OK;
+}
 
 extern "C" int psx_match(int device, const float* d_left, int l_len, const float* d_right, int r_len,
                          int* host_match, float* host_dist)

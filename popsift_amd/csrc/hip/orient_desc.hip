@@ -994,9 +994,9 @@ hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, const 
     return hipGetLastError();
 }
 
-hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, const PsxExport& x, hipStream_t s)
+hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, const PsxExport& x, int cus, hipStream_t s)
 {
-    const dim3 grid(2048), block(NT);
+    const dim3 grid(cus > 0 ? 8 * cus : 2048), block(NT);
     switch (desc_mode) {
     case PSX_DESC_ILOOP:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_ILOOP>, grid, block, 0, s, d_params, d_cnt, x); break;
     case PSX_DESC_GRID:   hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_GRID>, grid, block, 0, s, d_params, d_cnt, x); break;
@@ -1007,18 +1007,15 @@ hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounte
     return hipGetLastError();
 }
 
-hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, const PsxExport& x, hipStream_t s)
+hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, const PsxExport& x, int cus, hipStream_t s)
 {
     const bool exporting = x.desc != nullptr;
     // 5 workgroups (20 waves, 32 KB of LDS each) are resident per CU; 10 per CU = two full rounds measured best for
     // the descriptors of a 1080p frame (stage time 0.159 ms at 8 per CU, 0.143 at 10, 0.142 at 12, 0.147 at 15, 0.148
     // at 20).  With the zero-copy export attached every wave ends in stores that cross PCIe; fewer resident waves
     // leave room for the other streams' kernels meanwhile (3 per CU measured +11 % on the export leg of bench.py).
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+    // cus = compute units of the CONTEXT's device (one PopSift per GPU may sit on unequal devices).
+    if (cus <= 0) cus = 256;
     const int grid = exporting ? 3 * cus : 10 * cus;
     hipLaunchKernelGGL(k_descriptors, dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
     return hipGetLastError();

@@ -145,8 +145,8 @@ hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt,
 hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, const PsxExport& x, hipStream_t s);
 hipError_t psx_launch_feature_ptrs(const psx_feature* in, psx_feature_dev* out, int n, float* desc_base, int num_desc,
                                    hipStream_t s);
-hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, const PsxExport& x, hipStream_t s);
-hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, const PsxExport& x, hipStream_t s);
+hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, const PsxExport& x, int cus, hipStream_t s);
+hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, const PsxExport& x, int cus, hipStream_t s);
 
 // ---- small device helpers --------------------------------------------------------------------
 __device__ __forceinline__ int psx_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

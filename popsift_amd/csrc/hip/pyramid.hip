@@ -343,6 +343,428 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// blur_body_dma: the same marching strip with the staged rows brought in by LDS-DMA
+// (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through VGPRs) into a ring of NBUF stage
+// buffers, NBUF-1 steps ahead.  Why: a 3840x2160 plane is ONE round of ~900 workgroups that all
+// start together and run in lockstep, so with a one-step register prefetch the memory system idles
+// while every workgroup computes and the VALUs idle while every workgroup waits (kernel time ~ sum
+// of the two phases).  Two steps of loads in flight per workgroup keep HBM busy through the
+// arithmetic; the commit phase (3-4 ds_write_b128 per thread and step) and its 12-16 VGPRs go away.
+//
+// vmcnt accounting (the compiler does not count an asm load, cdna_hip_programming.md 5.7): per step a wave issues
+//   s_waitcnt vmcnt(pending DMA batches newer than this step's) -> flush(k-1) stores -> barrier A -> DMA(k+NBUF-1)
+// so at the wait the NEWEST operations are exactly the DMA batches that may stay in flight (NLD wave
+// instructions each, every wave issues all of them: partial lane masks only); everything older -- this
+// step's batch and the stores of step k-2 -- must have completed.  Loads return in order among loads, so
+// the count is right whether or not stores may overtake loads.
+//
+// Staged layout = the old one (odd number of 16-byte chunks per row, pad chunk never written): chunk c of a
+// buffer is row c / CH, column chunk c % CH; DMA instruction i (NLDT per step, NLD per wave) covers chunks
+// [i*P, (i+1)*P) with lanes 0..P-1, its LDS base (M0) = buffer + i*P*16.  Columns outside the source row
+// (first / last strip) cannot be clamped per element by a 16-byte DMA: those strips load in-row chunks and
+// patch the out-of-range columns in LDS after the batch has landed (one extra barrier, edge strips only).
+// ---------------------------------------------------------------------------------------------
+template <int R, int NBUF, int RINGROWS>
+struct GeomD {
+    static constexpr int HALO = (R + 3) & ~3;
+    static constexpr int SW   = TW + 2 * HALO;
+    static constexpr int SW4  = SW / 4;
+    static constexpr int CH   = SW4 | 1;                // chunks per staged row (odd)
+    static constexpr int SWA  = 4 * CH;
+    static constexpr int NCH  = BR * CH;                // chunks per stage buffer
+    static constexpr int nldt() { for (int n = 4; n <= 64; n += 4) if (NCH % n == 0 && NCH / n <= 64) return n; return 0; }
+    static constexpr int NLDT = nldt();
+    static constexpr int NLD  = NLDT / 4;               // DMA wave instructions per wave and step
+    static constexpr int P    = NCH / NLDT;             // chunks (= active lanes) per DMA instruction
+    static constexpr int RING = RINGROWS;
+    static constexpr int VWIN = 4 + 2 * R;
+    static constexpr int MIRROR = VWIN - 1;
+    static constexpr int RS   = TW + 4;
+    static constexpr int STAGE_FLOATS = BR * SWA;
+    static constexpr int LDS_FLOATS = NBUF * STAGE_FLOATS + (RING + MIRROR) * RS;
+    static_assert(NLDT > 0 && P <= 64, "no DMA tiling for this radius");
+    static_assert(RING >= BR + 2 * R && RING % 16 == 0, "ring too small");
+    static_assert((SW4 & 1) == 0, "the pad chunk is assumed to exist");
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// one LDS-DMA wave instruction: lanes 0..P-1 each move 16 bytes from (base + voff[lane]) to LDS byte address
+// lds_dst + 16*lane.  EXEC is narrowed to the low P lanes inside the statement (the callers run in wave-uniform
+// control flow with all 64 lanes on) and M0, which is compiler-reserved, is saved and restored; s_nop 4 covers the
+// SALU-written base / M0 / EXEC -> VMEM hazards, which hipcc does not pad inside an asm statement.
+template <int P>
+__device__ __forceinline__ void dma16(const char* base, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep_m0;
+    unsigned long long keep_exec;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b64 %1, exec\n\t"
+                 "s_lshr_b64 exec, -1, %5\n\t"
+                 "s_mov_b32 m0, %4\n\t"
+                 "s_nop 4\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(voff), "s"(base), "s"(lds_dst), "n"(64 - P) : "memory");
+}
+
+template <int R, bool LEVEL0, int NBUF, int RINGROWS>
+__device__ __forceinline__ void blur_body_dma(const BlurArgs& a, const int lid)
+{
+    using G = GeomD<R, NBUF, RINGROWS>;
+    constexpr int HALO = G::HALO, SW = G::SW, SW4 = G::SW4, CH = G::CH, SWA = G::SWA, NLD = G::NLD, P = G::P;
+    constexpr int RING = G::RING, VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS, STAGE = G::STAGE_FLOATS;
+    constexpr int D = NBUF - 1;                          // DMA batches in flight ahead of the step being filtered
+    __shared__ __attribute__((aligned(16))) float s_all[G::LDS_FLOATS];
+    float* const s_ring = s_all + NBUF * STAGE;
+
+    const int t     = threadIdx.x;
+    const int lane  = t & 63;
+    const int wv    = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int strip = lid % a.nstrips;
+    const int chunk = lid / a.nstrips;
+    const int x0    = strip * TW;
+    const int Y0    = chunk * a.chunk_rows;
+    const int Y1    = min(Y0 + a.chunk_rows, a.H);
+    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
+    const int xs0   = x0 - HALO + a.src_xoff;            // source column of staged column 0
+    const bool interior = (xs0 >= 0) && (xs0 + SW <= a.src_width);
+    const unsigned lds0 = (unsigned)(unsigned long)(LDS_AS float*)s_all;
+
+    // ---- DMA geometry of this lane (step invariant) ----
+    int st_row[NLD]; unsigned st_xb[NLD], st_off[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; j++) {
+        const int c = (wv * NLD + j) * P + lane;
+        const int row = c / CH, cc = c - row * CH;
+        st_row[j] = row;
+        // in-row chunk (the source rows are pitch floats long, pitch % 4 == 0): columns outside [0, src_width) are patched
+        // later; the lane of the pad chunk (cc == SW4) loads 16 in-row bytes nobody reads, lanes >= P are masked in dma16
+        const int xc = psx_clampi(xs0 + cc * 4, 0, a.src_pitch - 4);
+        st_xb[j]  = (unsigned)xc * 4u;
+        st_off[j] = (unsigned)(row * a.src_pitch) * 4u + st_xb[j];
+    }
+    auto issue = [&](const int k) {
+        const int ybase = Y0 - R + k * BR;
+        const unsigned buf = lds0 + (unsigned)((k % NBUF) * STAGE * 4);
+        if (ybase >= 0 && ybase + BR <= a.H) {           // workgroup uniform: scalar row base + step-invariant offsets
+            const char* step_base = reinterpret_cast<const char*>(a.src + (ptrdiff_t)ybase * a.src_pitch);
+#pragma unroll
+            for (int j = 0; j < NLD; j++)
+                dma16<P>(step_base, st_off[j], buf + (unsigned)((wv * NLD + j) * P * 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < NLD; j++) {
+                const int y = psx_clampi(ybase + st_row[j], 0, a.H - 1);
+                const unsigned off = (unsigned)(y * a.src_pitch) * 4u + st_xb[j];
+                dma16<P>(reinterpret_cast<const char*>(a.src), off, buf + (unsigned)((wv * NLD + j) * P * 16));
+            }
+        }
+    };
+
+    // ---- horizontal pass geometry (as blur_body) ----
+    int h_row, h_seg;
+    {
+        const int blk = (t & 31) >> 2;
+        const int rq = (0x21120330 >> (4 * blk)) & 3;
+        const int sh = (0xCC >> blk) & 1;
+        h_row = (t >> 6) * 8 + ((t >> 5) & 1) * 4 + rq;
+        h_seg = sh * 4 + (t & 3);
+    }
+    const int h_off = h_row * SWA + h_seg * 8;           // floats into a stage buffer
+    const int v_pp = t & 31, v_rg = t >> 5;
+    const int v_x  = x0 + 2 * v_pp;
+    const unsigned v_doff = (unsigned)((v_rg * 4) * a.pitch + v_x) * 4u;
+    const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
+    // edge strips: staged columns [0, e_l) take the value of column e_l, columns [e_r, SW) that of column e_r - 1
+    const int e_l = min(max(-xs0, 0), SW - 1), e_r = max(min(a.src_width - xs0, SW), 1);
+
+    v2f pend[4];
+    auto flush = [&](const int kk) {
+        const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
+        char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r_out = r_out0 + i;
+            if (r_out >= Y0 && r_out < Y1 && v_xok) {
+                char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
+                if (v_pair) {
+                    unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else *reinterpret_cast<float*>(di) = pend[i].x;
+                if (a.half_dst != nullptr && (r_out & 1) == 0)
+                    a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
+            }
+        }
+    };
+
+#pragma unroll
+    for (int q = 0; q < D; q++) if (q < nsteps) issue(q);
+    int sbase = 0;                                       // ring slot of the first row filtered in step k = (k * BR) mod RING
+    for (int k = 0; k < nsteps; k++) {
+        // this step's batch has landed (newer batches stay in flight)
+        if (D >= 2 && k + 1 < nsteps) {
+            if (D >= 3 && k + 2 < nsteps) wait_vmcnt<(D >= 3 ? 2 : 0) * NLD>(); else wait_vmcnt<(D >= 2 ? 1 : 0) * NLD>();
+        } else wait_vmcnt<0>();
+        flush(k - 1);
+        __syncthreads();                                 // A: everyone's part of batch k is in LDS; V(k-1) and H(k-1) are done
+        if (k + D < nsteps) issue(k + D);                // into the buffer H(k-1) read
+        float* const stage = s_all + (k % NBUF) * STAGE;
+        if (!interior) {
+            const int row = t >> 3, sub = t & 7;
+            float* rp = stage + row * SWA;
+            const float vl = rp[e_l], vr = rp[e_r - 1];
+            for (int c = sub; c < e_l; c += 8) rp[c] = vl;
+            for (int c = e_r + sub; c < SW; c += 8) rp[c] = vr;
+            __syncthreads();
+        }
+
+        // ---- horizontal ----
+        {
+            const LDS_AS float* h_src = (const LDS_AS float*)(stage + h_off);
+            float win[8 + 2 * HALO];
+#pragma unroll
+            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
+                const v4f v = ((const volatile LDS_AS v4f*)h_src)[q];
+                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+            }
+            float out[8];
+            hfilter8_km<R, HALO, LEVEL0>(win, a.taps, out);
+            int slot = sbase + h_row; if (slot >= RING) slot -= RING;
+            float* rp = &s_ring[slot * RS + h_seg * 8];
+            reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
+            reinterpret_cast<float4*>(rp)[1] = make_float4(out[4], out[5], out[6], out[7]);
+            if (slot < MIRROR) {
+                reinterpret_cast<float4*>(rp + RING * RS)[0] = make_float4(out[0], out[1], out[2], out[3]);
+                reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
+            }
+        }
+        __syncthreads();                                 // B
+
+        // ---- vertical ----
+        {
+            const int rel0 = k * BR - 2 * R + v_rg * 4;
+            const int r_out0 = Y0 + rel0;
+            if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
+                int vs = sbase - 2 * R + v_rg * 4;       // ring slot of T[r_out0 - R]
+                if (vs < 0) vs += RING;
+                if (vs >= RING) vs -= RING;
+                const LDS_AS float* vp = (const LDS_AS float*)&s_ring[vs * RS + 2 * v_pp];
+                v2f v[VWIN];
+#pragma unroll
+                for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
+                v2f o[4];
+                vfilter2x4_km<R>(v, LEVEL0 ? a.taps_v : a.taps, o);
+                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+#pragma unroll
+                for (int i = 0; i < 4; i++) pend[i] = o[i];
+            }
+        }
+        sbase += BR; if (sbase >= RING) sbase -= RING;
+    }
+    flush(nsteps - 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// blur_body_ldw: k_blur_dma with a fifth wave per workgroup that does nothing but the LDS-DMA.
+// Why: vmcnt is ONE in-order counter per wave for loads and stores.  A wave that both waits for its staged rows
+// and stores its results therefore also waits, every step, for the write-through acknowledgements of the stores
+// it issued a step earlier (measured with in-kernel stamps: 2400 cycles per step in the wait+store phase, 1100
+// with the stores compiled out, identical whether the loads hit the cache or HBM).  With the roles on different
+// waves the loader's counter only ever holds DMA batches (counted waits, NBUF-1 batches ahead) and the four
+// filter waves never wait on vmcnt at all: their stores drain behind the arithmetic of later steps.
+// Barrier protocol per step (all five waves): A = batch k landed (loader waited for it) and the buffer of step
+// k-1 is free, [edge strips: patch + barrier], B = ring rows of step k written.
+// ---------------------------------------------------------------------------------------------
+template <int R, bool LEVEL0, int NBUF, int RINGROWS>
+__device__ __forceinline__ void blur_body_ldw(const BlurArgs& a, const int lid)
+{
+    using G = GeomD<R, NBUF, RINGROWS>;
+    constexpr int HALO = G::HALO, SW = G::SW, CH = G::CH, SWA = G::SWA, NLDT = G::NLDT, P = G::P;
+    constexpr int RING = G::RING, VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS, STAGE = G::STAGE_FLOATS;
+    constexpr int D = NBUF - 1;
+    static_assert(D >= 1 && D <= 3 && (D - 1) * NLDT <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) float s_all[G::LDS_FLOATS];
+    float* const s_ring = s_all + NBUF * STAGE;
+
+    const int t     = threadIdx.x;
+    const int lane  = t & 63;
+    const int wv    = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int strip = lid % a.nstrips;
+    const int chunk = lid / a.nstrips;
+    const int x0    = strip * TW;
+    const int Y0    = chunk * a.chunk_rows;
+    const int Y1    = min(Y0 + a.chunk_rows, a.H);
+    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
+    const int xs0   = x0 - HALO + a.src_xoff;
+    const bool interior = (xs0 >= 0) && (xs0 + SW <= a.src_width);
+
+    if (wv == 4) {
+        // ------------------------------ loader wave ------------------------------
+        const unsigned lds0 = (unsigned)(unsigned long)(LDS_AS float*)s_all;
+        unsigned st_xb[NLDT], st_off[NLDT];
+#pragma unroll
+        for (int i = 0; i < NLDT; i++) {
+            const int c = i * P + lane;
+            const int row = c / CH, cc = c - row * CH;
+            const int xc = psx_clampi(xs0 + cc * 4, 0, a.src_pitch - 4);
+            st_xb[i]  = (unsigned)xc * 4u;
+            st_off[i] = (unsigned)(row * a.src_pitch) * 4u + st_xb[i];
+        }
+        auto issue = [&](const int k) {
+            const int ybase = Y0 - R + k * BR;
+            const unsigned buf = lds0 + (unsigned)((k % NBUF) * STAGE * 4);
+            if (ybase >= 0 && ybase + BR <= a.H) {
+                const char* step_base = reinterpret_cast<const char*>(a.src + (ptrdiff_t)ybase * a.src_pitch);
+#pragma unroll
+                for (int i = 0; i < NLDT; i++) dma16<P>(step_base, st_off[i], buf + (unsigned)(i * P * 16));
+            } else {
+#pragma unroll
+                for (int i = 0; i < NLDT; i++) {
+                    const int row = (i * P + lane) / CH;
+                    const int y = psx_clampi(ybase + row, 0, a.H - 1);
+                    dma16<P>(reinterpret_cast<const char*>(a.src), (unsigned)(y * a.src_pitch) * 4u + st_xb[i], buf + (unsigned)(i * P * 16));
+                }
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < D; q++) if (q < nsteps) issue(q);
+        for (int k = 0; k < nsteps; k++) {
+            const int newer = min(D - 1, nsteps - 1 - k);          // batches issued after batch k
+            if (newer >= 2) wait_vmcnt<(D >= 3 ? 2 : 0) * NLDT>();
+            else if (newer == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * NLDT>();
+            else wait_vmcnt<0>();
+            __syncthreads();                                     // A
+            if (k + D < nsteps) issue(k + D);
+            if (!interior) __syncthreads();
+            __syncthreads();                                     // B
+        }
+        return;
+    }
+
+    // ------------------------------ filter waves (threads 0..255) ------------------------------
+    int h_row, h_seg;
+    {
+        const int blk = (t & 31) >> 2;
+        const int rq = (0x21120330 >> (4 * blk)) & 3;
+        const int sh = (0xCC >> blk) & 1;
+        h_row = (t >> 6) * 8 + ((t >> 5) & 1) * 4 + rq;
+        h_seg = sh * 4 + (t & 3);
+    }
+    const int h_off = h_row * SWA + h_seg * 8;
+    const int v_pp = t & 31, v_rg = t >> 5;
+    const int v_x  = x0 + 2 * v_pp;
+    const unsigned v_doff = (unsigned)((v_rg * 4) * a.pitch + v_x) * 4u;
+    const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
+    const int e_l = min(max(-xs0, 0), SW - 1), e_r = max(min(a.src_width - xs0, SW), 1);
+
+    v2f pend[4];
+    auto flush = [&](const int kk) {
+        const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
+        char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r_out = r_out0 + i;
+            if (r_out >= Y0 && r_out < Y1 && v_xok) {
+                char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
+                if (v_pair) {
+                    unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else *reinterpret_cast<float*>(di) = pend[i].x;
+                if (a.half_dst != nullptr && (r_out & 1) == 0)
+                    a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
+            }
+        }
+    };
+
+    int sbase = 0;
+    for (int k = 0; k < nsteps; k++) {
+        __syncthreads();                                     // A
+        float* const stage = s_all + (k % NBUF) * STAGE;
+        if (!interior) {
+            const int row = t >> 3, sub = t & 7;
+            float* rp = stage + row * SWA;
+            const float vl = rp[e_l], vr = rp[e_r - 1];
+            for (int c = sub; c < e_l; c += 8) rp[c] = vl;
+            for (int c = e_r + sub; c < SW; c += 8) rp[c] = vr;
+            __syncthreads();
+        }
+        {
+            const LDS_AS float* h_src = (const LDS_AS float*)(stage + h_off);
+            float win[8 + 2 * HALO];
+#pragma unroll
+            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
+                const v4f v = ((const volatile LDS_AS v4f*)h_src)[q];
+                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+            }
+            float out[8];
+            hfilter8_km<R, HALO, LEVEL0>(win, a.taps, out);
+            int slot = sbase + h_row; if (slot >= RING) slot -= RING;
+            float* rp = &s_ring[slot * RS + h_seg * 8];
+            reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
+            reinterpret_cast<float4*>(rp)[1] = make_float4(out[4], out[5], out[6], out[7]);
+            if (slot < MIRROR) {
+                reinterpret_cast<float4*>(rp + RING * RS)[0] = make_float4(out[0], out[1], out[2], out[3]);
+                reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
+            }
+        }
+        __syncthreads();                                     // B
+        {
+            const int rel0 = k * BR - 2 * R + v_rg * 4;
+            const int r_out0 = Y0 + rel0;
+            if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
+                int vs = sbase - 2 * R + v_rg * 4;
+                if (vs < 0) vs += RING;
+                if (vs >= RING) vs -= RING;
+                const LDS_AS float* vp = (const LDS_AS float*)&s_ring[vs * RS + 2 * v_pp];
+                v2f v[VWIN];
+#pragma unroll
+                for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
+                v2f o[4];
+                vfilter2x4_km<R>(v, LEVEL0 ? a.taps_v : a.taps, o);
+                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+#pragma unroll
+                for (int i = 0; i < 4; i++) pend[i] = o[i];
+            }
+        }
+        flush(k);                                            // never waited for: these waves issue no loads
+        sbase += BR; if (sbase >= RING) sbase -= RING;
+    }
+}
+
+constexpr int NT_LDW = NT + 64;
+template <int R, int NBUF, int RINGROWS>
+constexpr int ldw_waves_per_simd()
+{
+    const int lds = GeomD<R, NBUF, RINGROWS>::LDS_FLOATS * 4;
+    int n = (160 * 1024) / lds;                 // workgroups per CU by LDS
+    n = n > 4 ? 4 : (n < 1 ? 1 : n);
+    return (n * 5 + 3) / 4;                     // 5 waves per workgroup over 4 SIMDs
+}
+template <int R, bool LEVEL0, int NBUF, int RINGROWS>
+__global__ __launch_bounds__(NT_LDW, (ldw_waves_per_simd<R, NBUF, RINGROWS>())) void k_blur_ldw(BlurArgs a)
+{
+    blur_body_ldw<R, LEVEL0, NBUF, RINGROWS>(a, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// workgroups of 256 threads a CU can hold for a variant (LDS bound; 4 waves per SIMD at <= 128 VGPRs)
+template <int R, int NBUF, int RINGROWS>
+constexpr int dma_wg_per_cu()
+{
+    const int lds = GeomD<R, NBUF, RINGROWS>::LDS_FLOATS * 4;
+    const int n = (160 * 1024) / lds;
+    return n > 4 ? 4 : (n < 1 ? 1 : n);
+}
+
+template <int R, bool LEVEL0, int NBUF, int RINGROWS>
+__global__ __launch_bounds__(NT, (dma_wg_per_cu<R, NBUF, RINGROWS>())) void k_blur_dma(BlurArgs a)
+{
+    blur_body_dma<R, LEVEL0, NBUF, RINGROWS>(a, xcd_remap(blockIdx.x, gridDim.x));
+}
+
 template <int R, bool LEVEL0, bool DEFER = true>
 __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur(BlurArgs a)
 {
@@ -491,11 +913,15 @@ __global__ void k_dog(const float* a, const float* b, float* d, int W, int H, in
 
 // Tuning switches for A/B measurements on the GPU (read once): POPSIFT_BLUR_STEPS = marching steps per chunk
 // on large planes (default 5), POPSIFT_BLUR_DEFER=0 stores the vertical results at once (the round-1 kernel).
-struct BlurTuning { int steps; bool defer; };
+struct BlurTuning { int steps; bool defer; int dma; int dma_steps; };
 inline const BlurTuning& blur_tuning()
 {
     static const BlurTuning t = [] {
-        BlurTuning v{5, true};
+        BlurTuning v{5, true, 0, 0};
+        // POPSIFT_BLUR_DMA: 0 = register-staged k_blur, 2 / 3 = LDS-DMA staging with 2 / 3 stage buffers (k_blur_dma)
+        // 12 / 13 / 14 = the same with a dedicated loader wave per workgroup (k_blur_ldw) and 2 / 3 / 4 stage buffers
+        if (const char* e = getenv("POPSIFT_BLUR_DMA")) { const int n = atoi(e); if (n == 0 || n == 2 || n == 3 || (n >= 12 && n <= 14)) v.dma = n; }
+        if (const char* e = getenv("POPSIFT_BLUR_DMA_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.dma_steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_DEFER")) v.defer = e[0] != '0';
         return v;
@@ -552,6 +978,61 @@ hipError_t launch_blur2_r(const PsxBlurJob& ja, const PsxBlurJob& jb, hipStream_
     return hipGetLastError();
 }
 
+// ring rows of the LDS-DMA variant: the smallest multiple of 16 that holds a step's BR + 2R rows
+constexpr int dma_ring(int R) { return (BR + 2 * R + 15) & ~15; }
+inline int device_cus()
+{
+    static const int n = [] { int d = 0, c = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256; return c; }();
+    return n;
+}
+
+// Chunking for k_blur_dma.  A plane that fits one round of resident workgroups should be exactly one round (a second,
+// nearly empty round doubles the launch): take the smallest S >= 5 steps per chunk that fits; planes of several rounds
+// take 7 steps (less warm-up work per output row), small planes fewer (they are latency chains).
+inline void chunking_dma(int W, int H, int R, int slots, int& chunk_rows, int& nchunks)
+{
+    const int nstrips = (W + TW - 1) / TW;
+    auto nwg = [&](int S) { const int cr = S * BR - 2 * R; return nstrips * ((H + cr - 1) / cr); };
+    int S = blur_tuning().dma_steps;
+    if (S == 0) {
+        S = 5;
+        if (nwg(5) > slots) {
+            int fit = 0;
+            for (int q = 6; q <= 10; q++) if (nwg(q) <= slots) { fit = q; break; }
+            S = fit ? fit : 7;
+        } else {
+            for (; S > 2; S--) { const int cr = S * BR - 2 * R; if (cr >= BR && nwg(S) >= 384) break; }
+        }
+    }
+    int cr = S * BR - 2 * R;
+    if (cr < BR / 2) cr = BR / 2;
+    if (cr > H) cr = H;
+    chunk_rows = cr;
+    nchunks = (H + cr - 1) / cr;
+}
+
+template <int R, bool LEVEL0, int NBUF>
+void launch_dma(BlurArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    constexpr int RING = dma_ring(R);
+    int nchunks;
+    chunking_dma(a.W, a.H, R, dma_wg_per_cu<R, NBUF, RING>() * device_cus(), a.chunk_rows, nchunks);
+    const dim3 grid(a.nstrips * nchunks), block(NT);
+    if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((k_blur_dma<R, LEVEL0, NBUF, RING>), grid, block, 0, s, ev0, ev1, 0, a);
+    else                                  hipLaunchKernelGGL((k_blur_dma<R, LEVEL0, NBUF, RING>), grid, block, 0, s, a);
+}
+
+template <int R, bool LEVEL0, int NBUF>
+void launch_ldw(BlurArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    constexpr int RING = dma_ring(R);
+    int nchunks;
+    chunking_dma(a.W, a.H, R, dma_wg_per_cu<R, NBUF, RING>() * device_cus(), a.chunk_rows, nchunks);
+    const dim3 grid(a.nstrips * nchunks), block(NT_LDW);
+    if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((k_blur_ldw<R, LEVEL0, NBUF, RING>), grid, block, 0, s, ev0, ev1, 0, a);
+    else                                  hipLaunchKernelGGL((k_blur_ldw<R, LEVEL0, NBUF, RING>), grid, block, 0, s, a);
+}
+
 template <int R>
 hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, const PsxTaps& taps,
                          float* half_dst, int half_pitch, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
@@ -561,6 +1042,14 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
     j.src = src; j.dst = dst; j.half_dst = half_dst; j.W = W; j.H = H; j.pitch = pitch; j.half_pitch = half_pitch;
     j.taps = taps; j.span = R + 1;
     const dim3 grid(fill_job<R>(a, j)), block(NT);
+    if constexpr (R <= 13) {
+        const int dma = blur_tuning().dma;
+        if (dma == 2) { launch_dma<R, false, 2>(a, s, ev0, ev1); return hipGetLastError(); }
+        if (dma == 3) { launch_dma<R, false, 3>(a, s, ev0, ev1); return hipGetLastError(); }
+        if (dma == 12) { launch_ldw<R, false, 2>(a, s, ev0, ev1); return hipGetLastError(); }
+        if (dma == 13) { launch_ldw<R, false, 3>(a, s, ev0, ev1); return hipGetLastError(); }
+        if (dma == 14) { launch_ldw<R, false, 4>(a, s, ev0, ev1); return hipGetLastError(); }
+    }
     const bool ext = ev0 != nullptr || ev1 != nullptr;       // kernel begin / end timestamps of THIS dispatch (what rocprofv3 --kernel-trace reports)
     if (blur_tuning().defer) {
         if (ext) hipExtLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, ev0, ev1, 0, a);
@@ -596,6 +1085,14 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
 #ifdef PSX_PHASE_TIMING
     a.dbg = 0;
 #endif
+    if constexpr (R <= 8) {
+        const int dma = blur_tuning().dma;
+        if (dma == 2) { launch_dma<R, true, 2>(a, s, nullptr, nullptr); return hipGetLastError(); }
+        if (dma == 3) { launch_dma<R, true, 3>(a, s, nullptr, nullptr); return hipGetLastError(); }
+        if (dma == 12) { launch_ldw<R, true, 2>(a, s, nullptr, nullptr); return hipGetLastError(); }
+        if (dma == 13) { launch_ldw<R, true, 3>(a, s, nullptr, nullptr); return hipGetLastError(); }
+        if (dma == 14) { launch_ldw<R, true, 4>(a, s, nullptr, nullptr); return hipGetLastError(); }
+    }
     hipLaunchKernelGGL((k_blur<R, true>), dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
     return hipGetLastError();
 }

@@ -71,11 +71,23 @@ void to_psx( const popsift::Config& c, psx_config& p )
     p.grid_filter_mode    = (int)c.getFilterSorting();
 }
 
+// Worker threads (= extraction contexts) per PopSift.  Default: 8, but never more than this process' share of the
+// host cores -- with one replica per GPU (torchrun sets LOCAL_WORLD_SIZE; POPSIFT_LOCAL_REPLICAS for other launchers)
+// 8 x 8 workers plus the callers would oversubscribe a small host and the result hand-off, not the GPU, would bend the
+// 1 -> 8 curve.  POPSIFT_PIPE_DEPTH overrides.
 int pipe_depth()
 {
-    int d = 8;
-    if( const char* e = getenv( "POPSIFT_PIPE_DEPTH" ) ) d = atoi( e );
-    return d < 1 ? 1 : ( d > 32 ? 32 : d );
+    if( const char* e = getenv( "POPSIFT_PIPE_DEPTH" ) ) { const int d = atoi( e ); return d < 1 ? 1 : ( d > 32 ? 32 : d ); }
+    int cores = 0;
+    cpu_set_t set;
+    if( sched_getaffinity( 0, sizeof(set), &set ) == 0 ) cores = CPU_COUNT( &set );
+    if( cores <= 0 ) cores = (int)std::thread::hardware_concurrency();
+    int replicas = 1;
+    if( const char* e = getenv( "POPSIFT_LOCAL_REPLICAS" ) ) replicas = atoi( e );
+    else if( const char* e2 = getenv( "LOCAL_WORLD_SIZE" ) ) replicas = atoi( e2 );
+    if( replicas < 1 ) replicas = 1;
+    const int share = cores > 0 ? cores / replicas : 8;
+    return std::max( 2, std::min( 8, share ) );
 }
 
 // pinned bytes that jobs and result objects may hold before they fall back to pageable memory (POPSIFT_PINNED_LIMIT_MB)
@@ -171,6 +183,7 @@ struct PopSift::Impl
     int                          octaves_resolved = -1;  // sticky automatic octave count (popsift.cpp:118-122); cfg_mutex
     // POPSIFT_PROFILE=1: seconds spent per phase (all workers), printed by uninit()
     std::mutex                   prof_mutex;
+    std::mutex                   log_mutex;              // LogMode::All dumps share fixed file names: one frame at a time
     double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0, t_pool = 0;
     int    n_done = 0;
 };
@@ -245,6 +258,7 @@ void PopSift::uninit( )
     }
     _impl->contexts_exist = false;
     _isInit = false;
+    psx_match_release();                                // matcher scratch of the calling thread, if it ever matched
 }
 
 PopSift::AllocTest PopSift::testTextureFit( int width, int height )
@@ -346,22 +360,35 @@ popsift::FeaturesHost* collect_host( Slot& s, std::atomic<int>& want_desc, doubl
     const psx_feature* src = s.xfeat;
     std::vector<psx_feature> tmp;
     popsift::Descriptor* base = nullptr;
-    if( ne > EXPORT_FEATURES || no > s.desc_cap ) {
-        // result larger than the export targets: ordinary download of the complete device copy
-        size_t cap = 0;
-        base = (popsift::Descriptor*)popsift::pool::get_pinned( (size_t)std::max( no, 1 ) * sizeof(popsift::Descriptor), &cap );
-        if( base == nullptr ) { popsift::pool::put_plain( dst, ext_cap ); delete f; throw std::runtime_error( "out of host memory for descriptors" ); }
-        f->adopt( ne, no, dst, ext_cap, base, cap );
+    // the frame was launched with export targets attached (POPSIFT_EXPORT=1) and fits them: the kernels already
+    // stored records and descriptors into s.xfeat / s.xdesc.  Everything else is downloaded from the device copy --
+    // also a frame with keypoints and no descriptors: s.xfeat holds nothing the GPU wrote unless an export was attached.
+    const bool exported = s.xdesc != nullptr && s.desc_cap > 0 && ne <= EXPORT_FEATURES && no <= s.desc_cap;
+    const bool hoarding = popsift::pool::pinned_in_use() > pinned_limit();
+    if( !exported ) {
         psx_feature* ftarget = s.xfeat;                       // pinned: the D2H copy stays asynchronous
-        if( ftarget == nullptr || ne > EXPORT_FEATURES ) { tmp.resize( ne ); ftarget = tmp.data(); }
-        check( s.ctx, psx_download( s.ctx, ftarget, ne, (float*)base, no ), "psx_download" );
+        if( ftarget == nullptr || ne > EXPORT_FEATURES ) { tmp.resize( std::max( ne, 1 ) ); ftarget = tmp.data(); }
+        if( hoarding ) {
+            // a caller that hoards results must not exhaust pinned memory: beyond the limit the result gets ordinary
+            // page-aligned arrays (what the reference hands out, features.cu:58-84) and the download goes there
+            popsift::pool::put_plain( dst, ext_cap );
+            try { f->reset( ne, no ); } catch( ... ) { delete f; throw; }
+            dst = f->getFeatures();
+            base = f->getDescriptors();
+        } else {
+            size_t cap = 0;
+            base = (popsift::Descriptor*)popsift::pool::get_pinned( (size_t)std::max( no, 1 ) * sizeof(popsift::Descriptor), &cap );
+            if( base == nullptr ) { popsift::pool::put_plain( dst, ext_cap ); delete f; throw std::runtime_error( "out of host memory for descriptors" ); }
+            f->adopt( ne, no, dst, ext_cap, base, cap );
+        }
+        try {
+            check( s.ctx, psx_download( s.ctx, ftarget, ne, (float*)base, no ), "psx_download" );
+        } catch( ... ) { delete f; throw; }
         src = ftarget;
-    } else if( popsift::pool::pinned_in_use() > pinned_limit() ) {
-        // a caller that hoards results must not exhaust pinned memory: beyond the limit the result gets an
-        // ordinary page-aligned copy (what the reference hands out) and the context keeps its pinned buffer
-        f->reset( ne, no );
-        memcpy( f->getDescriptors(), s.xdesc, (size_t)no * sizeof(popsift::Descriptor) );
+    } else if( hoarding ) {
         popsift::pool::put_plain( dst, ext_cap );
+        try { f->reset( ne, no ); } catch( ... ) { delete f; throw; }
+        memcpy( f->getDescriptors(), s.xdesc, (size_t)no * sizeof(popsift::Descriptor) );
         dst = f->getFeatures();
         base = f->getDescriptors();
     } else {
@@ -494,6 +521,9 @@ void PopSift::dispatchLoop( )
             if( _proc_mode == popsift::Config::ExtractingMode ) {
                 f = collect_host( s, p.want_desc, &tf );
                 if( _config.getLogMode() == popsift::Config::All ) {      // popsift.cpp:330-338
+                    // the reference writes these dumps from its single worker (popsift.cpp:330-338); here PIPE_DEPTH
+                    // workers would interleave writes to the same dir-octave / dir-dog / dir-desc files
+                    std::lock_guard<std::mutex> lg( p.log_mutex );
                     std::string why;
                     if( !popsift::log_dump( s.ctx, static_cast<popsift::FeaturesHost*>( f ), _config.getUpscaleFactor(), "pyramid", &why ) )
                         throw std::runtime_error( "log output failed:\n    " + why );

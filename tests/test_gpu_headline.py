@@ -1,0 +1,100 @@
+"""Parity of the path bench.py's headline number times, at its own shape:
+distinct 1920x1080 frames -- bench.py's own frame set -- streamed through PopSift::enqueue / SiftJob::get
+(the loop replacing popsift.cpp:306-344) with 24 jobs outstanding over the worker contexts, pooled pinned
+result buffers recycled under load; EVERY result is matched against the oracle, per frame with budget() and
+summed over the run with the same rate.  A cross-frame race (a result buffer handed out twice, an upload
+overtaking a running frame) shows up as a frame whose features belong to another frame."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.headline_worker import bench_frames, stream
+from tests.parity import assert_parity, budget, match_features
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NFRAMES = 32
+_REF = {}
+
+
+def _ref(oracle, frames, i):
+    """oracle result of bench frame i (features, descriptors), computed once per session"""
+    if i not in _REF:
+        r = oracle.run(oracle.default_config(octaves=5), frames[i])
+        _REF[i] = (r.features().copy(), r.descriptors().copy())
+        r.close()
+    return _REF[i]
+
+
+def _check_all(oracle, frames, results, what):
+    n = len(frames)
+    tot = dict(kp=0, ori=0, desc=0, n=0)
+    assert len(results) % n == 0 and len(results) >= n
+    for j, (fb, db) in enumerate(results):
+        fa, da = _ref(oracle, frames, j % n)
+        assert len(fb) == len(fa) and len(db) == len(da), "%s: job %d (frame %d) has %d / %d features, oracle %d / %d" % (
+            what, j, j % n, len(fb), len(db), len(fa), len(da))
+        m = match_features(fa, da, fb, db)
+        assert_parity(m, what="%s job %d (frame %d)" % (what, j, j % n), **budget(len(fa)))
+        tot["kp"] += m["kp_miss"]; tot["ori"] += m["ori_miss"]; tot["desc"] += m["desc_miss"]; tot["n"] += len(fa)
+    b = budget(tot["n"])
+    assert tot["kp"] <= b["kp"] and tot["ori"] <= b["ori"] and tot["desc"] <= b["desc"], (what, tot, b)
+    return tot
+
+
+def test_headline_path_distinct_1080p_frames_24_outstanding(oracle, capi):
+    frames = bench_frames(NFRAMES)
+    assert len({f.tobytes() for f in frames}) == NFRAMES                 # really distinct
+    ps = capi.PopSift(capi.default_config(octaves=5))
+    results = stream(ps, frames, outstanding=24, passes=2)               # second pass: recycled pool buffers
+    ps.close()
+    tot = _check_all(oracle, frames, results, "e2e")
+    assert tot["n"] > 2 * NFRAMES * 5000
+
+
+@pytest.mark.parametrize("depth", [1, 16])
+def test_headline_path_pipe_depths(oracle, capi, depth):
+    frames = bench_frames(12)
+    old = os.environ.get("POPSIFT_PIPE_DEPTH")
+    os.environ["POPSIFT_PIPE_DEPTH"] = str(depth)
+    try:
+        ps = capi.PopSift(capi.default_config(octaves=5))
+    finally:
+        if old is None:
+            del os.environ["POPSIFT_PIPE_DEPTH"]
+        else:
+            os.environ["POPSIFT_PIPE_DEPTH"] = old
+    results = stream(ps, frames, outstanding=24, passes=2)
+    ps.close()
+    _check_all(oracle, frames, results, "pipe depth %d" % depth)
+
+
+def _worker(tmp_path, env, n, outstanding, passes, *extra):
+    out = str(tmp_path / "res.npz")
+    e = dict(os.environ)
+    e.update(env)
+    subprocess.run([sys.executable, "-m", "tests.headline_worker", out, str(n), str(outstanding), str(passes), *extra],
+                   cwd=ROOT, env=e, check=True, timeout=600)
+    z = np.load(out)
+    return [(z["f%d" % i], z["d%d" % i]) for i in range(len(z.files) // 2)]
+
+
+def test_headline_path_zero_copy_export(oracle, capi, tmp_path):
+    """POPSIFT_EXPORT=1: the descriptor kernel stores straight into the pinned buffer that becomes the FeaturesHost."""
+    frames = bench_frames(16)
+    results = _worker(tmp_path, {"POPSIFT_EXPORT": "1"}, 16, 24, 2)
+    _check_all(oracle, frames, results, "export")
+
+
+@pytest.mark.parametrize("export", ["0", "1"])
+def test_hoarded_results_fall_back_to_pageable_memory(oracle, capi, tmp_path, export):
+    """A caller that keeps every FeaturesHost alive with a 16 MB pinned limit: results beyond the limit come in
+    page-aligned pageable arrays (what the reference hands out) and are still the oracle's."""
+    frames = bench_frames(8)
+    results = _worker(tmp_path, {"POPSIFT_EXPORT": export, "POPSIFT_PINNED_LIMIT_MB": "16"}, 8, 8, 3, "keep")
+    assert len(results) == 24
+    _check_all(oracle, frames, results, "hoarding export=%s" % export)
