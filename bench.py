@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[1] / BASELINE.md workload 2): 1920x1080 grayscal
 Config with octaves=5, levels=3 (x2 upsample => octave 0 is 3840x2160), distinct frames streamed
 through the product's public API: host image -> PopSift::enqueue -> SiftJob::get -> FeaturesHost
 (the C++14 library popsift_amd/lib/libpopsift.so, bound through include/popsift_c.h).  A "step" is
-BATCH = 8 frames per GPU.  Frames are independent: frame i of the global sequence goes to GPU i mod N
+BATCH = 16 frames per GPU (so that the driver's 20 steps time 320 frames: SURVEY.md 8d asks for >= 200).  Frames are independent: frame i of the global sequence goes to GPU i mod N
 (BASELINE config 4), ranks share nothing, no collective on the data path (weak scaling);
 value = total pixels of all ranks / max-over-ranks time, results of every timed frame collected inside the
 timed region.
@@ -25,6 +25,12 @@ The JSON line also carries
   config3      : BASELINE config 3 (4096x4096, 6 octaves, 8192x8192 octave 0), device resident, one context
   cpu_baseline : the CPU oracle (port of the reference arithmetic, OpenMP over the host cores) timed on a
                  bounded sample of the same frames (rank 0, N=1 only)
+  parity_checked : 4 of the timed frames re-run through the SAME PopSift object after the timed region and matched
+                 against the oracle (exact mismatch counts)
+  sustained    : the end-to-end leg kept running for >= 3 s / >= 8000 frames (N=1): Mpix/s per 208-frame window
+                 (min / median / max), GPU clock before and after
+  sparse_frames: the end-to-end leg on a second frame set with ~2 keypoints / 1000 px (the default set has ~7)
+  pcie_gbs, pipe_roofline, roofline.stage, alt_modes_ms: see DESIGN.md section 6
 """
 import argparse
 import json
@@ -37,11 +43,50 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-BATCH = 8          # frames per step per rank
+BATCH = 16         # frames per step per rank (20 driver steps = 320 timed frames per GPU; SURVEY.md 8d: >= 200)
 NDISTINCT = 64     # distinct frames per rank that the steps cycle through
 NCTX = int(os.environ.get("POPSIFT_BENCH_CTX", "16"))       # C-ABI legs: extraction contexts in flight per GPU
 MAX_OUT = int(os.environ.get("POPSIFT_BENCH_OUTSTANDING", "24"))   # end-to-end leg: jobs outstanding per PopSift
 HBM_PEAK_GBS = 8000.0
+SUSTAINED_S = float(os.environ.get("POPSIFT_BENCH_SUSTAINED_S", "3.0"))
+SUSTAINED_FRAMES = int(os.environ.get("POPSIFT_BENCH_SUSTAINED_FRAMES", "8000"))
+WINDOW = 13 * BATCH                                          # frames per sustained-leg window (208)
+
+
+def octave_pixels(w, h, octaves, up=1):
+    """Pixels of every octave's planes for a w x h input (popsift.cpp:124-125, sift_pyramid.cu:132-133)."""
+    import math
+    W0, H0 = int(math.ceil(w * 2 ** up)), int(math.ceil(h * 2 ** up))
+    out = []
+    for _ in range(octaves):
+        out.append(W0 * H0)
+        W0, H0 = (W0 + 1) // 2, (H0 + 1) // 2
+    return out
+
+
+def algorithmic_bytes(w, h, octaves, levels=3, input_bytes_per_px=1):
+    """SURVEY.md 8d.  stage: the separable-Gaussian stage alone (8 B per pixel and level: octave 0 has levels+2
+    plane-to-plane blurs + level 0 from the input = 4 N written; octaves > 0 a decimation + levels+2 blurs);
+    pipe: A_min of the whole image pipe (+ 24 B per pixel for the fused DoG / extrema scan)."""
+    px = octave_pixels(w, h, octaves)
+    L = levels + 3
+    stage = (8 * (L - 1) + 4) * px[0] + (8 * (L - 1) + 8) * sum(px[1:]) + w * h * input_bytes_per_px
+    pipe = stage + 24 * sum(px)
+    return stage, pipe
+
+
+def read_sclk_mhz(device=0):
+    """Current shader clock from sysfs (the line marked '*' in pp_dpm_sclk); None when not readable."""
+    import glob
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        txt = open(cards[min(device, len(cards) - 1)]).read()
+        for line in txt.splitlines():
+            if line.strip().endswith("*"):
+                return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+    except Exception:
+        pass
+    return None
 
 
 def usable_cores():
@@ -61,11 +106,13 @@ def frame_seed(j, rank, world):
     return 1000 + j * world + rank
 
 
-def make_frames(rank, world, synth):
+def make_frames(rank, world, synth, sparse=False):
     """NDISTINCT distinct frames for this rank: BATCH synthetic base frames (popsift_amd/synth.py; base 0 of
-    rank 0 is the frame the parity tests check) and cheap distinct variants of them (cyclic shift + flip)."""
+    rank 0 is the frame the parity tests check) and cheap distinct variants of them (cyclic shift + flip).
+    sparse: the ~2 keypoints / 1000 px variant of the generator."""
     import numpy as np
-    base = [synth(W, H, frame_seed(j, rank, world)) for j in range(BATCH)]
+    base = [synth(W, H, frame_seed(j, rank, world), sparse=True) if sparse else synth(W, H, frame_seed(j, rank, world))
+            for j in range(BATCH)]
     frames = []
     for v in range(NDISTINCT // BATCH):
         for b in base:
@@ -92,10 +139,13 @@ class GpuBackend:
         self.np, self.torch, self.capi = np, torch, capi
         self.device = local_rank
         self.dev = torch.device("cuda", local_rank)
-        self.frames_np = make_frames(rank, world, synth)
+        self.frames_dense = make_frames(rank, world, synth)
+        self.frames_sparse = make_frames(rank, world, synth, sparse=True)
+        self.frames_np = self.frames_dense
         self.cfg = capi.default_config(octaves=5)
         self.ps = None
         self.ctxs = []
+        self.desc_total = 0
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -111,7 +161,36 @@ class GpuBackend:
         return self.ps.enqueue(self.frames_np[i % NDISTINCT])      # PopSift::enqueue (deep copy of the image)
 
     def e2e_get(self, job):
-        return self.ps.get_counts(job)[0]                          # SiftJob::get (blocks); FeaturesHost deleted
+        ne, no = self.ps.get_counts(job)                           # SiftJob::get (blocks); FeaturesHost deleted
+        self.desc_total += no
+        return ne
+
+    def e2e_select(self, which):
+        """frame set of the following end-to-end legs: 'dense' (default, ~7 keypoints / 1000 px) or 'sparse' (~2)"""
+        self.frames_np = self.frames_sparse if which == "sparse" else self.frames_dense
+
+    def e2e_parity(self, indices):
+        """Outside the timed region: the given timed frames once more through the SAME PopSift object, full results
+        matched against the oracle (the checker; nothing here is timed or shipped)."""
+        from oracle import pyoracle as po
+        from tests.parity import budget, match_features
+        ocfg = po.default_config(octaves=5)
+        tot = {"frames": 0, "keypoints": 0, "descriptors": 0, "kp_miss": 0, "ori_miss": 0, "desc_miss": 0, "max_desc_dist": 0.0}
+        jobs = [(i, self.ps.enqueue(self.frames_np[i % NDISTINCT])) for i in indices]
+        for i, job in jobs:
+            fb, db = self.ps.get(job)
+            ref = po.run(ocfg, self.frames_np[i % NDISTINCT])
+            fa, da = ref.features(), ref.descriptors()
+            m = match_features(fa, da, fb, db)
+            tot["frames"] += 1; tot["keypoints"] += len(fa); tot["descriptors"] += len(da)
+            tot["kp_miss"] += m["kp_miss"] + abs(len(fa) - len(fb)); tot["ori_miss"] += m["ori_miss"]; tot["desc_miss"] += m["desc_miss"]
+            tot["max_desc_dist"] = round(max(tot["max_desc_dist"], m["max_desc_dist"]), 6)
+            ref.close()
+        b = budget(tot["keypoints"])
+        tot["within_budget"] = bool(tot["kp_miss"] <= b["kp"] and tot["ori_miss"] <= b["ori"] and tot["desc_miss"] <= b["desc"])
+        tot["frame_indices"] = list(indices)
+        tot["what"] = "timed frames re-run through the same PopSift object after the timed region, matched against oracle/ (tolerances 1e-3, budget 0 keypoints, 1 + n/10000 orientations / descriptors)"
+        return tot
 
     def e2e_close(self):
         self.ps.close()
@@ -217,7 +296,49 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
             kp += be.e2e_get(jobs.popleft())
         return kp
 
+    desc0 = getattr(be, "desc_total", 0)
     dt_e2e, kps_e2e = timed(e2e_step, e2e_drain)
+    descs_e2e = getattr(be, "desc_total", 0) - desc0
+
+    # ---- outside the timed region, same PopSift object: parity of timed frames, sustained run, sparse frame set ----
+    parity = sustained = sparse = None
+    if hasattr(be, "e2e_parity") and not args.no_extras:
+        if rank == 0 and not args.no_parity:
+            parity = be.e2e_parity([0, NDISTINCT // 4 + 1, NDISTINCT // 2 + 2, 3 * NDISTINCT // 4 + 3])
+        if world == 1 and SUSTAINED_S > 0:
+            wins, clk, n_s, kp_s = [], [], 0, 0
+            t_s0 = tw = time.perf_counter()
+            while n_s < SUSTAINED_FRAMES or time.perf_counter() - t_s0 < SUSTAINED_S:
+                kp_s += e2e_step()
+                n_s += BATCH
+                if n_s % WINDOW == 0:
+                    now = time.perf_counter()
+                    wins.append(WINDOW * W * H / (now - tw) / 1e6)
+                    tw = now
+                    if len(wins) % 4 == 1:                    # shader clock WHILE the pipe is full (an idle GPU reads ~150 MHz)
+                        c = read_sclk_mhz(local_rank)
+                        if c:
+                            clk.append(c)
+            kp_s += e2e_drain()
+            dt_s = time.perf_counter() - t_s0
+            first, last = wins[:len(wins) // 4 or 1], wins[-(len(wins) // 4 or 1):]
+            wins_sorted = sorted(wins)
+            sustained = {"seconds": round(dt_s, 3), "frames": n_s, "value": round(n_s * W * H / dt_s / 1e6, 1), "unit": "Mpix/s",
+                         "window_frames": WINDOW, "window_min": round(wins_sorted[0], 1),
+                         "window_median": round(wins_sorted[len(wins) // 2], 1), "window_max": round(wins_sorted[-1], 1),
+                         "first_quarter_mean": round(sum(first) / len(first), 1), "last_quarter_mean": round(sum(last) / len(last), 1),
+                         "sclk_mhz_first": clk[0] if clk else None, "sclk_mhz_last": clk[-1] if clk else None,
+                         "sclk_mhz_min": min(clk) if clk else None, "sclk_mhz_max": max(clk) if clk else None,
+                         "keypoints_per_s": round(kp_s / dt_s, 1)}
+        be.e2e_select("sparse")
+        e2e["i"] = 0
+        dt_sp, kps_sp = timed(e2e_step, e2e_drain)
+        be.e2e_select("dense")
+        sparse = {"value": round(world * BATCH * args.steps * W * H / dt_sp / 1e6, 1), "unit": "Mpix/s",
+                  "keypoints_per_frame": round(kps_sp / (world * BATCH * args.steps), 1),
+                  "keypoints_per_1000px": round(kps_sp / (world * BATCH * args.steps) / (W * H / 1000.0), 2),
+                  "keypoints_per_s": round(kps_sp / dt_sp, 1),
+                  "what": "the end-to-end leg on frames with ~2 keypoints / 1000 px (popsift_amd/synth.py sparse=True)"}
     be.e2e_close()
 
     # ---- legs 2 and 3: C-ABI, inputs already resident in HBM ----
@@ -265,17 +386,32 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
                                    "pipe (pyramid, extrema, orientation, descriptors)" % NDISTINCT,
                        "frames_per_step_per_gpu": BATCH, "frames_timed": n_frames,
                        "jobs_outstanding_per_gpu": MAX_OUT,
-                       "pipe_depth": int(os.environ.get("POPSIFT_PIPE_DEPTH", "8")),
+                       "pipe_depth": os.environ.get("POPSIFT_PIPE_DEPTH", "min(8, usable cores / local replicas)"),
                        "parallelism": "replicas x%d (frame i -> GPU i mod N, no collective)" % world},
             "keypoints_per_s": round(kps_e2e / dt_e2e, 1),
             "keypoints_per_frame": round(kps_e2e / n_frames, 1),
             "ms_per_frame": round(dt_e2e / (BATCH * args.steps) * 1e3, 4),
+            "keypoints_per_1000px": round(kps_e2e / n_frames / (W * H / 1000.0), 2),
+            "parity_checked": parity, "sustained": sustained, "sparse_frames": sparse,
             "device_resident": {"value": rate(dt_dev), "unit": "Mpix/s", "ms_per_step": round(dt_dev / args.steps * 1e3, 4),
                                 "keypoints_per_s": round(kps_dev / dt_dev, 1), "contexts_per_gpu": NCTX,
                                 "what": "C-ABI psx_extract, inputs and results resident in HBM (no PCIe in the timed region)"},
             "host_export": {"value": rate(dt_x), "unit": "Mpix/s", "ms_per_step": round(dt_x / args.steps * 1e3, 4),
                             "what": "C-ABI, inputs resident in HBM, Feature records + descriptors streamed into pinned host memory"},
         }
+        if hasattr(be, "desc_total"):
+            # PCIe inside the timed region of `value`: the u8 frame up, 52-byte records + 512-byte descriptors down
+            h2d = n_frames * W * H
+            d2h = kps_e2e * 52 + descs_e2e * 512 * (world if world > 1 else 1)
+            result["pcie_gbs"] = {"h2d": round(h2d / dt_e2e / 1e9, 2), "d2h": round(d2h / dt_e2e / 1e9, 2),
+                                  "what": "host<->device bytes of the end-to-end leg / its time (all GPUs; D2H from rank 0's descriptor count)"}
+        stage_b, pipe_b = algorithmic_bytes(W, H, 5)
+        result["pipe_roofline"] = {
+            "algorithmic_bytes_per_frame": pipe_b, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "end_to_end": round(pipe_b * n_frames / dt_e2e / 1e9, 1), "device_resident": round(pipe_b * n_frames / dt_dev / 1e9, 1),
+            "frac_end_to_end": round(pipe_b * n_frames / dt_e2e / 1e9 / HBM_PEAK_GBS / world, 4),
+            "frac_device_resident": round(pipe_b * n_frames / dt_dev / 1e9 / HBM_PEAK_GBS / world, 4),
+            "what": "A_min of SURVEY.md 8d (68 N0 + 72 sum N_o + input) x frames / time, per GPU fraction of 8 TB/s"}
         if not args.no_extras:
             result.update(be.extras(args, world))
         print(json.dumps(result), file=out, flush=True)
@@ -293,6 +429,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of 4 timed frames")
     ap.add_argument("--no-extras", action="store_true", help="only the three timed legs")
     return ap.parse_args(argv)
 
@@ -340,6 +477,8 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "avg_launch_ms": round(avg_ms, 5), "per_level_ms": [round(m, 5) for m in per_level],
         "bytes_per_launch": by, "traffic": traffic,
+        "traffic_source": "profiles/pmc_summary.json: a committed rocprofv3 --pmc pass of an earlier builder run (FETCH_SIZE x 2 + WRITE_SIZE, "
+                          "MI355X_MICROARCH.md HBM section), NOT measured in this run",
         "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
         "measured_copy_what": "hand-written 16 B/lane copy kernel, 1 GiB read + 1 GiB written (psx_copy_bench)",
         "isolated_replay_avg_ms": round(sum(iso) / len(iso), 5),
@@ -362,6 +501,36 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
                           "what": "median wall time of one frame at a time on one context (no overlap between frames)"}
     ex["stage_ms_single_frame"] = {"pyramid": round(stages[0], 4), "extrema": round(stages[1], 4),
                                    "orientation": round(stages[2], 4), "descriptors": round(stages[3], 4)}
+    # the separable-Gaussian STAGE (every level of every octave, level 0 from the input), not one launch
+    stage_b, _ = algorithmic_bytes(W, H, 5)
+    stage_gbs = stage_b / (stages[0] * 1e-3) / 1e9
+    ex["roofline"]["stage"] = {"bytes": stage_b, "ms": round(stages[0], 4), "achieved": round(stage_gbs, 1), "unit": "GB/s",
+                               "frac": round(stage_gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(stage_gbs / copy_gbs, 4),
+                               "what": "algorithmic bytes of the whole pyramid build (SURVEY.md 8d: 44 N0 + 48 sum N_o + input) / "
+                                       "pyramid stage time of one frame on one context (HIP events around psx_build_pyramid)"}
+
+    # ---- every alternative Gauss / scaling / descriptor mode once: single-frame wall time, one context ----
+    try:
+        alt = {}
+        for name, kw in (("gauss_relative", dict(gauss_mode=1)), ("gauss_relative_all", dict(gauss_mode=2)),
+                         ("gauss_opencv", dict(gauss_mode=3)), ("gauss_fixed9", dict(gauss_mode=4)),
+                         ("gauss_fixed15", dict(gauss_mode=5)), ("scale_direct", dict(scaling_mode=0)),
+                         ("desc_iloop", dict(desc_mode=1)), ("desc_grid", dict(desc_mode=2)),
+                         ("desc_igrid", dict(desc_mode=3)), ("desc_notile", dict(desc_mode=4))):
+            ca = capi.Context(capi.default_config(octaves=5, **kw), device=device)
+            ca.set_input_tensor(frames[0])
+            ts = []
+            for i in range(7):
+                t1 = time.perf_counter()
+                ca.extract()
+                ca.counts()
+                ts.append(time.perf_counter() - t1)
+            alt[name] = round(sorted(ts[2:])[len(ts[2:]) // 2] * 1e3, 4)
+            ca.close()
+        alt["default"] = round(single_ms, 4)
+        ex["alt_modes_ms"] = alt
+    except Exception as e:
+        ex["alt_modes_ms"] = "failed: %s" % e
 
     # ---- BASELINE config 3: 4096x4096, 6 octaves (octave 0 = 8192x8192), one context, device resident ----
     try:

@@ -111,6 +111,8 @@ def lib():
             f = getattr(L, name)
             f.argtypes = [C.c_void_p]
             f.restype = C.c_void_p
+        L.osift_describe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.osift_describe.restype = C.c_int
         L.osift_set_threads.argtypes = [C.c_int]
         L.osift_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.osift_match.restype = None
@@ -203,6 +205,15 @@ class Result:
 
     def feat_to_ext(self):
         return _arr(lib().osift_feat_to_ext(self._h), np.int32, self.ori_total)
+
+    def describe(self, extrema, n_desc):
+        """Descriptor stage alone on this result's pyramid for caller-supplied oriented extrema (EXT_DTYPE records,
+        e.g. a device run's psx_dump_extrema): (n_desc, 128) array indexed by idx_ori + k."""
+        ext = np.ascontiguousarray(extrema)
+        assert ext.dtype.itemsize == EXT_DTYPE.itemsize
+        out = np.zeros((max(n_desc, 1), 128), np.float32)
+        lib().osift_describe(self._h, ext.ctypes.data, len(ext), n_desc, out.ctypes.data)
+        return out[:n_desc]
 
     def close(self):
         if self._h:

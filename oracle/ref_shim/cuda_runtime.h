@@ -238,9 +238,17 @@ static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; retu
 
 // glibc's <math.h> declares __expf / __sincosf as its own internal entry points: rename ours
 static inline float shim_expf_(float x) { return expf(x); }
-static inline void shim_sincosf_(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
+// evaluated in double and rounded once: the grid descriptor's pixel snapping (s_desc_grid.cu:72-78) flips on the last
+// bit of sin / cos, so the stand-in must not depend on libm's float sinf / cosf rounding (oracle/sift_oracle.c does the same)
+static inline void shim_sincosf_(float a, float* s, float* c) { *s = (float)sin((double)a); *c = (float)cos((double)a); }
 #define __expf shim_expf_
 #define __sincosf shim_sincosf_
+// CUDA's atan2f (<= 2 ulp, unspecified beyond that) picks the orientation-histogram bin through
+// roundf(36 (theta + pi) / 2 pi) (s_orientation.cu:148-151): on exactly diagonal gradients (binary images, symmetric
+// patterns) the bin hangs on theta's last ulp.  The stand-in is the correctly rounded value -- atan2 in double,
+// rounded once -- which the oracle and the HIP kernel use too, so that all three sides take the same bin.
+static inline float shim_atan2f_(float y, float x) { return (float)atan2((double)y, (double)x); }
+#define atan2f shim_atan2f_
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float __fsqrt_rn(float a) { return sqrtf(a); }

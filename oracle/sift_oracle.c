@@ -1052,13 +1052,19 @@ static inline float rdata(const float* plane, int W, int H, int x, int y)
     return plane[(size_t)y * W + x];
 }
 
+/* atan2f of the reference's device code (CUDA libdevice, <= 2 ulp): the angle picks the orientation-histogram bin
+ * through roundf(36 (theta + pi) / 2 pi), and on exactly diagonal gradients (binary images, symmetric patterns) the
+ * bin hangs on theta's last ulp.  All sides -- this file, the HIP kernels' exact path, the shim's stand-in --
+ * therefore use the correctly rounded value: atan2 evaluated in double, rounded once. */
+static inline float atan2f_1r(float y, float x) { return (float)atan2((double)y, (double)x); }
+
 /* s_gradiant.h:56-69 (texture variant) */
 static inline void get_gradiant(float* grad, float* theta, int x, int y, const float* plane, int W, int H)
 {
     float dx = rdata(plane, W, H, x + 1, y) - rdata(plane, W, H, x - 1, y);
     float dy = rdata(plane, W, H, x, y + 1) - rdata(plane, W, H, x, y - 1);
     *grad  = hypotf(dx, dy);
-    *theta = atan2f(dy, dx);
+    *theta = atan2f_1r(dy, dx);
 }
 
 /* common/warp_bitonic_sort.h:17-79, lane-synchronous emulation of Warp32<float>::sort64 */
@@ -1355,7 +1361,7 @@ static inline void get_gradiant_rot(float* grad, float* theta, float x, float y,
     const float dx = plane_linear(plane, W, H, x + cos_t, y + sin_t) - plane_linear(plane, W, H, x - cos_t, y - sin_t);
     const float dy = plane_linear(plane, W, H, x - sin_t, y + cos_t) - plane_linear(plane, W, H, x + sin_t, y - cos_t);
     *grad = hypotf(dx, dy);
-    *theta = atan2f(dy, dx);
+    *theta = atan2f_1r(dy, dx);
 }
 
 /* point-texture gradient at float coordinates that are integers after rounding (s_gradiant.h:56-69 called
@@ -1365,7 +1371,7 @@ static inline void get_gradiant_pt(float* grad, float* theta, int x, int y, cons
     const float dx = rdata(plane, W, H, x + 1, y) - rdata(plane, W, H, x - 1, y);
     const float dy = rdata(plane, W, H, x, y + 1) - rdata(plane, W, H, x, y - 1);
     *grad = hypotf(dx, dy);
-    *theta = atan2f(dy, dx);
+    *theta = atan2f_1r(dy, dx);
 }
 
 /* the shuffle_down tree of a group of `width` lanes as lane 0 sees it (lanes beyond the group read their own value) */
@@ -1442,7 +1448,11 @@ static void descriptor_grid(const osift_result* r, const osift_ext* ext, float a
     const float* plane = r->data[o] + (size_t)clampi(ext->lpos, 0, r->L - 1) * W * H;
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (SBP == 0) return;
-    const float cos_t = cosf(ang), sin_t = sinf(ang);          /* __sincosf */
+    /* __sincosf in the reference.  The sample positions of this mode go through (int)(pt + (round(pt + pix) - pt)),
+     * which flips to the neighbouring pixel on the last bit of pt, i.e. of sin / cos: all three sides (this file, the
+     * HIP kernel, the shim's __sincosf stand-in) therefore evaluate them in double and round ONCE, so that equal
+     * orientation bits give equal sample positions. */
+    const float cos_t = (float)cos((double)ang), sin_t = (float)sin((double)ang);
     const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
     for (int iy = 0; iy < 4; iy++)
     for (int ix = 0; ix < 4; ix++) {
@@ -1743,6 +1753,34 @@ static osift_result* run_impl(const osift_config* cin, const void* img, int w, i
 
 osift_result* osift_run(const osift_config* c, const void* img, int w, int h, int is_float)
 { return run_impl(c, img, w, h, is_float, 1); }
+
+/* Descriptor stage alone (sift_desc.cu:66-83 + normalisation) on r's pyramid for CALLER-SUPPLIED oriented extrema
+ * (e.g. the ones a device run produced, bit for bit): descriptor k of extremum i goes to out + (idx_ori + k) * 128.
+ * Lets a test compare the descriptor arithmetic under identical keypoint and orientation bits. */
+int osift_describe(const osift_result* r, const osift_ext* ext, int n_ext, int n_desc, float* out)
+{
+    const osift_config* c = &r->cfg;
+    init_desc_tables();
+    #pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < n_ext; i++) {
+        const osift_ext* e = &ext[i];
+        if (e->octave < 0 || e->octave >= r->num_octaves) continue;
+        for (int k = 0; k < e->num_ori && k < OSIFT_ORI_MAX; k++) {
+            const int j = e->idx_ori + k;
+            if (j < 0 || j >= n_desc) continue;
+            float* dj = out + (size_t)j * 128;
+            switch (c->desc_mode) {
+            case OSIFT_DESC_ILOOP:  descriptor_iloop(r, e, e->orientation[k], dj); break;
+            case OSIFT_DESC_GRID:   descriptor_grid(r, e, e->orientation[k], dj); break;
+            case OSIFT_DESC_IGRID:  descriptor_igrid(r, e, e->orientation[k], dj); break;
+            case OSIFT_DESC_NOTILE: descriptor_notile(r, e, e->orientation[k], dj); break;
+            default:                descriptor_one(r, e, e->orientation[k], dj); break;
+            }
+            normalize_desc(c, dj);
+        }
+    }
+    return 0;
+}
 osift_result* osift_run_pyramid(const osift_config* c, const void* img, int w, int h, int is_float)
 { return run_impl(c, img, w, h, is_float, 0); }
 

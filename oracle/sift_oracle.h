@@ -164,6 +164,11 @@ const osift_feature* osift_features(const osift_result* r);
 const float*         osift_descriptors(const osift_result* r);   /* ori_total * 128 */
 const int*           osift_feat_to_ext(const osift_result* r);   /* ori_total */
 
+/* Descriptor stage alone on r's pyramid and config for caller-supplied oriented extrema (same layout as the
+ * device's psx_extremum): descriptor k of extremum i is written to out + (ext[i].idx_ori + k) * 128 when that index
+ * is below n_desc.  For stage-level parity under identical keypoint / orientation bits. */
+int   osift_describe(const osift_result* r, const osift_ext* ext, int n_ext, int n_desc, float* out);
+
 /* set number of OpenMP threads used by osift_run (0 = library default) */
 void  osift_set_threads(int n);
 

@@ -2,7 +2,7 @@
 
   popsift_amd/lib/libpopsift_hip.so   C-ABI + HIP kernels for gfx950 (hipcc)
   popsift_amd/lib/libpopsift.so       C++14 host library: PopSift / SiftJob / Config / Features (g++)
-  popsift_amd/lib/popsift_demo        small C++ driver over the C++ API (raw frames; used by tests)
+  popsift_amd/lib/popsift-testdriver        small C++ driver over the C++ API (raw frames; used by tests)
   popsift_amd/lib/popsift-demo        the command line extractor (PGM/PPM in, output-features.txt out; reference main.cpp)
   popsift_amd/lib/popsift-match       the MatchingMode tool (reference match.cpp)
 
@@ -101,9 +101,9 @@ def build_host(verbose=False):
     so = os.path.join(LIBDIR, "libpopsift.so")
     if rebuilt or not os.path.exists(so):
         _run(["g++", "-shared", "-fPIC", "-pthread", "-o", so] + objs +
-             ["-L", LIBDIR, "-lpopsift_hip", "-Wl,-rpath,$ORIGIN"])
-    demo_src = os.path.join(hostdir, "demo_main.cpp")
-    demo = os.path.join(LIBDIR, "popsift_demo")
+             ["-L", LIBDIR, "-lpopsift_hip", "-ldl", "-Wl,-rpath,$ORIGIN"])
+    demo_src = os.path.join(hostdir, "testdriver_main.cpp")
+    demo = os.path.join(LIBDIR, "popsift-testdriver")
     if os.path.exists(demo_src) and (_newer(demo, [demo_src, so] + hdrs)):
         _run(["g++"] + HOST_FLAGS + [demo_src, "-o", demo, "-L", LIBDIR, "-lpopsift", "-lpopsift_hip",
                                       "-Wl,-rpath,$ORIGIN"])

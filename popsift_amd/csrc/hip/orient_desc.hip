@@ -85,6 +85,9 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // atan2 on the gradient: degree-13 odd minimax polynomial for atan (max error 3.3e-7 rad), v_rcp_f32
+// atan2 evaluated in double and rounded once (what oracle/sift_oracle.c::atan2f_1r does): only on the rare exact path
+__device__ __noinline__ float atan2_1r(float y, float x) { return (float)atan2((double)y, (double)x); }
+
 __device__ __forceinline__ float fast_atan2(float y, float x)
 {
     const float ax = fabsf(x), ay = fabsf(y);
@@ -239,16 +242,18 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                     at = (gy < 0.0f) ? -at : at;
                     const float grad = __builtin_amdgcn_sqrtf(e == 0 ? m2.x : m2.y);
                     const float weight = grad * __builtin_amdgcn_exp2f((float)(e == 0 ? sq0 : sq1) * factor2);
-                    // Bin = roundf(36 (atan2f(gdy,gdx) + pi) / 2pi) with accurate atan2f and IEEE division, as in the
-                    // CPU restatement: gradients along exact bin boundaries (gdx == gdy gives 45 deg = bin 22.5) are common in
-                    // smooth images and one heavy sample in the wrong bin moves the interpolated peak by ~6e-3 rad.
+                    // Bin = roundf(36 (atan2f(gdy,gdx) + pi) / 2pi) with the correctly rounded atan2 (evaluated in double,
+                    // rounded once: the CPU restatement and the reference shim do the same) and IEEE division: gradients
+                    // along exact bin boundaries (gdx == gdy gives 45 deg = bin 22.5) are common in smooth images and
+                    // the rule in binary / symmetric ones, where the bin hangs on the last ulp of the angle; one heavy
+                    // sample in the wrong bin moves the interpolated peak by ~6e-3 rad.
                     // The 3.3e-7 rad polynomial (2e-6 bins) decides every sample that is not within 1e-3 bins of a
                     // boundary; only those (about 0.2 % of the samples) take the exact, ~50-instruction form.
                     const float bfast = (float)ORI_NBINS * (at + PI_F) * (1.0f / PI2_F);
                     const float bfl = floorf(bfast);
                     int bidx = (int)bfl + ((bfast - bfl) >= 0.5f ? 1 : 0);
                     if (fabsf((bfast - bfl) - 0.5f) < 1e-3f)
-                        bidx = (int)roundf((float)ORI_NBINS * (atan2f(gy, gx) + PI_F) / PI2_F);
+                        bidx = (int)roundf((float)ORI_NBINS * (atan2_1r(gy, gx) + PI_F) / PI2_F);
                     bidx = (bidx == ORI_NBINS) ? 0 : bidx;
                     atomicAdd(&myhist[bidx], (fix64)(weight * OFIX));
                 }
@@ -774,7 +779,7 @@ __device__ __forceinline__ void d_gradiant_rot(float& grad, float& theta, float 
     const float dx = d_plane_linear(plane, W, H, pitch, x + cos_t, y + sin_t) - d_plane_linear(plane, W, H, pitch, x - cos_t, y - sin_t);
     const float dy = d_plane_linear(plane, W, H, pitch, x - sin_t, y + cos_t) - d_plane_linear(plane, W, H, pitch, x + sin_t, y - cos_t);
     grad = hypotf(dx, dy);
-    theta = atan2f(dy, dx);
+    theta = atan2_1r(dy, dx);
 }
 // get_gradiant on the point texture at integer coordinates (s_gradiant.h:56-69)
 __device__ __forceinline__ void d_gradiant_pt(float& grad, float& theta, int x, int y, const float* plane, int W, int H, int pitch)
@@ -783,7 +788,7 @@ __device__ __forceinline__ void d_gradiant_pt(float& grad, float& theta, int x, 
     const float dx = rd(x + 1, y) - rd(x - 1, y);
     const float dy = rd(x, y + 1) - rd(x, y - 1);
     grad = hypotf(dx, dy);
-    theta = atan2f(dy, dx);
+    theta = atan2_1r(dy, dx);
 }
 
 constexpr int ALT_BINS = 9;
@@ -818,7 +823,10 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
         wave_fence();
 
         if (SBP != 0.0f) {
-            const float cos_t = cosf(ang), sin_t = sinf(ang);      // __sincosf
+            // __sincosf in the reference.  GRID snaps its sample points through (int)(pt + (round(pt + pix) - pt)), which
+            // flips on the last bit of sin / cos: that mode evaluates them in double and rounds once, as the oracle does
+            const float cos_t = MODE == PSX_DESC_GRID ? (float)cos((double)ang) : cosf(ang);
+            const float sin_t = MODE == PSX_DESC_GRID ? (float)sin((double)ang) : sinf(ang);
             const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
 
             if (MODE == PSX_DESC_ILOOP) {

@@ -750,6 +750,200 @@ __global__ __launch_bounds__(NT_LDW, (ldw_waves_per_simd<R, NBUF, RINGROWS>())) 
     blur_body_ldw<R, LEVEL0, NBUF, RINGROWS>(a, xcd_remap(blockIdx.x, gridDim.x));
 }
 
+template <int R, int NB>
+constexpr int dma_wg_per_cu_fwd()
+{
+    const int lds = GeomD<R, NB, ((2 * BR + 2 * R + 15) & ~15)>::LDS_FLOATS * 4;
+    const int n = (160 * 1024) / lds;
+    return n > 4 ? 4 : (n < 1 ? 1 : n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// blur_body_hv: the horizontal and the vertical pass on DIFFERENT waves, running concurrently.
+// The stamps and counters of round 3 say that a step of k_blur is a serial chain inside the workgroup -- wait for the
+// staged rows, H, barrier, V, stores -- and that only the four workgroups of a CU overlap each other.  Here waves 0-1
+// (the H role) bring step k's rows in by LDS-DMA and filter them horizontally into the ring while waves 2-3 (the V
+// role) filter step k-1's ring rows vertically and store them: ONE barrier per step, both roles carry the same
+// arithmetic (4 (2R+1) packed operations per task, two tasks per lane), the H waves' vmcnt only ever holds DMA
+// batches (counted waits) and the V waves never wait on memory at all.
+// Ring: rows being written by H(k) + the window V(k-1) reads = 2 BR + 2R rows.  Stage buffers: NB = 2 (batch k+1
+// issued at the top of iteration k into the buffer H(k-1) read) or 3 (batch k+2 issued after H(k)).
+// Iteration k: H(k) || V(k-1); the H waves wait for batch k+1 before the barrier, so after it every wave may read it.
+// ---------------------------------------------------------------------------------------------
+template <int R, int NB, int RINGROWS>
+__device__ __forceinline__ void blur_body_hv(const BlurArgs& a, const int lid)
+{
+    using G = GeomD<R, NB, RINGROWS>;
+    constexpr int HALO = G::HALO, SW = G::SW, CH = G::CH, SWA = G::SWA, NLDT = G::NLDT, P = G::P;
+    constexpr int RING = G::RING, VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS, STAGE = G::STAGE_FLOATS;
+    constexpr int NLDH = NLDT / 2;                       // DMA wave instructions per H wave and step
+    static_assert(NLDT % 2 == 0 && (NB == 2 || NB == 3), "geometry");
+    static_assert(RING >= 2 * BR + 2 * R, "ring holds the rows H writes plus the window V reads");
+    __shared__ __attribute__((aligned(16))) float s_all[G::LDS_FLOATS];
+    float* const s_ring = s_all + NB * STAGE;
+
+    const int t     = threadIdx.x;
+    const int lane  = t & 63;
+    const int wv    = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int strip = lid % a.nstrips;
+    const int chunk = lid / a.nstrips;
+    const int x0    = strip * TW;
+    const int Y0    = chunk * a.chunk_rows;
+    const int Y1    = min(Y0 + a.chunk_rows, a.H);
+    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
+    const int xs0   = x0 - HALO + a.src_xoff;
+    const bool interior = (xs0 >= 0) && (xs0 + SW <= a.src_width);
+    const int e_l = min(max(-xs0, 0), SW - 1), e_r = max(min(a.src_width - xs0, SW), 1);
+
+    if (wv < 2) {
+        // ------------------------------ H role: waves 0, 1 ------------------------------
+        const unsigned lds0 = (unsigned)(unsigned long)(LDS_AS float*)s_all;
+        unsigned st_xb[NLDH], st_off[NLDH];
+#pragma unroll
+        for (int j = 0; j < NLDH; j++) {
+            const int c = (wv * NLDH + j) * P + lane;
+            const int row = c / CH, cc = c - row * CH;
+            const int xc = psx_clampi(xs0 + cc * 4, 0, a.src_pitch - 4);
+            st_xb[j]  = (unsigned)xc * 4u;
+            st_off[j] = (unsigned)(row * a.src_pitch) * 4u + st_xb[j];
+        }
+        auto issue = [&](const int k) {
+            const int ybase = Y0 - R + k * BR;
+            const unsigned buf = lds0 + (unsigned)((k % NB) * STAGE * 4);
+            if (ybase >= 0 && ybase + BR <= a.H) {
+                const char* step_base = reinterpret_cast<const char*>(a.src + (ptrdiff_t)ybase * a.src_pitch);
+#pragma unroll
+                for (int j = 0; j < NLDH; j++) dma16<P>(step_base, st_off[j], buf + (unsigned)((wv * NLDH + j) * P * 16));
+            } else {
+#pragma unroll
+                for (int j = 0; j < NLDH; j++) {
+                    const int row = ((wv * NLDH + j) * P + lane) / CH;
+                    const int y = psx_clampi(ybase + row, 0, a.H - 1);
+                    dma16<P>(reinterpret_cast<const char*>(a.src), (unsigned)(y * a.src_pitch) * 4u + st_xb[j], buf + (unsigned)((wv * NLDH + j) * P * 16));
+                }
+            }
+        };
+        // two tasks per lane: virtual thread ids t and t + 128 of the 256-thread layout of blur_body
+        int h_off[2], h_rowv[2], h_segv[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int tv = t + 128 * q;
+            const int blk = (tv & 31) >> 2;
+            const int rq = (0x21120330 >> (4 * blk)) & 3;
+            const int sh = (0xCC >> blk) & 1;
+            h_rowv[q] = (tv >> 6) * 8 + ((tv >> 5) & 1) * 4 + rq;
+            h_segv[q] = sh * 4 + (tv & 3);
+            h_off[q]  = h_rowv[q] * SWA + h_segv[q] * 8;
+        }
+
+        issue(0);
+        if (NB == 3 && nsteps > 1) { issue(1); wait_vmcnt<NLDH>(); } else wait_vmcnt<0>();
+        __syncthreads();                                 // batch 0 visible
+        int sbase = 0;
+        for (int k = 0; k <= nsteps; k++) {
+            if (k < nsteps) {
+                if (NB == 2 && k + 1 < nsteps) issue(k + 1);           // into the buffer H(k-1) read
+                float* const stage = s_all + (k % NB) * STAGE;
+                if (!interior) {
+                    const int row = t >> 2, sub = t & 3;               // 128 threads: 32 rows x 4
+                    float* rp = stage + row * SWA;
+                    const float vl = rp[e_l], vr = rp[e_r - 1];
+                    for (int c = sub; c < e_l; c += 4) rp[c] = vl;
+                    for (int c = e_r + sub; c < SW; c += 4) rp[c] = vr;
+                    __syncthreads();                                   // edge strips only (the V waves join it)
+                }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const LDS_AS float* h_src = (const LDS_AS float*)(stage + h_off[q]);
+                    float win[8 + 2 * HALO];
+#pragma unroll
+                    for (int i = 0; i < (8 + 2 * HALO) / 4; i++) {
+                        const v4f v = ((const volatile LDS_AS v4f*)h_src)[i];
+                        win[4 * i + 0] = v.x; win[4 * i + 1] = v.y; win[4 * i + 2] = v.z; win[4 * i + 3] = v.w;
+                    }
+                    float out[8];
+                    hfilter8_km<R, HALO, false>(win, a.taps, out);
+                    int slot = sbase + h_rowv[q]; if (slot >= RING) slot -= RING;
+                    float* rp = &s_ring[slot * RS + h_segv[q] * 8];
+                    reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
+                    reinterpret_cast<float4*>(rp)[1] = make_float4(out[4], out[5], out[6], out[7]);
+                    if (slot < MIRROR) {
+                        reinterpret_cast<float4*>(rp + RING * RS)[0] = make_float4(out[0], out[1], out[2], out[3]);
+                        reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
+                    }
+                }
+                if (NB == 3 && k + 2 < nsteps) issue(k + 2);           // into the buffer H(k-1) read
+                // batch k+1 must have landed before the barrier; a newer batch (NB == 3) stays in flight
+                if (NB == 3 && k + 2 < nsteps) wait_vmcnt<NLDH>(); else wait_vmcnt<0>();
+            } else if (!interior) {
+                // nothing
+            }
+            __syncthreads();
+            sbase += BR; if (sbase >= RING) sbase -= RING;
+        }
+        return;
+    }
+
+    // ------------------------------ V role: waves 2, 3 ------------------------------
+    {
+        const int u = t - 128;
+        int v_ppv[2], v_rgv[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) { const int tv = u + 128 * q; v_ppv[q] = tv & 31; v_rgv[q] = tv >> 5; }
+        __syncthreads();                                 // batch 0 visible (prologue barrier of the H role)
+        int sbase = 0;                                   // ring slot of step k's first row; V works on step k-1
+        for (int k = 0; k <= nsteps; k++) {
+            if (k < nsteps && !interior) __syncthreads();              // the edge-strip barrier of the H role
+            if (k >= 1) {
+                const int kk = k - 1;
+                int sb = sbase - BR; if (sb < 0) sb += RING;           // slot of step kk's first row
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int v_pp = v_ppv[q], v_rg = v_rgv[q];
+                    const int v_x = x0 + 2 * v_pp;
+                    const int rel0 = kk * BR - 2 * R + v_rg * 4;
+                    const int r_out0 = Y0 + rel0;
+                    if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
+                        int vs = sb - 2 * R + v_rg * 4;
+                        if (vs < 0) vs += RING;
+                        if (vs >= RING) vs -= RING;
+                        const LDS_AS float* vp = (const LDS_AS float*)&s_ring[vs * RS + 2 * v_pp];
+                        v2f v[VWIN];
+#pragma unroll
+                        for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
+                        v2f o[4];
+                        vfilter2x4_km<R>(v, a.taps, o);
+                        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+                        const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int r_out = r_out0 + i;
+                            if (r_out >= Y0 && r_out < Y1 && v_xok) {
+                                float* di = a.dst + (size_t)r_out * a.pitch + v_x;
+                                if (v_pair) {
+                                    unsigned long long bits; __builtin_memcpy(&bits, &o[i], 8);
+                                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                } else *di = o[i].x;
+                                if (a.half_dst != nullptr && (r_out & 1) == 0)
+                                    a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = o[i].x;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            sbase += BR; if (sbase >= RING) sbase -= RING;
+        }
+    }
+}
+
+constexpr int hv_ring(int R) { return (2 * BR + 2 * R + 15) & ~15; }
+template <int R, int NB>
+__global__ __launch_bounds__(NT, (dma_wg_per_cu_fwd<R, NB>())) void k_blur_hv(BlurArgs a)
+{
+    blur_body_hv<R, NB, hv_ring(R)>(a, xcd_remap(blockIdx.x, gridDim.x));
+}
+
 // workgroups of 256 threads a CU can hold for a variant (LDS bound; 4 waves per SIMD at <= 128 VGPRs)
 template <int R, int NBUF, int RINGROWS>
 constexpr int dma_wg_per_cu()
@@ -901,6 +1095,231 @@ __global__ __launch_bounds__(256) void k_upscale(UpArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Octave 0, level 0 at the default x2 upsampling, FUSED (round 3): k_upscale materialised U (33 MB written,
+// 33 MB read back) only so that k_blur<R, true> could stage it; here the marching strip's staging phase reads the
+// input texels themselves (1/16 of the bytes for a u8 image) and the texture fetch is split along its two lerps:
+//   staging : Tx[j][X] = lerp_x(T[j][i0(X)], T[j][i0(X)+1], alpha_X) for the ~18 texel rows j a step touches,
+//             once per texel row (two output rows share each at x2), into an LDS buffer of NTX rows;
+//   H pass  : U(X, y) = lerp_y(Tx[j0(y)][X], Tx[j0(y)+1][X], beta_y) on the thread's two windows, then the
+//             "dd" taps exactly as k_blur<R, true> (pairs outermost-in, centre, x255).
+// Same operations in the same order as k_upscale + k_blur<R, true> (l0_axis, l0_unorm8, l0_lerp are shared), so the
+// plane is bit-identical; U for columns outside [0, W) is defined by clamped TEXELS, which the staging computes
+// directly -- no padded plane, no edge-strip special case.  Vertical pass, ring, deferred stores: as k_blur.
+// Used when upscale_factor == 1 and the image is at least 4 texels wide; every other configuration keeps
+// k_upscale + k_blur<R, true>.
+// ---------------------------------------------------------------------------------------------
+struct L0Args {
+    const void* img; int w, h;
+    float* dst; int W, H, pitch;
+    float shift;
+    int nstrips, chunk_rows;
+    PsxTaps taps;      // dd horizontal
+    PsxTaps taps_v;    // inc[0] vertical
+};
+
+template <int R>
+struct GeomL0 {
+    static constexpr int HALO = (R + 3) & ~3;
+    static constexpr int SW   = TW + 2 * HALO;
+    static constexpr int SW4  = SW / 4;
+    static constexpr int SWA  = 4 * (SW4 | 1);
+    static constexpr int NTX  = BR / 2 + 3;                // texel rows a step of BR output rows touches at x2 (+ rounding slack)
+    static constexpr int NIT  = (NTX * SW4 + NT - 1) / NT; // staging items (texel row, column quad) per thread
+    static constexpr int RING = (BR + 2 * R <= 64) ? 64 : 128;
+    static constexpr int VWIN = 4 + 2 * R;
+    static constexpr int MIRROR = VWIN - 1;
+    static constexpr int RS   = TW + 4;
+};
+
+__device__ __forceinline__ float sel4(float a, float b, float c, float d, int i)
+{
+    const float lo = i & 1 ? b : a, hi = i & 1 ? d : c;
+    return i & 2 ? hi : lo;
+}
+
+template <int R, bool ISFLOAT>
+__device__ __forceinline__ void level0_body(const L0Args& a, const int lid)
+{
+    using G = GeomL0<R>;
+    constexpr int HALO = G::HALO, SW4 = G::SW4, SWA = G::SWA, NTX = G::NTX, NIT = G::NIT, RING = G::RING;
+    constexpr int VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS;
+    __shared__ __attribute__((aligned(16))) float s_tx[NTX * SWA];
+    __shared__ __attribute__((aligned(16))) float s_ring[(RING + MIRROR) * RS];
+
+    const int t     = threadIdx.x;
+    const int strip = lid % a.nstrips;
+    const int chunk = lid / a.nstrips;
+    const int x0    = strip * TW;
+    const int Y0    = chunk * a.chunk_rows;
+    const int Y1    = min(Y0 + a.chunk_rows, a.H);
+    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
+    const float fW = (float)a.W, fH = (float)a.H;
+
+    // ---- staging items of this thread: (texel row slot, column quad); the column side is step invariant ----
+    int it_row[NIT], it_lds[NIT], it_base[NIT];
+    int it_sa[NIT][4], it_sb[NIT][4];                   // texel of output e within the 4-texel window: index (float) / bit shift (u8)
+    float it_al[NIT][4];
+    bool it_on[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; j++) {
+        const int idx = t + j * NT;
+        const int row = idx / SW4, cq = idx - row * SW4;
+        it_on[j]  = row < NTX;
+        it_row[j] = row;
+        it_lds[j] = row * SWA + cq * 4;
+        int ia[4], ib[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int i0;
+            l0_axis(((float)(x0 - HALO + cq * 4 + e) + a.shift) / fW, a.w, i0, it_al[j][e]);
+            ia[e] = psx_clampi(i0, 0, a.w - 1); ib[e] = psx_clampi(i0 + 1, 0, a.w - 1);
+        }
+        // the 8 texel columns of 4 adjacent outputs lie within 4 consecutive texels at x2 (host checks w >= 4)
+        const int base = min(ia[0], a.w - 4);
+        it_base[j] = base;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int da = psx_clampi(ia[e] - base, 0, 3), db = psx_clampi(ib[e] - base, 0, 3);
+            it_sa[j][e] = ISFLOAT ? da : da * 8; it_sb[j][e] = ISFLOAT ? db : db * 8;
+        }
+    }
+    // texel row of output row y (clamped like the plane rows of k_blur): j0, j0 + 1 clamped, and the 1.8 weight
+    auto row_axis = [&](int y, int& ja, int& jb, float& be) {
+        int j0;
+        l0_axis(((float)psx_clampi(y, 0, a.H - 1) + a.shift) / fH, a.h, j0, be);
+        ja = psx_clampi(j0, 0, a.h - 1); jb = psx_clampi(j0 + 1, 0, a.h - 1);
+    };
+    auto step_jlo = [&](int k) { int ja, jb; float be; row_axis(Y0 - R + k * BR, ja, jb, be); return __builtin_amdgcn_readfirstlane(ja); };
+
+    // ---- horizontal / vertical geometry as blur_body ----
+    int h_row, h_seg;
+    {
+        const int blk = (t & 31) >> 2;
+        const int rq = (0x21120330 >> (4 * blk)) & 3;
+        const int sh = (0xCC >> blk) & 1;
+        h_row = (t >> 6) * 8 + ((t >> 5) & 1) * 4 + rq;
+        h_seg = sh * 4 + (t & 3);
+    }
+    const int v_pp = t & 31, v_rg = t >> 5;
+    const int v_x  = x0 + 2 * v_pp;
+    const unsigned v_doff = (unsigned)((v_rg * 4) * a.pitch + v_x) * 4u;
+    const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
+
+    typedef typename std::conditional<ISFLOAT, v4f, unsigned>::type texel4;
+    texel4 pre[NIT];
+    auto issue = [&](int k) {
+        const int jlo = step_jlo(k);
+#pragma unroll
+        for (int j = 0; j < NIT; j++) {
+            if (it_on[j]) {
+                const int jr = psx_clampi(jlo + it_row[j], 0, a.h - 1);
+                if (ISFLOAT) __builtin_memcpy(&pre[j], static_cast<const float*>(a.img) + (size_t)jr * a.w + it_base[j], 16);
+                else         __builtin_memcpy(&pre[j], static_cast<const uint8_t*>(a.img) + (size_t)jr * a.w + it_base[j], 4);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NIT; j++) {
+            if (it_on[j]) {
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float p, q;
+                    if constexpr (ISFLOAT) {
+                        p = sel4(pre[j].x, pre[j].y, pre[j].z, pre[j].w, it_sa[j][e]);
+                        q = sel4(pre[j].x, pre[j].y, pre[j].z, pre[j].w, it_sb[j][e]);
+                    } else {
+                        p = l0_unorm8((pre[j] >> it_sa[j][e]) & 0xffu);
+                        q = l0_unorm8((pre[j] >> it_sb[j][e]) & 0xffu);
+                    }
+                    r[e] = l0_lerp(p, q, it_al[j][e]);
+                }
+                *reinterpret_cast<float4*>(&s_tx[it_lds[j]]) = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+    };
+
+    v2f pend[4];
+    auto flush = [&](const int kk) {
+        const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
+        char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r_out = r_out0 + i;
+            if (r_out >= Y0 && r_out < Y1 && v_xok) {
+                char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
+                if (v_pair) {
+                    unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else *reinterpret_cast<float*>(di) = pend[i].x;
+            }
+        }
+    };
+
+    issue(0);
+    for (int k = 0; k < nsteps; k++) {
+        commit();
+        flush(k - 1);
+        const int jlo = step_jlo(k);
+        __syncthreads();
+        if (k + 1 < nsteps) issue(k + 1);
+
+        // ---- horizontal: lerp_y of the two texel-row windows, then the dd taps ----
+        {
+            int ja, jb; float be;
+            row_axis(Y0 - R + k * BR + h_row, ja, jb, be);
+            const int oa = psx_clampi(ja - jlo, 0, NTX - 1), ob = psx_clampi(jb - jlo, 0, NTX - 1);
+            const LDS_AS float* pa = (const LDS_AS float*)&s_tx[oa * SWA + h_seg * 8];
+            const LDS_AS float* pb = (const LDS_AS float*)&s_tx[ob * SWA + h_seg * 8];
+            float win[8 + 2 * HALO];
+#pragma unroll
+            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
+                const v4f va = ((const volatile LDS_AS v4f*)pa)[q];
+                const v4f vb = ((const volatile LDS_AS v4f*)pb)[q];
+                win[4 * q + 0] = l0_lerp(va.x, vb.x, be); win[4 * q + 1] = l0_lerp(va.y, vb.y, be);
+                win[4 * q + 2] = l0_lerp(va.z, vb.z, be); win[4 * q + 3] = l0_lerp(va.w, vb.w, be);
+            }
+            float out[8];
+            hfilter8_km<R, HALO, true>(win, a.taps, out);
+            const int slot = (k * BR + h_row) & (RING - 1);
+            float* rp = &s_ring[slot * RS + h_seg * 8];
+            reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
+            reinterpret_cast<float4*>(rp)[1] = make_float4(out[4], out[5], out[6], out[7]);
+            if (slot < MIRROR) {
+                reinterpret_cast<float4*>(rp + RING * RS)[0] = make_float4(out[0], out[1], out[2], out[3]);
+                reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
+            }
+        }
+        __syncthreads();
+
+        // ---- vertical ----
+        {
+            const int rel0 = k * BR - 2 * R + v_rg * 4;
+            const int r_out0 = Y0 + rel0;
+            if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
+                const LDS_AS float* vp = (const LDS_AS float*)&s_ring[(rel0 & (RING - 1)) * RS + 2 * v_pp];
+                v2f v[VWIN];
+#pragma unroll
+                for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
+                v2f o[4];
+                vfilter2x4_km<R>(v, a.taps_v, o);
+                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+#pragma unroll
+                for (int i = 0; i < 4; i++) pend[i] = o[i];
+            }
+        }
+    }
+    flush(nsteps - 1);
+}
+
+template <int R, bool ISFLOAT>
+__global__ __launch_bounds__(NT, 4) void k_level0_fused(L0Args a)
+{
+    level0_body<R, ISFLOAT>(a, xcd_remap(blockIdx.x, gridDim.x));
+}
+
 // make_dog (s_pyramid_build.cu:74-92) for one level pair; debug/dump use only
 __global__ void k_dog(const float* a, const float* b, float* d, int W, int H, int pitch)
 {
@@ -920,7 +1339,8 @@ inline const BlurTuning& blur_tuning()
         BlurTuning v{5, true, 0, 0};
         // POPSIFT_BLUR_DMA: 0 = register-staged k_blur, 2 / 3 = LDS-DMA staging with 2 / 3 stage buffers (k_blur_dma)
         // 12 / 13 / 14 = the same with a dedicated loader wave per workgroup (k_blur_ldw) and 2 / 3 / 4 stage buffers
-        if (const char* e = getenv("POPSIFT_BLUR_DMA")) { const int n = atoi(e); if (n == 0 || n == 2 || n == 3 || (n >= 12 && n <= 14)) v.dma = n; }
+        // 22 / 23 = H and V pass on different waves (k_blur_hv) with 2 / 3 stage buffers
+        if (const char* e = getenv("POPSIFT_BLUR_DMA")) { const int n = atoi(e); if (n == 0 || n == 2 || n == 3 || (n >= 12 && n <= 14) || n == 22 || n == 23) v.dma = n; }
         if (const char* e = getenv("POPSIFT_BLUR_DMA_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.dma_steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_DEFER")) v.defer = e[0] != '0';
@@ -1033,6 +1453,16 @@ void launch_ldw(BlurArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
     else                                  hipLaunchKernelGGL((k_blur_ldw<R, LEVEL0, NBUF, RING>), grid, block, 0, s, a);
 }
 
+template <int R, int NB>
+void launch_hv(BlurArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    int nchunks;
+    chunking_dma(a.W, a.H, R, dma_wg_per_cu_fwd<R, NB>() * device_cus(), a.chunk_rows, nchunks);
+    const dim3 grid(a.nstrips * nchunks), block(NT);
+    if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((k_blur_hv<R, NB>), grid, block, 0, s, ev0, ev1, 0, a);
+    else                                  hipLaunchKernelGGL((k_blur_hv<R, NB>), grid, block, 0, s, a);
+}
+
 template <int R>
 hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, const PsxTaps& taps,
                          float* half_dst, int half_pitch, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
@@ -1049,11 +1479,16 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
         if (dma == 12) { launch_ldw<R, false, 2>(a, s, ev0, ev1); return hipGetLastError(); }
         if (dma == 13) { launch_ldw<R, false, 3>(a, s, ev0, ev1); return hipGetLastError(); }
         if (dma == 14) { launch_ldw<R, false, 4>(a, s, ev0, ev1); return hipGetLastError(); }
+        if (dma == 22) { launch_hv<R, 2>(a, s, ev0, ev1); return hipGetLastError(); }
+        if (dma == 23) { launch_hv<R, 3>(a, s, ev0, ev1); return hipGetLastError(); }
     }
     const bool ext = ev0 != nullptr || ev1 != nullptr;       // kernel begin / end timestamps of THIS dispatch (what rocprofv3 --kernel-trace reports)
     if (blur_tuning().defer) {
-        if (ext) hipExtLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, ev0, ev1, 0, a);
-        else     hipLaunchKernelGGL((k_blur<R, false, true>), grid, block, 0, s, a);
+        // POPSIFT_BLUR_LDS_PAD (measurement switch): extra dynamic LDS per workgroup, i.e. fewer resident k_blur
+        // workgroups per CU, leaving room for another stream's kernels on the same CUs
+        static const unsigned pad = [] { const char* e = getenv("POPSIFT_BLUR_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+        if (ext) hipExtLaunchKernelGGL((k_blur<R, false, true>), grid, block, pad, s, ev0, ev1, 0, a);
+        else     hipLaunchKernelGGL((k_blur<R, false, true>), grid, block, pad, s, a);
     } else {
         if (ext) hipExtLaunchKernelGGL((k_blur<R, false, false>), grid, block, 0, s, ev0, ev1, 0, a);
         else     hipLaunchKernelGGL((k_blur<R, false, false>), grid, block, 0, s, a);
@@ -1061,9 +1496,31 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
     return hipGetLastError();
 }
 
+// POPSIFT_LEVEL0_FUSED=0 keeps k_upscale + k_blur<R, true> for every configuration
+inline bool level0_fused_enabled()
+{
+    static const bool on = [] { const char* e = getenv("POPSIFT_LEVEL0_FUSED"); return !(e != nullptr && e[0] == '0'); }();
+    return on;
+}
+
 template <int R>
 hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
 {
+    if constexpr (R <= 8) {
+        // the default x2 upsampling: W = 2w, H = 2h exactly
+        if (level0_fused_enabled() && h.W == 2 * h.w && h.H == 2 * h.h && h.w >= 4) {
+            L0Args f;
+            f.img = h.img; f.w = h.w; f.h = h.h; f.dst = h.dst; f.W = h.W; f.H = h.H; f.pitch = h.pitch; f.shift = h.shift;
+            f.nstrips = (h.W + TW - 1) / TW;
+            int nchunks;
+            chunking(h.W, h.H, R, f.chunk_rows, nchunks);
+            f.taps = h.taps_h; f.taps_v = h.taps_v;
+            const dim3 grid(f.nstrips * nchunks), block(NT);
+            if (h.is_float) hipLaunchKernelGGL((k_level0_fused<R, true>), grid, block, 0, s, f);
+            else            hipLaunchKernelGGL((k_level0_fused<R, false>), grid, block, 0, s, f);
+            return hipGetLastError();
+        }
+    }
     const int pad = PSX_LEVEL0_PAD;
     const int wr = ((h.W + TW - 1) / TW) * TW;           // every strip reads full-width source rows
     UpArgs u;

@@ -20,8 +20,11 @@
 #include <fstream>
 #include <iostream>
 #include <list>
+#include <memory>
 #include <queue>
 #include <string>
+#include <vector>
+#include <cstdlib>
 
 using namespace std;
 
@@ -30,6 +33,7 @@ static bool print_time_info = false;
 static bool write_as_uchar  = false;
 static bool dont_write      = false;
 static bool float_mode      = false;
+static std::vector<int> device_list;          // one PopSift replica per entry (popsift.h:158,166-168); default: device 0
 
 static void parseargs( int argc, char** argv, popsift::Config& config, string& inputFile )
 {
@@ -46,6 +50,25 @@ static void parseargs( int argc, char** argv, popsift::Config& config, string& i
     all.flag( "dont-write", 0, "Suppress descriptor output", [&]() { dont_write = true; } );
     all.flag( "pgmread-loading", 0, "Use the PGM/PPM loader (the only loader of this build)", []() {} );
     all.flag( "float-mode", 0, "Upload image to GPU as float instead of byte", [&]() { float_mode = true; } );
+    // not in the reference tool: several replicas in one process, image i goes to replica i mod N (BASELINE config 4)
+    all.add( "devices", 0, true, "Number of GPUs: one PopSift replica on each of devices 0..N-1", [&]( const string& v ) {
+        const int n = atoi( v.c_str() );
+        if( n < 1 ) throw runtime_error( "--devices needs a positive number" );
+        device_list.clear();
+        for( int d = 0; d < n; d++ ) device_list.push_back( d );
+    } );
+    all.add( "device-list", 0, true, "Comma separated device ids, one PopSift replica each (an id may repeat: 0,0)", [&]( const string& v ) {
+        device_list.clear();
+        size_t pos = 0;
+        while( pos <= v.size() ) {
+            const size_t c = v.find( ',', pos );
+            const string tok = v.substr( pos, c == string::npos ? string::npos : c - pos );
+            if( tok.empty() || tok.find_first_not_of( "0123456789" ) != string::npos ) throw runtime_error( "--device-list: bad device id '" + tok + "'" );
+            device_list.push_back( atoi( tok.c_str() ) );
+            if( c == string::npos ) break;
+            pos = c + 1;
+        }
+    } );
     try {
         all.parse( argc, argv );
         if( help ) { all.usage( cout ); exit( EXIT_SUCCESS ); }
@@ -134,20 +157,29 @@ int main( int argc, char** argv )
         return EXIT_FAILURE;
     }
 
+    if( device_list.empty() ) device_list.push_back( 0 );
     popsift::cuda::device_prop_t deviceInfo;
-    deviceInfo.set( 0, print_dev_info );
+    deviceInfo.set( device_list[0], print_dev_info );
     if( print_dev_info ) deviceInfo.print();
 
     try {
         const auto t0 = chrono::steady_clock::now();
-        PopSift sift( config, popsift::Config::ExtractingMode, float_mode ? PopSift::FloatImages : PopSift::ByteImages );
+        // One PopSift per listed device (the reference's model for several GPUs: independent objects, popsift.h:158);
+        // image i goes to replica i mod N, results are read back in input order.  The replicas share the host: tell
+        // them how many they are so that each takes its share of worker threads (POPSIFT_PIPE_DEPTH still overrides).
+        const size_t nrep = device_list.size();
+        if( nrep > 1 && getenv( "POPSIFT_LOCAL_REPLICAS" ) == nullptr ) setenv( "POPSIFT_LOCAL_REPLICAS", to_string( nrep ).c_str(), 1 );
+        vector<unique_ptr<PopSift>> sifts;
+        for( int d : device_list )
+            sifts.emplace_back( new PopSift( config, popsift::Config::ExtractingMode, float_mode ? PopSift::FloatImages : PopSift::ByteImages, d ) );
         queue<SiftJob*> jobs;
-        for( const string& f : inputFiles ) jobs.push( process_image( f, sift ) );
+        size_t i = 0;
+        for( const string& f : inputFiles ) jobs.push( process_image( f, *sifts[i++ % nrep] ) );
         while( !jobs.empty() ) {
             SiftJob* job = jobs.front(); jobs.pop();
             if( job ) { read_job( job, !dont_write ); delete job; }
         }
-        sift.uninit();
+        for( auto& sp : sifts ) sp->uninit();
         if( print_time_info )
             cerr << "Processing " << inputFiles.size() << " image(s) took "
                  << chrono::duration<double, milli>( chrono::steady_clock::now() - t0 ).count() << " ms" << endl;

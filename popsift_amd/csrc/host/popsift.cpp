@@ -15,6 +15,7 @@
 #include "popsift/features.h"
 #include "host_pool.h"
 #include "log_dump.h"
+#include "trace.h"
 
 #include "popsift_hip.h"
 
@@ -508,17 +509,22 @@ void PopSift::dispatchLoop( )
                 check( s.ctx, psx_attach_export_mapped( s.ctx, s.xfeat, EXPORT_FEATURES, s.xdesc, s.desc_cap ), "psx_attach_export_mapped" );
             }
             const double t1 = pnow();
+            popsift::trace::Range r_frame( "popsift frame" );
+            { popsift::trace::Range r_up( "inserting image" );                   // popsift.cpp:441-446
             if( job->isPinned() )
                 check( s.ctx, psx_upload_pinned( s.ctx, job->getData(), job->getWidth(), job->getHeight(), job->isFloat() ? 1 : 0 ), "psx_upload_pinned" );
             else if( job->isFloat() )
                 check( s.ctx, psx_upload_f32( s.ctx, (const float*)job->getData(), job->getWidth(), job->getHeight() ), "psx_upload_f32" );
             else
                 check( s.ctx, psx_upload_u8( s.ctx, job->getData(), job->getWidth(), job->getHeight() ), "psx_upload_u8" );
+            }
             const double t2 = pnow();
-            check( s.ctx, psx_extract( s.ctx ), "psx_extract" );
+            { popsift::trace::Range r_ex( "extract (launch chain)" );
+              check( s.ctx, psx_extract( s.ctx ), "psx_extract" ); }
             const double t3 = pnow();
             double tf = 0;
             if( _proc_mode == popsift::Config::ExtractingMode ) {
+                popsift::trace::Range r_dl( "download descriptors" );              // sift_pyramid.cu:288-319
                 f = collect_host( s, p.want_desc, &tf );
                 if( _config.getLogMode() == popsift::Config::All ) {      // popsift.cpp:330-338
                     // the reference writes these dumps from its single worker (popsift.cpp:330-338); here PIPE_DEPTH

@@ -1,7 +1,7 @@
-// demo_main.cpp -- minimal driver over the C++ API (used by the tests; the reference's
-// popsift-demo needs Boost and DevIL, which are not part of this hot-path build).
+// testdriver_main.cpp -- TEST-ONLY driver over the C++ API on raw frames (no image decoding): used by tests/ and
+// tools/cpp_api_bench.sh.  The command line tool with the reference's option surface is app/main.cpp (popsift-demo).
 //
-// usage: popsift_demo <w> <h> <raw-u8-or-f32-file> <out.txt> [--float] [--vlfeat|--opencv]
+// usage: popsift-testdriver <w> <h> <raw-u8-or-f32-file> <out.txt> [--float] [--vlfeat|--opencv]
 //                     [--octaves N] [--repeat N] [--norm-multi M] [--classic] [--match <second-raw-file>]
 //                     [--filter-max N] grid filter as AliceVision configures it (LargestScaleFirst)
 //                     [--bench N]   stream N frames through enqueue/get with at most 16 jobs outstanding per

@@ -45,15 +45,18 @@ def _upsampled_noise(seed, stream, w, h, div):
 
 # (divisor, amplitude, hash stream): a roughly 1/f stack so that keypoints appear in every octave
 _NOISE_STACK = ((2, 0.10, 10), (4, 0.20, 1), (8, 0.30, 7), (16, 0.30, 8), (32, 0.30, 9))
+# the same without the two finest layers and with fewer blobs: ~2 keypoints per 1000 input pixels with the default
+# Config -- the natural-image density SURVEY.md 8d asks for (the full stack gives ~7, the hard side for keypoint work)
+_NOISE_STACK_SPARSE = ((8, 0.24, 7), (16, 0.30, 8), (32, 0.30, 9))
 
 
-def synth(w, h, seed=1000):
-    """Return an (h, w) uint8 frame."""
+def synth(w, h, seed=1000, sparse=False):
+    """Return an (h, w) uint8 frame; sparse=True: ~2 instead of ~7 keypoints per 1000 pixels."""
     img = np.full((h, w), 128.0)
-    for div, amp, stream in _NOISE_STACK:
+    for div, amp, stream in (_NOISE_STACK_SPARSE if sparse else _NOISE_STACK):
         img += amp * (_upsampled_noise(seed, stream, w, h, div) - 128.0)
 
-    k = max(1, (w * h) // 4096)
+    k = max(1, (w * h) // (6144 if sparse else 4096))
     cx = _rand01(seed, 2, k) * w
     cy = _rand01(seed, 3, k) * h
     sg = 1.5 + _rand01(seed, 4, k) * 10.5

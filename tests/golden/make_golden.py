@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import pyoracle as po, pyref as pr   # noqa: E402
 from popsift_amd.synth import synth, synth_float  # noqa: E402
+from tests import adversarial as adv  # noqa: E402
 
 CASES = {
     # name: (w, h, seed, float_input, config overrides)
@@ -48,6 +49,15 @@ CASES = {
     "mode_grid_120x90": (120, 90, 207, False, dict(octaves=3, desc_mode=po.DESC_GRID)),
     "mode_igrid_120x90": (120, 90, 208, False, dict(octaves=3, desc_mode=po.DESC_IGRID, norm_mode=po.NORM_CLASSIC, norm_multi=9)),
     "mode_notile_120x90": (120, 90, 209, False, dict(octaves=3, desc_mode=po.DESC_NOTILE)),
+    # adversarial content (tests/adversarial.py): saturated plateaus, step edges, binary strokes, exact DoG ties, a
+    # mosaic of all of them, and the two images without any extremum (sine grating, pure ramp); round 3
+    "adv_plateaus_192x144": (192, 144, "plateaus", False, dict(octaves=4)),
+    "adv_checker_160x120": (160, 120, "checker", False, dict(octaves=3, sift_mode=po.MODE_VLFEAT)),
+    "adv_textlike_160x120": (160, 120, "textlike", False, dict(octaves=3)),
+    "adv_stripes_160x120": (160, 120, "stripes", False, dict(octaves=3, sift_mode=po.MODE_OPENCV, gauss_mode=po.GAUSS_OPENCV_COMPUTE)),
+    "adv_composite_240x160": (240, 160, "composite", False, dict(octaves=4)),
+    "adv_grating_128x96": (128, 96, "grating", False, dict(octaves=3)),
+    "adv_ramp_128x96": (128, 96, "ramp", False, dict(octaves=3)),
 }
 
 
@@ -58,7 +68,10 @@ def main():
         path = os.path.join(out_dir, "ref_%s.npz" % name)
         if (only and name not in only) or (not only and os.path.exists(path)):
             continue                                   # existing fixtures are kept byte for byte; name them to redo
-        img = synth_float(w, h, seed) if is_float else synth(w, h, seed)
+        if isinstance(seed, str):
+            img = adv.make(seed, w, h)                 # named adversarial content instead of a synth() seed
+        else:
+            img = synth_float(w, h, seed) if is_float else synth(w, h, seed)
         cfg = po.default_config(**kw)
         r = pr.run(cfg, img)
         planes = {}

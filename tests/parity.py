@@ -158,6 +158,35 @@ def match_features(fa, da, fb, db, norm_scale=1.0, max_report=25):
     return res
 
 
+def extrema_from_features(fb, up_fac, fa_ref, lpos_ref):
+    """Oriented-extremum records (oracle EXT layout: xpos, ypos, lpos, sigma, octave, num_ori, idx_ori, orientation)
+    for the keypoints of feature set fb, so that the oracle can redo the DESCRIPTOR stage on exactly these keypoint
+    and orientation bits (pyoracle.Result.describe).  Positions and sigma are mapped back to octave units (division by
+    a power of two: exact); the level index, which Feature records do not carry, is taken from the partner keypoint in
+    (fa_ref, lpos_ref)."""
+    from oracle.pyoracle import EXT_DTYPE
+    partner = _assign_keypoints(fb, fa_ref)
+    assert (partner >= 0).all(), "%d keypoints without a partner" % int((partner < 0).sum())
+    ext = np.zeros(len(fb), EXT_DTYPE)
+    s = np.exp2(fb["debug_octave"].astype(np.float64) - up_fac).astype(np.float32)
+    ext["xpos"] = fb["xpos"] / s; ext["ypos"] = fb["ypos"] / s; ext["sigma"] = fb["sigma"] / s
+    ext["lpos"] = lpos_ref[partner]
+    ext["octave"] = fb["debug_octave"]; ext["num_ori"] = fb["num_ori"]
+    ext["idx_ori"] = fb["desc_idx"][:, 0]
+    ext["orientation"] = fb["orientation"]
+    return ext
+
+
+def assert_descriptor_rows(want, got, n_keypoints, what="", norm_scale=1.0):
+    """Row-wise comparison of two descriptor arrays with equal indexing: at most budget(n)['desc'] rows beyond 1e-3."""
+    assert want.shape == got.shape, (want.shape, got.shape)
+    dist = np.sqrt(((want.astype(np.float64) - got.astype(np.float64)) ** 2).sum(1)) / norm_scale
+    bad = np.flatnonzero(dist > TOL_DESC)
+    assert len(bad) <= budget(n_keypoints)["desc"], "%s: %d of %d descriptors beyond 1e-3 (max %.3g): rows %s" % (
+        what, len(bad), len(dist), dist.max() if len(dist) else 0.0, bad[:10].tolist())
+    return float(dist.max()) if len(dist) else 0.0
+
+
 def assert_parity(m, kp=0, ori=0, desc=0, what=""):
     """Exact mismatch budget: at most `kp` unmatched keypoints, `ori` orientation mismatches and `desc`
     descriptors beyond 1e-3; every mismatch is printed with its cause when the budget is exceeded."""
@@ -176,7 +205,7 @@ def sort_iext(a):
 def budget(n_keypoints):
     """Mismatch budget of a HIP-vs-oracle comparison with n keypoints.  Positions are bit-exact (0 keypoint
     misses).  Orientations / descriptors go through transcendentals (libm on the CPU, ocml and fast paths on
-    the GPU): measured on MI355X (tools/parity_counts.py, profiles/r02_parity_counts.json) about 4 orientation
+    the GPU): measured on MI355X (tools/parity_counts.py -> profiles/r03_parity_counts.json) about 4 orientation
     flips per 100 000 keypoints (a gradient sample within an ulp of a histogram-bin boundary) and fewer
     descriptor outliers; the budget is that rate with head-room: 1 + n/10000 each."""
     return dict(kp=0, ori=1 + n_keypoints // 10000, desc=1 + n_keypoints // 10000)

@@ -134,3 +134,28 @@ def test_match_tool(oracle, tmp_path):
     lines = [l for l in p.stdout.splitlines() if l.startswith(("accept", "reject"))]
     assert len(lines) == ra.ori_total
     assert sum(l.startswith("accept") for l in lines) > 0.3 * len(lines)
+
+
+def test_demo_device_list_two_replicas_on_one_gpu(oracle, tmp_path):
+    """popsift-demo --device-list 0,0 / --devices 1: one PopSift replica per listed device in ONE process (the
+    reference's multi-GPU model, popsift.h:158,166-168), image i -> replica i mod N, results read in input order.
+    Two replicas on device 0 (the reference cannot do that: global device symbols) give every image's oracle counts;
+    the last image's output-features.txt equals the single-replica run's."""
+    d = tmp_path / "imgs"
+    d.mkdir()
+    imgs = [synth(200 + 16 * i, 150 + 8 * i, 40 + i) for i in range(5)]
+    for i, im in enumerate(imgs):
+        _write_pgm(d / ("%02d.pgm" % i), im)
+    want = []
+    for im in imgs:
+        r = oracle.run(oracle.default_config(octaves=3), im)
+        want.append("Number of feature points: %d number of feature descriptors: %d" % (r.ext_total, r.ori_total))
+    outs = {}
+    for name, extra in (("two", ["--device-list", "0,0"]), ("one", ["--devices", "1"])):
+        p = _run([DEMO, "-i", "imgs", "--octaves", "3"] + extra, tmp_path)
+        got = [ln for ln in p.stderr.splitlines() if ln.startswith("Number of feature points")]
+        assert got == want, (name, got, want)
+        outs[name] = _sorted(np.loadtxt(str(tmp_path / "output-features.txt"), ndmin=2))
+    assert outs["one"].shape == outs["two"].shape and np.allclose(outs["one"], outs["two"], atol=2e-3)
+    bad = subprocess.run([DEMO, "-i", "imgs", "--device-list", "0,x"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert bad.returncode != 0 and "device-list" in bad.stderr

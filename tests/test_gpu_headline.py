@@ -98,3 +98,27 @@ def test_hoarded_results_fall_back_to_pageable_memory(oracle, capi, tmp_path, ex
     results = _worker(tmp_path, {"POPSIFT_EXPORT": export, "POPSIFT_PINNED_LIMIT_MB": "16"}, 8, 8, 3, "keep")
     assert len(results) == 24
     _check_all(oracle, frames, results, "hoarding export=%s" % export)
+
+
+def test_two_popsift_replicas_on_one_device_round_robin(oracle, capi):
+    """Multi-GPU readiness without a multi-GPU box: two PopSift objects on device 0 in one
+    process, driven round-robin from ONE thread -- the reference's N-device shape (one PopSift per device,
+    popsift.h:158,166-168, frame i -> replica i mod N) with both replicas forced onto the same GPU, which the
+    reference itself cannot do (global device symbols).  Every result is the oracle's."""
+    frames = bench_frames(12)
+    from collections import deque
+    reps = [capi.PopSift(capi.default_config(octaves=5)) for _ in range(2)]
+    jobs, res = deque(), []
+    for p in range(2):
+        for i, f in enumerate(frames):
+            if len(jobs) >= 16:
+                r, j = jobs.popleft()
+                res.append(reps[r].get(j))
+            r = (p * len(frames) + i) % 2
+            jobs.append((r, reps[r].enqueue(f)))
+    while jobs:
+        r, j = jobs.popleft()
+        res.append(reps[r].get(j))
+    for rp in reps:
+        rp.close()
+    _check_all(oracle, frames, res, "two replicas on device 0")

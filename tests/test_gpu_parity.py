@@ -385,8 +385,8 @@ def test_cpp_api_demo_matches_oracle(oracle, tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    demo = os.path.join(root, "popsift_amd", "lib", "popsift_demo")
-    assert os.path.exists(demo), "popsift_amd/lib/popsift_demo missing: run __graft_entry__.build()"
+    demo = os.path.join(root, "popsift_amd", "lib", "popsift-testdriver")
+    assert os.path.exists(demo), "popsift_amd/lib/popsift-testdriver missing: run __graft_entry__.build()"
     w, h = 400, 300
     img = synth(w, h, 55)
     raw = tmp_path / "in.raw"
@@ -454,7 +454,7 @@ def test_cpp_matching_mode(tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    demo = os.path.join(root, "popsift_amd", "lib", "popsift_demo")
+    demo = os.path.join(root, "popsift_amd", "lib", "popsift-testdriver")
     w, h = 256, 192
     img = synth(w, h, 91)
     raw = tmp_path / "in.raw"
@@ -505,7 +505,7 @@ def test_cpp_streaming_reuses_result_buffers(capi, tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    demo = os.path.join(root, "popsift_amd", "lib", "popsift_demo")
+    demo = os.path.join(root, "popsift_amd", "lib", "popsift-testdriver")
     w, h = 512, 384
     img = synth(w, h, 404)
     raw = tmp_path / "in.raw"
@@ -581,6 +581,9 @@ def test_bench_workload_bit_exact_and_repeatable(oracle, capi):
     ctx.close()
 
 
+_FUZZ_TOTAL = dict(cases=0, keypoints=0, descriptors=0, kp_miss=0, ori_miss=0, desc_miss=0)
+
+
 def _fuzz_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
@@ -617,11 +620,30 @@ def test_fuzz_small_configs(oracle, capi, w, h, seed, is_float, kw):
     fb, db = ctx.download()
     fa, da = ref.features(), ref.descriptors()
     assert len(fa) == len(fb)
+    _FUZZ_TOTAL["cases"] += 1
     if len(fa):
         m = match_features(fa, da, fb, db, norm_scale=float(2 ** kw["norm_multi"]))
-        # small sets: at most one orientation / descriptor flip (a 1e-7 atan difference moving a sample across a bin)
+        # small sets: at most one orientation / descriptor flip (a 1e-7 atan difference moving a sample across a bin) ...
         assert_parity(m, what="fuzz %dx%d seed %d %s" % (w, h, seed, kw), **budget(len(fa)))
+        # ... and the sweep as a whole is held to the same RATE (test_fuzz_sweep_total_budget): 100 cases with one
+        # free flip each could otherwise hide 100 flips
+        for k in ("kp_miss", "ori_miss", "desc_miss"):
+            _FUZZ_TOTAL[k] += m[k]
+        _FUZZ_TOTAL["keypoints"] += len(fa)
+        _FUZZ_TOTAL["descriptors"] += m["desc_compared"]
     ctx.close()
+
+
+def test_fuzz_sweep_total_budget():
+    """Mismatches summed over the whole fuzz sweep against budget(total keypoints): 0 keypoints, 1 + N/10000
+    orientations, 1 + N/10000 descriptors.  Runs after the parametrised cases (file order)."""
+    t = _FUZZ_TOTAL
+    if t["cases"] == 0:
+        pytest.skip("the fuzz cases did not run in this session")
+    print("fuzz sweep:", t)
+    b = budget(t["keypoints"])
+    assert t["cases"] == 100 or t["keypoints"] > 0
+    assert t["kp_miss"] <= b["kp"] and t["ori_miss"] <= b["ori"] and t["desc_miss"] <= b["desc"], (t, b)
 
 
 @pytest.mark.parametrize("w,h", [(3000, 9), (7, 2500), (65, 65), (63, 129), (4097, 33), (128, 1), (1, 128), (2, 2), (1920, 16)])

@@ -180,13 +180,21 @@ def test_interpolating_descriptor_modes_match_reference(oracle, ref, desc_mode, 
 def test_grid_descriptor_mode_matches_reference(oracle, ref):
     """ext_desc_grid snaps its 16 x 16 sample points per tile to pixels through  (int)(pt + (round(pt + pix) - pt))
     (s_desc_grid.cu:72-78): whenever |round(..)| < |pt| / 2 the float sum may land one ulp BELOW the integer and
-    truncate to the neighbouring pixel -- decided by the last bit of pt, i.e. of the keypoint position.  Oracle and
-    reference positions differ in that bit for some keypoints (see above), so a fraction of the descriptors near the
-    image border differs by up to ~0.02; the rest agrees to 1e-5."""
+    truncate to the neighbouring pixel -- decided by the last bits of pt, i.e. of the keypoint position and of
+    sin / cos of the orientation.  The descriptor STAGE is therefore pinned strictly on the reference's own
+    keypoints: the oracle redoes the descriptors for exactly the reference's positions and orientation bits
+    (osift_describe; both evaluate sin / cos in double, rounded once) and every descriptor agrees within 1e-3.
+    End to end, oracle and reference positions differ in the last bit for some keypoints (FMA contraction in
+    solve()), which moves knife-edge samples of a share of the descriptors: bounded, not strict."""
+    from tests.parity import assert_descriptor_rows, extrema_from_features
     img = synth(200, 150, 3)
     cfg = oracle.default_config(octaves=4, desc_mode=2)
     r, o = ref.run(cfg, img), oracle.run(cfg, img)
     assert r.ext_total == o.ext_total and r.ori_total == o.ori_total > 150
-    m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors())
+    rf, rd = r.features(), r.descriptors()
+    ext = extrema_from_features(rf, int(cfg.upscale_factor), o.features(), o.extrema()["lpos"])
+    worst = assert_descriptor_rows(o.describe(ext, len(rd)), rd, len(rf), what="grid descriptor stage on the reference's keypoints")
+    assert worst < 1e-3
+    m = match_features(rf, rd, o.features(), o.descriptors())
     assert m["kp_miss"] == 0 and m["ori_miss"] == 0
     assert m["desc_miss"] <= 0.1 * m["desc_compared"] and m["max_desc_dist"] < 0.05, m

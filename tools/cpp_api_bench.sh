@@ -8,6 +8,6 @@ synth(1920,1080,1000).tofile("/tmp/f.raw")
 PY
 for d in 2 4 8 16; do
   echo "POPSIFT_PIPE_DEPTH=$d"
-  POPSIFT_PROFILE=1 POPSIFT_PIPE_DEPTH=$d popsift_amd/lib/popsift_demo 1920 1080 /tmp/f.raw /tmp/o.txt --octaves 5 --bench 400 2>&1 | grep -E "bench:|profile"
-  POPSIFT_PIPE_DEPTH=$d popsift_amd/lib/popsift_demo 1920 1080 /tmp/f.raw /tmp/o.txt --octaves 5 --bench 400 --filter-max 5000 2>&1 | grep -E "bench:"
+  POPSIFT_PROFILE=1 POPSIFT_PIPE_DEPTH=$d popsift_amd/lib/popsift-testdriver 1920 1080 /tmp/f.raw /tmp/o.txt --octaves 5 --bench 400 2>&1 | grep -E "bench:|profile"
+  POPSIFT_PIPE_DEPTH=$d popsift_amd/lib/popsift-testdriver 1920 1080 /tmp/f.raw /tmp/o.txt --octaves 5 --bench 400 --filter-max 5000 2>&1 | grep -E "bench:"
 done
