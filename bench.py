@@ -76,29 +76,20 @@ def algorithmic_bytes(w, h, octaves, levels=3, input_bytes_per_px=1):
 
 
 def read_sclk_mhz(device=0):
-    """Current shader clock from sysfs (the line marked '*' in pp_dpm_sclk); None when not readable."""
+    """Current shader clock from sysfs: the line marked '*' in pp_dpm_sclk.  The card index of the visible device is
+    not known inside the container (the box exposes every card's sysfs node), so this returns the HIGHEST current
+    clock over all cards -- sampled while this process keeps its GPU busy, that is this GPU's.  None when unreadable."""
     import glob
-    try:
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        txt = open(cards[min(device, len(cards) - 1)]).read()
-        for line in txt.splitlines():
-            if line.strip().endswith("*"):
-                return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
-    except Exception:
-        pass
-    return None
-
-
-def usable_cores():
-    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return max(1, n)
+    best = None
+    for path in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+        try:
+            for line in open(path).read().splitlines():
+                if line.strip().endswith("*"):
+                    mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+                    best = mhz if best is None else max(best, mhz)
+        except Exception:
+            pass
+    return best
 
 
 def frame_seed(j, rank, world):

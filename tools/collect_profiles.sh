@@ -15,4 +15,7 @@ cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.c
 cp $(find /tmp/p2 -name "*kernel_stats.csv" | head -1) $OUT/single_stream_kernel_stats.csv
 python $R/tools/profiles_summarize.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) $(find /tmp/p2 -name "*kernel_trace.csv" | head -1) \
        $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $(find /tmp/p4 -name "*counter_collection.csv" | head -1) $OUT
-ls -la $OUT
+bash $R/tools/pmc_desc.sh > /dev/null 2>&1
+# which file holds the shader clock on this box (bench.py sustained leg)
+{ for f in /sys/class/drm/card*/device/pp_dpm_sclk; do echo "== $f"; cat $f; done; rocm-smi --showclocks 2>&1 | head -30; } > $OUT/sclk_probe.txt 2>&1
+ls -la $OUT $R/gpurun_out/pmc_desc 2>/dev/null
