@@ -699,7 +699,7 @@ int psx_build_pyramid(psx_ctx* ctx)
     for (int o = 0; o + 1 < P.num_octaves; o++) {
         const int span = ctx->inc_span[P.L - 1];
         const bool fits = ctx->batch_octaves &&
-            psx_blur_grid(P.oct[o].w, P.oct[o].h, span) + psx_blur_grid(P.oct[o + 1].w, P.oct[o + 1].h, span) <= ctx->resident_blocks;
+            psx_blur_pair_ok(P.oct[o].w, P.oct[o].h, P.oct[o + 1].w, P.oct[o + 1].h, span, ctx->resident_blocks);
         t0[o + 1] = t0[o] + (fits ? D : P.L - 1);
     }
     const int T = t0[P.num_octaves - 1] + P.L - 1;
@@ -721,7 +721,7 @@ int psx_build_pyramid(psx_ctx* ctx)
             if (pair) {
                 const int o2 = jo[q + 1], level2 = t - t0[o2];
                 const int span = ctx->inc_span[level] > ctx->inc_span[level2] ? ctx->inc_span[level] : ctx->inc_span[level2];
-                pair = psx_blur_grid(P.oct[o].w, P.oct[o].h, span) + psx_blur_grid(P.oct[o2].w, P.oct[o2].h, span) <= ctx->resident_blocks;
+                pair = psx_blur_pair_ok(P.oct[o].w, P.oct[o].h, P.oct[o2].w, P.oct[o2].h, span, ctx->resident_blocks);
             }
             if (pair) {
                 const int o2 = jo[q + 1], level2 = t - t0[o2];

@@ -108,6 +108,7 @@ struct PsxBlurJob {
     PsxTaps taps; int span;
 };
 int psx_blur_grid(int W, int H, int span);
+bool psx_blur_pair_ok(int W1, int H1, int W2, int H2, int span, int resident_marching);
 hipError_t psx_launch_blur2(const PsxBlurJob& a, const PsxBlurJob& b, hipStream_t s,
                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // every non-default branch of Pyramid::build_pyramid (pyramid_alt.hip)

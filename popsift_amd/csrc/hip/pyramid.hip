@@ -568,382 +568,6 @@ __device__ __forceinline__ void blur_body_dma(const BlurArgs& a, const int lid)
     flush(nsteps - 1);
 }
 
-// ---------------------------------------------------------------------------------------------
-// blur_body_ldw: k_blur_dma with a fifth wave per workgroup that does nothing but the LDS-DMA.
-// Why: vmcnt is ONE in-order counter per wave for loads and stores.  A wave that both waits for its staged rows
-// and stores its results therefore also waits, every step, for the write-through acknowledgements of the stores
-// it issued a step earlier (measured with in-kernel stamps: 2400 cycles per step in the wait+store phase, 1100
-// with the stores compiled out, identical whether the loads hit the cache or HBM).  With the roles on different
-// waves the loader's counter only ever holds DMA batches (counted waits, NBUF-1 batches ahead) and the four
-// filter waves never wait on vmcnt at all: their stores drain behind the arithmetic of later steps.
-// Barrier protocol per step (all five waves): A = batch k landed (loader waited for it) and the buffer of step
-// k-1 is free, [edge strips: patch + barrier], B = ring rows of step k written.
-// ---------------------------------------------------------------------------------------------
-template <int R, bool LEVEL0, int NBUF, int RINGROWS>
-__device__ __forceinline__ void blur_body_ldw(const BlurArgs& a, const int lid)
-{
-    using G = GeomD<R, NBUF, RINGROWS>;
-    constexpr int HALO = G::HALO, SW = G::SW, CH = G::CH, SWA = G::SWA, NLDT = G::NLDT, P = G::P;
-    constexpr int RING = G::RING, VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS, STAGE = G::STAGE_FLOATS;
-    constexpr int D = NBUF - 1;
-    static_assert(D >= 1 && D <= 3 && (D - 1) * NLDT <= 63, "vmcnt range");
-    __shared__ __attribute__((aligned(16))) float s_all[G::LDS_FLOATS];
-    float* const s_ring = s_all + NBUF * STAGE;
-
-    const int t     = threadIdx.x;
-    const int lane  = t & 63;
-    const int wv    = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int strip = lid % a.nstrips;
-    const int chunk = lid / a.nstrips;
-    const int x0    = strip * TW;
-    const int Y0    = chunk * a.chunk_rows;
-    const int Y1    = min(Y0 + a.chunk_rows, a.H);
-    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
-    const int xs0   = x0 - HALO + a.src_xoff;
-    const bool interior = (xs0 >= 0) && (xs0 + SW <= a.src_width);
-
-    if (wv == 4) {
-        // ------------------------------ loader wave ------------------------------
-        const unsigned lds0 = (unsigned)(unsigned long)(LDS_AS float*)s_all;
-        unsigned st_xb[NLDT], st_off[NLDT];
-#pragma unroll
-        for (int i = 0; i < NLDT; i++) {
-            const int c = i * P + lane;
-            const int row = c / CH, cc = c - row * CH;
-            const int xc = psx_clampi(xs0 + cc * 4, 0, a.src_pitch - 4);
-            st_xb[i]  = (unsigned)xc * 4u;
-            st_off[i] = (unsigned)(row * a.src_pitch) * 4u + st_xb[i];
-        }
-        auto issue = [&](const int k) {
-            const int ybase = Y0 - R + k * BR;
-            const unsigned buf = lds0 + (unsigned)((k % NBUF) * STAGE * 4);
-            if (ybase >= 0 && ybase + BR <= a.H) {
-                const char* step_base = reinterpret_cast<const char*>(a.src + (ptrdiff_t)ybase * a.src_pitch);
-#pragma unroll
-                for (int i = 0; i < NLDT; i++) dma16<P>(step_base, st_off[i], buf + (unsigned)(i * P * 16));
-            } else {
-#pragma unroll
-                for (int i = 0; i < NLDT; i++) {
-                    const int row = (i * P + lane) / CH;
-                    const int y = psx_clampi(ybase + row, 0, a.H - 1);
-                    dma16<P>(reinterpret_cast<const char*>(a.src), (unsigned)(y * a.src_pitch) * 4u + st_xb[i], buf + (unsigned)(i * P * 16));
-                }
-            }
-        };
-#pragma unroll
-        for (int q = 0; q < D; q++) if (q < nsteps) issue(q);
-        for (int k = 0; k < nsteps; k++) {
-            const int newer = min(D - 1, nsteps - 1 - k);          // batches issued after batch k
-            if (newer >= 2) wait_vmcnt<(D >= 3 ? 2 : 0) * NLDT>();
-            else if (newer == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * NLDT>();
-            else wait_vmcnt<0>();
-            __syncthreads();                                     // A
-            if (k + D < nsteps) issue(k + D);
-            if (!interior) __syncthreads();
-            __syncthreads();                                     // B
-        }
-        return;
-    }
-
-    // ------------------------------ filter waves (threads 0..255) ------------------------------
-    int h_row, h_seg;
-    {
-        const int blk = (t & 31) >> 2;
-        const int rq = (0x21120330 >> (4 * blk)) & 3;
-        const int sh = (0xCC >> blk) & 1;
-        h_row = (t >> 6) * 8 + ((t >> 5) & 1) * 4 + rq;
-        h_seg = sh * 4 + (t & 3);
-    }
-    const int h_off = h_row * SWA + h_seg * 8;
-    const int v_pp = t & 31, v_rg = t >> 5;
-    const int v_x  = x0 + 2 * v_pp;
-    const unsigned v_doff = (unsigned)((v_rg * 4) * a.pitch + v_x) * 4u;
-    const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
-    const int e_l = min(max(-xs0, 0), SW - 1), e_r = max(min(a.src_width - xs0, SW), 1);
-
-    v2f pend[4];
-    auto flush = [&](const int kk) {
-        const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
-        char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r_out = r_out0 + i;
-            if (r_out >= Y0 && r_out < Y1 && v_xok) {
-                char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
-                if (v_pair) {
-                    unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                } else *reinterpret_cast<float*>(di) = pend[i].x;
-                if (a.half_dst != nullptr && (r_out & 1) == 0)
-                    a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
-            }
-        }
-    };
-
-    int sbase = 0;
-    for (int k = 0; k < nsteps; k++) {
-        __syncthreads();                                     // A
-        float* const stage = s_all + (k % NBUF) * STAGE;
-        if (!interior) {
-            const int row = t >> 3, sub = t & 7;
-            float* rp = stage + row * SWA;
-            const float vl = rp[e_l], vr = rp[e_r - 1];
-            for (int c = sub; c < e_l; c += 8) rp[c] = vl;
-            for (int c = e_r + sub; c < SW; c += 8) rp[c] = vr;
-            __syncthreads();
-        }
-        {
-            const LDS_AS float* h_src = (const LDS_AS float*)(stage + h_off);
-            float win[8 + 2 * HALO];
-#pragma unroll
-            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
-                const v4f v = ((const volatile LDS_AS v4f*)h_src)[q];
-                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
-            }
-            float out[8];
-            hfilter8_km<R, HALO, LEVEL0>(win, a.taps, out);
-            int slot = sbase + h_row; if (slot >= RING) slot -= RING;
-            float* rp = &s_ring[slot * RS + h_seg * 8];
-            reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
-            reinterpret_cast<float4*>(rp)[1] = make_float4(out[4], out[5], out[6], out[7]);
-            if (slot < MIRROR) {
-                reinterpret_cast<float4*>(rp + RING * RS)[0] = make_float4(out[0], out[1], out[2], out[3]);
-                reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
-            }
-        }
-        __syncthreads();                                     // B
-        {
-            const int rel0 = k * BR - 2 * R + v_rg * 4;
-            const int r_out0 = Y0 + rel0;
-            if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
-                int vs = sbase - 2 * R + v_rg * 4;
-                if (vs < 0) vs += RING;
-                if (vs >= RING) vs -= RING;
-                const LDS_AS float* vp = (const LDS_AS float*)&s_ring[vs * RS + 2 * v_pp];
-                v2f v[VWIN];
-#pragma unroll
-                for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
-                v2f o[4];
-                vfilter2x4_km<R>(v, LEVEL0 ? a.taps_v : a.taps, o);
-                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-#pragma unroll
-                for (int i = 0; i < 4; i++) pend[i] = o[i];
-            }
-        }
-        flush(k);                                            // never waited for: these waves issue no loads
-        sbase += BR; if (sbase >= RING) sbase -= RING;
-    }
-}
-
-constexpr int NT_LDW = NT + 64;
-template <int R, int NBUF, int RINGROWS>
-constexpr int ldw_waves_per_simd()
-{
-    const int lds = GeomD<R, NBUF, RINGROWS>::LDS_FLOATS * 4;
-    int n = (160 * 1024) / lds;                 // workgroups per CU by LDS
-    n = n > 4 ? 4 : (n < 1 ? 1 : n);
-    return (n * 5 + 3) / 4;                     // 5 waves per workgroup over 4 SIMDs
-}
-template <int R, bool LEVEL0, int NBUF, int RINGROWS>
-__global__ __launch_bounds__(NT_LDW, (ldw_waves_per_simd<R, NBUF, RINGROWS>())) void k_blur_ldw(BlurArgs a)
-{
-    blur_body_ldw<R, LEVEL0, NBUF, RINGROWS>(a, xcd_remap(blockIdx.x, gridDim.x));
-}
-
-template <int R, int NB>
-constexpr int dma_wg_per_cu_fwd()
-{
-    const int lds = GeomD<R, NB, ((2 * BR + 2 * R + 15) & ~15)>::LDS_FLOATS * 4;
-    const int n = (160 * 1024) / lds;
-    return n > 4 ? 4 : (n < 1 ? 1 : n);
-}
-
-// ---------------------------------------------------------------------------------------------
-// blur_body_hv: the horizontal and the vertical pass on DIFFERENT waves, running concurrently.
-// The stamps and counters of round 3 say that a step of k_blur is a serial chain inside the workgroup -- wait for the
-// staged rows, H, barrier, V, stores -- and that only the four workgroups of a CU overlap each other.  Here waves 0-1
-// (the H role) bring step k's rows in by LDS-DMA and filter them horizontally into the ring while waves 2-3 (the V
-// role) filter step k-1's ring rows vertically and store them: ONE barrier per step, both roles carry the same
-// arithmetic (4 (2R+1) packed operations per task, two tasks per lane), the H waves' vmcnt only ever holds DMA
-// batches (counted waits) and the V waves never wait on memory at all.
-// Ring: rows being written by H(k) + the window V(k-1) reads = 2 BR + 2R rows.  Stage buffers: NB = 2 (batch k+1
-// issued at the top of iteration k into the buffer H(k-1) read) or 3 (batch k+2 issued after H(k)).
-// Iteration k: H(k) || V(k-1); the H waves wait for batch k+1 before the barrier, so after it every wave may read it.
-// ---------------------------------------------------------------------------------------------
-template <int R, int NB, int RINGROWS>
-__device__ __forceinline__ void blur_body_hv(const BlurArgs& a, const int lid)
-{
-    using G = GeomD<R, NB, RINGROWS>;
-    constexpr int HALO = G::HALO, SW = G::SW, CH = G::CH, SWA = G::SWA, NLDT = G::NLDT, P = G::P;
-    constexpr int RING = G::RING, VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS, STAGE = G::STAGE_FLOATS;
-    constexpr int NLDH = NLDT / 2;                       // DMA wave instructions per H wave and step
-    static_assert(NLDT % 2 == 0 && (NB == 2 || NB == 3), "geometry");
-    static_assert(RING >= 2 * BR + 2 * R, "ring holds the rows H writes plus the window V reads");
-    __shared__ __attribute__((aligned(16))) float s_all[G::LDS_FLOATS];
-    float* const s_ring = s_all + NB * STAGE;
-
-    const int t     = threadIdx.x;
-    const int lane  = t & 63;
-    const int wv    = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int strip = lid % a.nstrips;
-    const int chunk = lid / a.nstrips;
-    const int x0    = strip * TW;
-    const int Y0    = chunk * a.chunk_rows;
-    const int Y1    = min(Y0 + a.chunk_rows, a.H);
-    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
-    const int xs0   = x0 - HALO + a.src_xoff;
-    const bool interior = (xs0 >= 0) && (xs0 + SW <= a.src_width);
-    const int e_l = min(max(-xs0, 0), SW - 1), e_r = max(min(a.src_width - xs0, SW), 1);
-
-    if (wv < 2) {
-        // ------------------------------ H role: waves 0, 1 ------------------------------
-        const unsigned lds0 = (unsigned)(unsigned long)(LDS_AS float*)s_all;
-        unsigned st_xb[NLDH], st_off[NLDH];
-#pragma unroll
-        for (int j = 0; j < NLDH; j++) {
-            const int c = (wv * NLDH + j) * P + lane;
-            const int row = c / CH, cc = c - row * CH;
-            const int xc = psx_clampi(xs0 + cc * 4, 0, a.src_pitch - 4);
-            st_xb[j]  = (unsigned)xc * 4u;
-            st_off[j] = (unsigned)(row * a.src_pitch) * 4u + st_xb[j];
-        }
-        auto issue = [&](const int k) {
-            const int ybase = Y0 - R + k * BR;
-            const unsigned buf = lds0 + (unsigned)((k % NB) * STAGE * 4);
-            if (ybase >= 0 && ybase + BR <= a.H) {
-                const char* step_base = reinterpret_cast<const char*>(a.src + (ptrdiff_t)ybase * a.src_pitch);
-#pragma unroll
-                for (int j = 0; j < NLDH; j++) dma16<P>(step_base, st_off[j], buf + (unsigned)((wv * NLDH + j) * P * 16));
-            } else {
-#pragma unroll
-                for (int j = 0; j < NLDH; j++) {
-                    const int row = ((wv * NLDH + j) * P + lane) / CH;
-                    const int y = psx_clampi(ybase + row, 0, a.H - 1);
-                    dma16<P>(reinterpret_cast<const char*>(a.src), (unsigned)(y * a.src_pitch) * 4u + st_xb[j], buf + (unsigned)((wv * NLDH + j) * P * 16));
-                }
-            }
-        };
-        // two tasks per lane: virtual thread ids t and t + 128 of the 256-thread layout of blur_body
-        int h_off[2], h_rowv[2], h_segv[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int tv = t + 128 * q;
-            const int blk = (tv & 31) >> 2;
-            const int rq = (0x21120330 >> (4 * blk)) & 3;
-            const int sh = (0xCC >> blk) & 1;
-            h_rowv[q] = (tv >> 6) * 8 + ((tv >> 5) & 1) * 4 + rq;
-            h_segv[q] = sh * 4 + (tv & 3);
-            h_off[q]  = h_rowv[q] * SWA + h_segv[q] * 8;
-        }
-
-        issue(0);
-        if (NB == 3 && nsteps > 1) { issue(1); wait_vmcnt<NLDH>(); } else wait_vmcnt<0>();
-        __syncthreads();                                 // batch 0 visible
-        int sbase = 0;
-        for (int k = 0; k <= nsteps; k++) {
-            if (k < nsteps) {
-                if (NB == 2 && k + 1 < nsteps) issue(k + 1);           // into the buffer H(k-1) read
-                float* const stage = s_all + (k % NB) * STAGE;
-                if (!interior) {
-                    const int row = t >> 2, sub = t & 3;               // 128 threads: 32 rows x 4
-                    float* rp = stage + row * SWA;
-                    const float vl = rp[e_l], vr = rp[e_r - 1];
-                    for (int c = sub; c < e_l; c += 4) rp[c] = vl;
-                    for (int c = e_r + sub; c < SW; c += 4) rp[c] = vr;
-                    __syncthreads();                                   // edge strips only (the V waves join it)
-                }
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const LDS_AS float* h_src = (const LDS_AS float*)(stage + h_off[q]);
-                    float win[8 + 2 * HALO];
-#pragma unroll
-                    for (int i = 0; i < (8 + 2 * HALO) / 4; i++) {
-                        const v4f v = ((const volatile LDS_AS v4f*)h_src)[i];
-                        win[4 * i + 0] = v.x; win[4 * i + 1] = v.y; win[4 * i + 2] = v.z; win[4 * i + 3] = v.w;
-                    }
-                    float out[8];
-                    hfilter8_km<R, HALO, false>(win, a.taps, out);
-                    int slot = sbase + h_rowv[q]; if (slot >= RING) slot -= RING;
-                    float* rp = &s_ring[slot * RS + h_segv[q] * 8];
-                    reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
-                    reinterpret_cast<float4*>(rp)[1] = make_float4(out[4], out[5], out[6], out[7]);
-                    if (slot < MIRROR) {
-                        reinterpret_cast<float4*>(rp + RING * RS)[0] = make_float4(out[0], out[1], out[2], out[3]);
-                        reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
-                    }
-                }
-                if (NB == 3 && k + 2 < nsteps) issue(k + 2);           // into the buffer H(k-1) read
-                // batch k+1 must have landed before the barrier; a newer batch (NB == 3) stays in flight
-                if (NB == 3 && k + 2 < nsteps) wait_vmcnt<NLDH>(); else wait_vmcnt<0>();
-            } else if (!interior) {
-                // nothing
-            }
-            __syncthreads();
-            sbase += BR; if (sbase >= RING) sbase -= RING;
-        }
-        return;
-    }
-
-    // ------------------------------ V role: waves 2, 3 ------------------------------
-    {
-        const int u = t - 128;
-        int v_ppv[2], v_rgv[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++) { const int tv = u + 128 * q; v_ppv[q] = tv & 31; v_rgv[q] = tv >> 5; }
-        __syncthreads();                                 // batch 0 visible (prologue barrier of the H role)
-        int sbase = 0;                                   // ring slot of step k's first row; V works on step k-1
-        for (int k = 0; k <= nsteps; k++) {
-            if (k < nsteps && !interior) __syncthreads();              // the edge-strip barrier of the H role
-            if (k >= 1) {
-                const int kk = k - 1;
-                int sb = sbase - BR; if (sb < 0) sb += RING;           // slot of step kk's first row
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int v_pp = v_ppv[q], v_rg = v_rgv[q];
-                    const int v_x = x0 + 2 * v_pp;
-                    const int rel0 = kk * BR - 2 * R + v_rg * 4;
-                    const int r_out0 = Y0 + rel0;
-                    if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
-                        int vs = sb - 2 * R + v_rg * 4;
-                        if (vs < 0) vs += RING;
-                        if (vs >= RING) vs -= RING;
-                        const LDS_AS float* vp = (const LDS_AS float*)&s_ring[vs * RS + 2 * v_pp];
-                        v2f v[VWIN];
-#pragma unroll
-                        for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
-                        v2f o[4];
-                        vfilter2x4_km<R>(v, a.taps, o);
-                        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-                        const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int r_out = r_out0 + i;
-                            if (r_out >= Y0 && r_out < Y1 && v_xok) {
-                                float* di = a.dst + (size_t)r_out * a.pitch + v_x;
-                                if (v_pair) {
-                                    unsigned long long bits; __builtin_memcpy(&bits, &o[i], 8);
-                                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                } else *di = o[i].x;
-                                if (a.half_dst != nullptr && (r_out & 1) == 0)
-                                    a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = o[i].x;
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            sbase += BR; if (sbase >= RING) sbase -= RING;
-        }
-    }
-}
-
-constexpr int hv_ring(int R) { return (2 * BR + 2 * R + 15) & ~15; }
-template <int R, int NB>
-__global__ __launch_bounds__(NT, (dma_wg_per_cu_fwd<R, NB>())) void k_blur_hv(BlurArgs a)
-{
-    blur_body_hv<R, NB, hv_ring(R)>(a, xcd_remap(blockIdx.x, gridDim.x));
-}
-
 // workgroups of 256 threads a CU can hold for a variant (LDS bound; 4 waves per SIMD at <= 128 VGPRs)
 template <int R, int NBUF, int RINGROWS>
 constexpr int dma_wg_per_cu()
@@ -1338,9 +962,9 @@ inline const BlurTuning& blur_tuning()
     static const BlurTuning t = [] {
         BlurTuning v{5, true, 0, 0};
         // POPSIFT_BLUR_DMA: 0 = register-staged k_blur, 2 / 3 = LDS-DMA staging with 2 / 3 stage buffers (k_blur_dma)
-        // 12 / 13 / 14 = the same with a dedicated loader wave per workgroup (k_blur_ldw) and 2 / 3 / 4 stage buffers
-        // 22 / 23 = H and V pass on different waves (k_blur_hv) with 2 / 3 stage buffers
-        if (const char* e = getenv("POPSIFT_BLUR_DMA")) { const int n = atoi(e); if (n == 0 || n == 2 || n == 3 || (n >= 12 && n <= 14) || n == 22 || n == 23) v.dma = n; }
+        // (a dedicated loader wave, H and V on different waves and a one-shot tile kernel for the small planes were built
+        // on top of it in round 3, measured slower and removed again: profiles/r03_blur_staging_experiments.txt, git history)
+        if (const char* e = getenv("POPSIFT_BLUR_DMA")) { const int n = atoi(e); if (n == 0 || n == 2 || n == 3) v.dma = n; }
         if (const char* e = getenv("POPSIFT_BLUR_DMA_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.dma_steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_DEFER")) v.defer = e[0] != '0';
@@ -1387,6 +1011,12 @@ int fill_job(BlurArgs& a, const PsxBlurJob& j)
     return a.nstrips * nchunks;
 }
 
+inline int device_cus()
+{
+    static const int n = [] { int d = 0, c = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256; return c; }();
+    return n;
+}
+
 template <int R>
 hipError_t launch_blur2_r(const PsxBlurJob& ja, const PsxBlurJob& jb, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
@@ -1400,11 +1030,6 @@ hipError_t launch_blur2_r(const PsxBlurJob& ja, const PsxBlurJob& jb, hipStream_
 
 // ring rows of the LDS-DMA variant: the smallest multiple of 16 that holds a step's BR + 2R rows
 constexpr int dma_ring(int R) { return (BR + 2 * R + 15) & ~15; }
-inline int device_cus()
-{
-    static const int n = [] { int d = 0, c = 0; if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c <= 0) c = 256; return c; }();
-    return n;
-}
 
 // Chunking for k_blur_dma.  A plane that fits one round of resident workgroups should be exactly one round (a second,
 // nearly empty round doubles the launch): take the smallest S >= 5 steps per chunk that fits; planes of several rounds
@@ -1442,27 +1067,6 @@ void launch_dma(BlurArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
     else                                  hipLaunchKernelGGL((k_blur_dma<R, LEVEL0, NBUF, RING>), grid, block, 0, s, a);
 }
 
-template <int R, bool LEVEL0, int NBUF>
-void launch_ldw(BlurArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
-{
-    constexpr int RING = dma_ring(R);
-    int nchunks;
-    chunking_dma(a.W, a.H, R, dma_wg_per_cu<R, NBUF, RING>() * device_cus(), a.chunk_rows, nchunks);
-    const dim3 grid(a.nstrips * nchunks), block(NT_LDW);
-    if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((k_blur_ldw<R, LEVEL0, NBUF, RING>), grid, block, 0, s, ev0, ev1, 0, a);
-    else                                  hipLaunchKernelGGL((k_blur_ldw<R, LEVEL0, NBUF, RING>), grid, block, 0, s, a);
-}
-
-template <int R, int NB>
-void launch_hv(BlurArgs& a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
-{
-    int nchunks;
-    chunking_dma(a.W, a.H, R, dma_wg_per_cu_fwd<R, NB>() * device_cus(), a.chunk_rows, nchunks);
-    const dim3 grid(a.nstrips * nchunks), block(NT);
-    if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((k_blur_hv<R, NB>), grid, block, 0, s, ev0, ev1, 0, a);
-    else                                  hipLaunchKernelGGL((k_blur_hv<R, NB>), grid, block, 0, s, a);
-}
-
 template <int R>
 hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, const PsxTaps& taps,
                          float* half_dst, int half_pitch, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
@@ -1476,11 +1080,6 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
         const int dma = blur_tuning().dma;
         if (dma == 2) { launch_dma<R, false, 2>(a, s, ev0, ev1); return hipGetLastError(); }
         if (dma == 3) { launch_dma<R, false, 3>(a, s, ev0, ev1); return hipGetLastError(); }
-        if (dma == 12) { launch_ldw<R, false, 2>(a, s, ev0, ev1); return hipGetLastError(); }
-        if (dma == 13) { launch_ldw<R, false, 3>(a, s, ev0, ev1); return hipGetLastError(); }
-        if (dma == 14) { launch_ldw<R, false, 4>(a, s, ev0, ev1); return hipGetLastError(); }
-        if (dma == 22) { launch_hv<R, 2>(a, s, ev0, ev1); return hipGetLastError(); }
-        if (dma == 23) { launch_hv<R, 3>(a, s, ev0, ev1); return hipGetLastError(); }
     }
     const bool ext = ev0 != nullptr || ev1 != nullptr;       // kernel begin / end timestamps of THIS dispatch (what rocprofv3 --kernel-trace reports)
     if (blur_tuning().defer) {
@@ -1546,9 +1145,6 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
         const int dma = blur_tuning().dma;
         if (dma == 2) { launch_dma<R, true, 2>(a, s, nullptr, nullptr); return hipGetLastError(); }
         if (dma == 3) { launch_dma<R, true, 3>(a, s, nullptr, nullptr); return hipGetLastError(); }
-        if (dma == 12) { launch_ldw<R, true, 2>(a, s, nullptr, nullptr); return hipGetLastError(); }
-        if (dma == 13) { launch_ldw<R, true, 3>(a, s, nullptr, nullptr); return hipGetLastError(); }
-        if (dma == 14) { launch_ldw<R, true, 4>(a, s, nullptr, nullptr); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((k_blur<R, true>), dim3(a.nstrips * nchunks), dim3(NT), 0, s, a);
     return hipGetLastError();
@@ -1572,6 +1168,13 @@ hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch
     if (R <= 22) return launch_blur_r<22>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
     if (R <= 30) return launch_blur_r<30>(src, dst, W, H, pitch, taps, half_dst, half_pitch, s, ev0, ev1);
     return hipErrorInvalidValue;
+}
+
+// Pairing rule of the diagonal schedule: the level launches of two planes share ONE launch when both chunk grids fit one
+// round of resident workgroups
+bool psx_blur_pair_ok(int W1, int H1, int W2, int H2, int span, int resident_marching)
+{
+    return psx_blur_grid(W1, H1, span) + psx_blur_grid(W2, H2, span) <= resident_marching;
 }
 
 // workgroups a blur of a W x H plane is launched with
