@@ -142,3 +142,17 @@ def test_cpp_host_library_api(tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert out.returncode == 0, out.stdout
     assert "ALL OK" in out.stdout
+
+
+def test_bench_algorithmic_bytes_match_the_survey():
+    """bench.py's roofline numerators: separable-Gaussian stage 44 N0 + 48 sum N_o + input, whole image
+    pipe 68 N0 + 72 sum N_o + input, for the 1080p workload (octave 0 = 3840 x 2160, 5 octaves)."""
+    import bench
+    px = bench.octave_pixels(1920, 1080, 5)
+    assert px == [3840 * 2160, 1920 * 1080, 960 * 540, 480 * 270, 240 * 135]
+    stage, pipe = bench.algorithmic_bytes(1920, 1080, 5)
+    assert stage == 44 * px[0] + 48 * sum(px[1:]) + 1920 * 1080
+    assert pipe == 68 * px[0] + 72 * sum(px[1:]) + 1920 * 1080
+    assert abs(pipe - 0.764e9) < 1e6 and abs(stage - 499.2e6) < 1e5
+    assert bench.BATCH * 20 >= 200                      # the driver's 20 steps time >= 200 frames per GPU
+    assert bench.octave_pixels(75, 61, 3) == [150 * 122, 75 * 61, 38 * 31]
