@@ -92,6 +92,18 @@ def read_sclk_mhz(device=0):
     return best
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def frame_seed(j, rank, world):
     """Seed of this rank's j-th base frame: global frame i = j * world + rank goes to GPU i mod world."""
     return 1000 + j * world + rank
