@@ -156,3 +156,25 @@ def test_bench_algorithmic_bytes_match_the_survey():
     assert abs(pipe - 0.764e9) < 1e6 and abs(stage - 499.2e6) < 1e5
     assert bench.BATCH * 20 >= 200                      # the driver's 20 steps time >= 200 frames per GPU
     assert bench.octave_pixels(75, 61, 3) == [150 * 122, 75 * 61, 38 * 31]
+
+
+def test_bench_has_no_undefined_names():
+    """bench.py's GPU-only legs cannot run here; at least every name they load must exist (a helper deleted by an edit
+    would otherwise only surface on the GPU box)."""
+    import ast
+    import builtins
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    known = set(dir(builtins)) | {"__file__"}
+    for n in ast.walk(tree):
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+            known.add(n.name)
+        elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+            known.add(n.id)
+        elif isinstance(n, ast.arg):
+            known.add(n.arg)
+        elif isinstance(n, (ast.Import, ast.ImportFrom)):
+            known.update((a.asname or a.name).split(".")[0] for a in n.names)
+        elif isinstance(n, ast.ExceptHandler) and n.name:
+            known.add(n.name)
+    loaded = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+    assert loaded <= known, sorted(loaded - known)
