@@ -501,6 +501,7 @@ __device__ __forceinline__ void blur_body_dma(const BlurArgs& a, const int lid)
         }
     };
 
+    if (NBUF == 1) issue(0);                             // single stage buffer: batch k+1 goes out after H(k) has read batch k
 #pragma unroll
     for (int q = 0; q < D; q++) if (q < nsteps) issue(q);
     int sbase = 0;                                       // ring slot of the first row filtered in step k = (k * BR) mod RING
@@ -511,7 +512,7 @@ __device__ __forceinline__ void blur_body_dma(const BlurArgs& a, const int lid)
         } else wait_vmcnt<0>();
         flush(k - 1);
         __syncthreads();                                 // A: everyone's part of batch k is in LDS; V(k-1) and H(k-1) are done
-        if (k + D < nsteps) issue(k + D);                // into the buffer H(k-1) read
+        if (NBUF > 1 && k + D < nsteps) issue(k + D);    // into the buffer H(k-1) read
         float* const stage = s_all + (k % NBUF) * STAGE;
         if (!interior) {
             const int row = t >> 3, sub = t & 7;
@@ -543,6 +544,7 @@ __device__ __forceinline__ void blur_body_dma(const BlurArgs& a, const int lid)
             }
         }
         __syncthreads();                                 // B
+        if (NBUF == 1 && k + 1 < nsteps) issue(k + 1);   // the one stage buffer is free again
 
         // ---- vertical ----
         {
@@ -574,7 +576,8 @@ constexpr int dma_wg_per_cu()
 {
     const int lds = GeomD<R, NBUF, RINGROWS>::LDS_FLOATS * 4;
     const int n = (160 * 1024) / lds;
-    return n > 4 ? 4 : (n < 1 ? 1 : n);
+    const int cap = NBUF == 1 ? 5 : 4;               // the single-buffer variant is lean enough for 5 (<= 96 VGPRs asked for)
+    return n > cap ? cap : (n < 1 ? 1 : n);
 }
 
 template <int R, bool LEVEL0, int NBUF, int RINGROWS>
@@ -964,7 +967,8 @@ inline const BlurTuning& blur_tuning()
         // POPSIFT_BLUR_DMA: 0 = register-staged k_blur, 2 / 3 = LDS-DMA staging with 2 / 3 stage buffers (k_blur_dma)
         // (a dedicated loader wave, H and V on different waves and a one-shot tile kernel for the small planes were built
         // on top of it in round 3, measured slower and removed again: profiles/r03_blur_staging_experiments.txt, git history)
-        if (const char* e = getenv("POPSIFT_BLUR_DMA")) { const int n = atoi(e); if (n == 0 || n == 2 || n == 3) v.dma = n; }
+        // 1 = one stage buffer (the next batch goes out after the H pass): the least LDS, up to 5 workgroups per CU
+        if (const char* e = getenv("POPSIFT_BLUR_DMA")) { const int n = atoi(e); if (n >= 0 && n <= 3) v.dma = n; }
         if (const char* e = getenv("POPSIFT_BLUR_DMA_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.dma_steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_STEPS")) { const int n = atoi(e); if (n >= 2 && n <= 64) v.steps = n; }
         if (const char* e = getenv("POPSIFT_BLUR_DEFER")) v.defer = e[0] != '0';
@@ -1078,6 +1082,7 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
     const dim3 grid(fill_job<R>(a, j)), block(NT);
     if constexpr (R <= 13) {
         const int dma = blur_tuning().dma;
+        if (dma == 1) { launch_dma<R, false, 1>(a, s, ev0, ev1); return hipGetLastError(); }
         if (dma == 2) { launch_dma<R, false, 2>(a, s, ev0, ev1); return hipGetLastError(); }
         if (dma == 3) { launch_dma<R, false, 3>(a, s, ev0, ev1); return hipGetLastError(); }
     }
