@@ -1,7 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/liboracle.so).
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
-cpu_baseline leg of bench.py -- never from popsift_amd/.
+cpu_baseline leg and the parity_checked step (checker, outside the timed regions) of bench.py -- never from popsift_amd/.
 """
 import ctypes as C
 import os

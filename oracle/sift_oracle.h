@@ -3,7 +3,9 @@
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing in the product (popsift_amd/, include/) may
  * include, link or call this.  Allowed users: tests/, __graft_entry__.smoke(),
- * and the cpu_baseline leg of bench.py.
+ * and bench.py -- its cpu_baseline leg (the thing timed there is the oracle itself, as the
+ * CPU baseline) and its parity_checked step (the checker of 4 timed frames, outside every
+ * timed region).
  *
  * The oracle restates, op by op, the arithmetic of the reference's default path
  * (reference = alicevision/popsift, paths relative to /root/reference/src/popsift):

@@ -105,6 +105,13 @@ def test_product_does_not_reference_the_oracle():
     hdr = open(os.path.join(ROOT, "include", "popsift_hip.h")).read()
     assert "oracle" not in hdr
     assert not bad, bad
+    # bench.py: the oracle is imported in exactly two places -- the CPU baseline and the post-run parity check --
+    # and neither sits inside a timed leg (e2e_parity is a backend method called after timed(); extras() runs last)
+    btxt = open(os.path.join(ROOT, "bench.py")).read()
+    assert btxt.count("from oracle import pyoracle") == 2
+    assert "def e2e_parity" in btxt and "from oracle import pyoracle as po" in btxt.split("def e2e_parity")[1].split("def ")[0]
+    timed_body = btxt.split("def timed(step, drain):")[1].split("# ---- leg 1")[0]
+    assert "oracle" not in timed_body
 
 
 def test_bench_frame_rule_is_round_robin_over_gpus():
