@@ -8,7 +8,8 @@ Workload (BASELINE.json configs[1] / BASELINE.md workload 2): 1920x1080 grayscal
 Config with octaves=5, levels=3 (x2 upsample => octave 0 is 3840x2160), distinct frames streamed
 through the product's public API: host image -> PopSift::enqueue -> SiftJob::get -> FeaturesHost
 (the C++14 library popsift_amd/lib/libpopsift.so, bound through include/popsift_c.h).  A "step" is
-BATCH = 16 frames per GPU (so that the driver's 20 steps time 320 frames: SURVEY.md 8d asks for >= 200).  Frames are independent: frame i of the global sequence goes to GPU i mod N
+BATCH = 64 frames per GPU = one pass over the rank's 64 distinct frames (BASELINE config 4's batch; the driver's 20 steps
+time 1280 frames: SURVEY.md 8d asks for >= 200).  Frames are independent: frame i of the global sequence goes to GPU i mod N
 (BASELINE config 4), ranks share nothing, no collective on the data path (weak scaling);
 value = total pixels of all ranks / max-over-ranks time, results of every timed frame collected inside the
 timed region.
@@ -27,7 +28,7 @@ The JSON line also carries
                  bounded sample of the same frames (rank 0, N=1 only)
   parity_checked : 4 of the timed frames re-run through the SAME PopSift object after the timed region and matched
                  against the oracle (exact mismatch counts)
-  sustained    : the end-to-end leg kept running for >= 3 s / >= 8000 frames (N=1): Mpix/s per 208-frame window
+  sustained    : the end-to-end leg kept running for >= 3 s / >= 8000 frames (N=1): Mpix/s per 256-frame window
                  (min / median / max), GPU clock before and after
   sparse_frames: the end-to-end leg on a second frame set with ~2 keypoints / 1000 px (the default set has ~7)
   pcie_gbs, pipe_roofline, roofline.stage, alt_modes_ms: see DESIGN.md section 6
@@ -43,14 +44,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-BATCH = 16         # frames per step per rank (20 driver steps = 320 timed frames per GPU; SURVEY.md 8d: >= 200)
+BATCH = 64         # frames per step per rank: one pass over the NDISTINCT distinct frames (20 driver steps = 1280 timed frames)
+NBASE = 16         # synthetic base frames per rank; the other distinct frames are shifted / flipped variants of them
 NDISTINCT = 64     # distinct frames per rank that the steps cycle through
 NCTX = int(os.environ.get("POPSIFT_BENCH_CTX", "16"))       # C-ABI legs: extraction contexts in flight per GPU
 MAX_OUT = int(os.environ.get("POPSIFT_BENCH_OUTSTANDING", "24"))   # end-to-end leg: jobs outstanding per PopSift
 HBM_PEAK_GBS = 8000.0
 SUSTAINED_S = float(os.environ.get("POPSIFT_BENCH_SUSTAINED_S", "3.0"))
 SUSTAINED_FRAMES = int(os.environ.get("POPSIFT_BENCH_SUSTAINED_FRAMES", "8000"))
-WINDOW = 13 * BATCH                                          # frames per sustained-leg window (208)
+WINDOW = 4 * BATCH                                           # frames per sustained-leg window (256)
 
 
 def octave_pixels(w, h, octaves, up=1):
@@ -110,14 +112,14 @@ def frame_seed(j, rank, world):
 
 
 def make_frames(rank, world, synth, sparse=False):
-    """NDISTINCT distinct frames for this rank: BATCH synthetic base frames (popsift_amd/synth.py; base 0 of
+    """NDISTINCT distinct frames for this rank: NBASE synthetic base frames (popsift_amd/synth.py; base 0 of
     rank 0 is the frame the parity tests check) and cheap distinct variants of them (cyclic shift + flip).
     sparse: the ~2 keypoints / 1000 px variant of the generator."""
     import numpy as np
     base = [synth(W, H, frame_seed(j, rank, world), sparse=True) if sparse else synth(W, H, frame_seed(j, rank, world))
-            for j in range(BATCH)]
+            for j in range(NBASE)]
     frames = []
-    for v in range(NDISTINCT // BATCH):
+    for v in range(NDISTINCT // NBASE):
         for b in base:
             f = b if v == 0 else np.roll(b, (53 * v, 97 * v), axis=(0, 1))
             if v & 1:
@@ -579,7 +581,7 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         po.run(ocfg, frames_np[0], threads=ncores).close()     # warm
         n_s = 0
         t1 = time.perf_counter()
-        while n_s < BATCH and (n_s < 2 or time.perf_counter() - t1 < 12.0):
+        while n_s < NBASE and (n_s < 2 or time.perf_counter() - t1 < 12.0):
             po.run(ocfg, frames_np[n_s], threads=ncores).close()
             n_s += 1
         cdt = time.perf_counter() - t1
