@@ -391,7 +391,7 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
                                    "pipe (pyramid, extrema, orientation, descriptors)" % NDISTINCT,
                        "frames_per_step_per_gpu": BATCH, "frames_timed": n_frames,
                        "jobs_outstanding_per_gpu": MAX_OUT,
-                       "pipe_depth": os.environ.get("POPSIFT_PIPE_DEPTH", "min(8, usable cores / local replicas)"),
+                       "pipe_depth": os.environ.get("POPSIFT_PIPE_DEPTH", "clamp(usable cores / local replicas, 4, 8)"),
                        "parallelism": "replicas x%d (frame i -> GPU i mod N, no collective)" % world},
             "keypoints_per_s": round(kps_e2e / dt_e2e, 1),
             "keypoints_per_frame": round(kps_e2e / n_frames, 1),
