@@ -84,7 +84,8 @@ def test_pgm_ppm_reader_all_variants(pgm_tool, tmp_path):
 DEMO_OPTIONS = ["help", "verbose", "log", "input-file", "octaves", "levels", "sigma", "threshold", "edge-threshold", "edge-limit",
                 "downsampling", "initial-blur", "gauss-mode", "desc-mode", "popsift-mode", "vlfeat-mode", "opencv-mode",
                 "direct-scaling", "norm-multi", "norm-mode", "root-sift", "filter-max-extrema", "filter-grid", "filter-sort",
-                "print-gauss-tables", "print-dev-info", "print-time-info", "write-as-uchar", "dont-write", "pgmread-loading", "float-mode"]
+                "print-gauss-tables", "print-dev-info", "print-time-info", "write-as-uchar", "dont-write", "pgmread-loading", "float-mode",
+                "devices", "device-list"]          # the last two are additions (replicas in one process), not reference options
 
 
 def test_demo_option_surface(built):
@@ -100,7 +101,8 @@ def test_demo_option_surface(built):
 
 def test_demo_rejects_bad_command_lines(built, tmp_path):
     demo = os.path.join(built, "popsift-demo")
-    for argv in (["--no-such-option"], ["--octaves"], ["--octaves", "x", "-i", "a.pgm"], ["--gauss-mode", "nonsense", "-i", "a.pgm"], []):
+    for argv in (["--no-such-option"], ["--octaves"], ["--octaves", "x", "-i", "a.pgm"], ["--gauss-mode", "nonsense", "-i", "a.pgm"], [],
+                 ["--devices", "0", "-i", "a.pgm"], ["--device-list", "0,,1", "-i", "a.pgm"], ["--device-list", "gpu0", "-i", "a.pgm"]):
         p = subprocess.run([demo] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path))
         assert p.returncode != 0, argv
     # a missing input is "nothing to do" with a failure exit code (main.cpp:289-292)
