@@ -4,15 +4,16 @@
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1] / BASELINE.md workload 2): 1920x1080 grayscale u8 frames, default
-Config with octaves=5, levels=3 (x2 upsample => octave 0 is 3840x2160), distinct frames streamed
-through the product's public API: host image -> PopSift::enqueue -> SiftJob::get -> FeaturesHost
-(the C++14 library popsift_amd/lib/libpopsift.so, bound through include/popsift_c.h).  A "step" is
-BATCH = 64 frames per GPU = one pass over the rank's 64 distinct frames (BASELINE config 4's batch; the driver's 20 steps
-time 1280 frames: SURVEY.md 8d asks for >= 200).  Frames are independent: frame i of the global sequence goes to GPU i mod N
-(BASELINE config 4), ranks share nothing, no collective on the data path (weak scaling);
-value = total pixels of all ranks / max-over-ranks time, results of every timed frame collected inside the
-timed region.
+Workload (BASELINE.json configs[1] / BASELINE.md workload 2): 1920x1080 grayscale u8 frames, config 1's Config
+(default Config, setOctaves(5), levels=3, setMode(VLFeat): BASELINE.md section 3; x2 upsample => octave 0 is
+3840x2160), distinct frames streamed through the product's public API: host image -> PopSift::enqueue ->
+SiftJob::get -> FeaturesHost (the C++14 library popsift_amd/lib/libpopsift.so, bound through include/popsift_c.h).
+A "step" is BATCH = 320 frames per GPU = five passes over the rank's 64 distinct frames (BASELINE config 4's batch
+five times; the driver's 20 steps time 6400 frames ~ 2.3 s: SURVEY.md 8d asks for >= 200 frames).  Frames are
+independent: frame i of the global sequence goes to GPU i mod N (BASELINE config 4), ranks share nothing, no
+collective on the data path; default = weak scaling (BATCH frames per GPU and step); --strong = BASELINE config 4's
+literal shape (BATCH frames per step in TOTAL, BATCH / N per GPU).  value = total pixels of all ranks /
+max-over-ranks time, results of every timed frame collected inside the timed region.
 
 Legs (same frames, same kernels, K steps each):
   value / end_to_end : host frames in, FeaturesHost out (upload + full pipe + results in host memory)
@@ -26,8 +27,13 @@ The JSON line also carries
   config3      : BASELINE config 3 (4096x4096, 6 octaves, 8192x8192 octave 0), device resident, one context
   cpu_baseline : the CPU oracle (port of the reference arithmetic, OpenMP over the host cores) timed on a
                  bounded sample of the same frames (rank 0, N=1 only)
-  parity_checked : 4 of the timed frames re-run through the SAME PopSift object after the timed region and matched
-                 against the oracle (exact mismatch counts)
+  parity_checked : 4 of the timed frames of EVERY rank re-run through the SAME PopSift object after the timed region and
+                 matched against the oracle (exact mismatch counts, summed over ranks)
+  popsift_mode : the end-to-end leg with setMode(PopSift) (the Config rounds 1-3 quoted as `value`)
+  caller_profile : the end-to-end leg in the shape of the external caller SURVEY.md 8b names (AliceVision):
+                 PopSift(config, ExtractingMode, FloatImages), float frames (4 bytes / pixel over PCIe),
+                 setFilterMaxExtrema + LargestScaleFirst (one host counter read per frame), setNormalizationMultiplier(9),
+                 with its own pcie_gbs and parity_checked
   sustained    : the end-to-end leg kept running for >= 3 s / >= 8000 frames (N=1): Mpix/s per 256-frame window
                  (min / median / max), GPU clock before and after
   sparse_frames: the end-to-end leg on a second frame set with ~2 keypoints / 1000 px (the default set has ~7)
@@ -44,7 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-BATCH = 64         # frames per step per rank: one pass over the NDISTINCT distinct frames (20 driver steps = 1280 timed frames)
+BATCH = 320        # frames per step per rank: five passes over the NDISTINCT distinct frames (20 driver steps = 6400 timed frames, > 2 s)
 NBASE = 16         # synthetic base frames per rank; the other distinct frames are shifted / flipped variants of them
 NDISTINCT = 64     # distinct frames per rank that the steps cycle through
 NCTX = int(os.environ.get("POPSIFT_BENCH_CTX", "16"))       # C-ABI legs: extraction contexts in flight per GPU
@@ -52,7 +58,23 @@ MAX_OUT = int(os.environ.get("POPSIFT_BENCH_OUTSTANDING", "24"))   # end-to-end 
 HBM_PEAK_GBS = 8000.0
 SUSTAINED_S = float(os.environ.get("POPSIFT_BENCH_SUSTAINED_S", "3.0"))
 SUSTAINED_FRAMES = int(os.environ.get("POPSIFT_BENCH_SUSTAINED_FRAMES", "8000"))
-WINDOW = 4 * BATCH                                           # frames per sustained-leg window (256)
+WINDOW = 256                                                 # frames per sustained-leg window
+SUB = 64                                                     # the sustained leg advances in sub-steps of SUB frames
+
+# Config profiles of the end-to-end legs (keyword overrides of capi.default_config)
+HEADLINE_KW = dict(octaves=5, sift_mode=2)                   # BASELINE config 1's Config: setOctaves(5), setMode(VLFeat)
+POPSIFT_KW = dict(octaves=5)                                 # setMode(PopSift), the default: rounds 1-3 quoted this one
+# the external caller of SURVEY.md 8b (AliceVision's popSIFT describer): FloatImages, grid filter with
+# LargestScaleFirst, descriptors scaled by 2^9
+CALLER_KW = dict(octaves=5, filter_max_extrema=10000, grid_filter_mode=1, norm_multi=9)
+PROFILES = {"headline": (HEADLINE_KW, False), "popsift": (POPSIFT_KW, False), "caller": (CALLER_KW, True)}
+SIFT_MODE_NAMES = {0: "PopSift", 1: "OpenCV", 2: "VLFeat"}
+
+
+def caller_frames(frames_u8):
+    """Float frames in [0, 1) as PopSift::FloatImages expects (popsift.h:68-73): v / 256 of the u8 frames."""
+    import numpy as np
+    return [(f.astype(np.float32) / np.float32(256.0)).astype(np.float32) for f in frames_u8]
 
 
 def octave_pixels(w, h, octaves, up=1):
@@ -146,8 +168,10 @@ class GpuBackend:
         self.dev = torch.device("cuda", local_rank)
         self.frames_dense = make_frames(rank, world, synth)
         self.frames_sparse = make_frames(rank, world, synth, sparse=True)
+        self.frames_float = None
         self.frames_np = self.frames_dense
-        self.cfg = capi.default_config(octaves=5)
+        self.cfg = capi.default_config(**HEADLINE_KW)
+        self.profile = "headline"
         self.ps = None
         self.ctxs = []
         self.desc_total = 0
@@ -159,8 +183,13 @@ class GpuBackend:
         return self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
 
     # ---- leg 1: the public C++ API, host frames in, FeaturesHost out ----
-    def e2e_open(self):
-        self.ps = self.capi.PopSift(self.cfg, device=self.device)
+    def e2e_open(self, profile="headline"):
+        kw, is_float = PROFILES[profile]
+        self.profile = profile
+        if is_float and self.frames_float is None:
+            self.frames_float = caller_frames(self.frames_dense)
+        self.frames_np = self.frames_float if is_float else self.frames_dense
+        self.ps = self.capi.PopSift(self.capi.default_config(**kw), device=self.device, float_images=is_float)
 
     def e2e_enqueue(self, i):
         return self.ps.enqueue(self.frames_np[i % NDISTINCT])      # PopSift::enqueue (deep copy of the image)
@@ -178,23 +207,22 @@ class GpuBackend:
         """Outside the timed region: the given timed frames once more through the SAME PopSift object, full results
         matched against the oracle (the checker; nothing here is timed or shipped)."""
         from oracle import pyoracle as po
-        from tests.parity import budget, match_features
-        ocfg = po.default_config(octaves=5)
+        from tests.parity import match_features
+        kw = PROFILES[self.profile][0]
+        ocfg = po.default_config(**kw)
+        scale = float(2 ** kw.get("norm_multi", 0))
         tot = {"frames": 0, "keypoints": 0, "descriptors": 0, "kp_miss": 0, "ori_miss": 0, "desc_miss": 0, "max_desc_dist": 0.0}
         jobs = [(i, self.ps.enqueue(self.frames_np[i % NDISTINCT])) for i in indices]
         for i, job in jobs:
             fb, db = self.ps.get(job)
             ref = po.run(ocfg, self.frames_np[i % NDISTINCT])
             fa, da = ref.features(), ref.descriptors()
-            m = match_features(fa, da, fb, db)
+            m = match_features(fa, da, fb, db, norm_scale=scale)
             tot["frames"] += 1; tot["keypoints"] += len(fa); tot["descriptors"] += len(da)
             tot["kp_miss"] += m["kp_miss"] + abs(len(fa) - len(fb)); tot["ori_miss"] += m["ori_miss"]; tot["desc_miss"] += m["desc_miss"]
             tot["max_desc_dist"] = round(max(tot["max_desc_dist"], m["max_desc_dist"]), 6)
             ref.close()
-        b = budget(tot["keypoints"])
-        tot["within_budget"] = bool(tot["kp_miss"] <= b["kp"] and tot["ori_miss"] <= b["ori"] and tot["desc_miss"] <= b["desc"])
         tot["frame_indices"] = list(indices)
-        tot["what"] = "timed frames re-run through the same PopSift object after the timed region, matched against oracle/ (tolerances 1e-3, budget 0 keypoints, 1 + n/10000 orientations / descriptors)"
         return tot
 
     def e2e_close(self):
@@ -204,7 +232,7 @@ class GpuBackend:
     # ---- legs 2, 3: C-ABI, inputs already resident in HBM ----
     def abi_open(self):
         torch, capi = self.torch, self.capi
-        self.frames = [torch.from_numpy(f).to(self.dev) for f in self.frames_np[:BATCH]]
+        self.frames = [torch.from_numpy(f).to(self.dev) for f in self.frames_dense[:NDISTINCT]]
         torch.cuda.synchronize()
         self.ctxs = [capi.Context(self.cfg, device=self.device) for _ in range(NCTX)]
         cap_f, cap_d = 100000, 200000
@@ -266,29 +294,46 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
         dist.all_reduce(kk, op=dist.ReduceOp.SUM)
         return float(tt.item()), float(kk.item())
 
-    def timed(step, drain):
+    def timed(step, drain, probe=None):
         """W untimed steps, then exactly K steps bracketed by barrier + synchronize; every frame of the K steps
-        is complete (and collected) inside the timed region."""
+        is complete (and collected) inside the timed region.  probe(): a counter sampled at both ends of the timed
+        region (the warm-up is excluded); its difference is returned as the third value."""
         for _ in range(args.warmup):
             step()
         drain()
         barrier()
+        p0 = probe() if probe else 0
         t0 = time.perf_counter()
         kps = 0
         for _ in range(args.steps):
             kps += step()
         kps += drain()
         barrier()
-        return reduce_max_sum(time.perf_counter() - t0, kps)
+        dt, kk = reduce_max_sum(time.perf_counter() - t0, kps)
+        return dt, kk, (probe() - p0 if probe else 0)
 
-    # ---- leg 1 (headline): the public C++ API, host frames in, FeaturesHost out ----
-    be.e2e_open()
+    def reduce_sum_dict(d, keys):
+        """sum the given integer fields over ranks (parity counts of every rank)"""
+        if dist is None:
+            return d
+        for k in keys:
+            t = be.reduce_tensor(float(d[k]))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            d[k] = int(round(float(t.item())))
+        t = be.reduce_tensor(float(d["max_desc_dist"]))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d["max_desc_dist"] = round(float(t.item()), 6)
+        return d
+
+    # frames per step of THIS rank: weak scaling = BATCH each; --strong = BASELINE config 4's literal shape, BATCH
+    # frames per step in total (frame i -> GPU i mod N)
+    per_rank = BATCH if not args.strong else max(1, BATCH // world)
     jobs = deque()
     e2e = {"i": 0}
 
-    def e2e_step():
+    def e2e_step(n=None):
         kp = 0
-        for _ in range(BATCH):
+        for _ in range(per_rank if n is None else n):
             if len(jobs) >= MAX_OUT:
                 kp += be.e2e_get(jobs.popleft())
             jobs.append(be.e2e_enqueue(e2e["i"]))
@@ -301,21 +346,38 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
             kp += be.e2e_get(jobs.popleft())
         return kp
 
-    desc0 = getattr(be, "desc_total", 0)
-    dt_e2e, kps_e2e = timed(e2e_step, e2e_drain)
-    descs_e2e = getattr(be, "desc_total", 0) - desc0
+    desc_probe = (lambda: be.desc_total) if hasattr(be, "desc_total") else None
+    parity_idx = [0, NDISTINCT // 4 + 1, NDISTINCT // 2 + 2, 3 * NDISTINCT // 4 + 3]
+
+    def parity_all_ranks():
+        """every rank re-runs 4 of ITS timed frames through its own PopSift object and checks them against the oracle;
+        the counts are summed over ranks"""
+        from tests.parity import budget
+        d = be.e2e_parity(parity_idx)
+        d = reduce_sum_dict(d, ["frames", "keypoints", "descriptors", "kp_miss", "ori_miss", "desc_miss"])
+        b = budget(d["keypoints"])
+        d["within_budget"] = bool(d["kp_miss"] <= b["kp"] and d["ori_miss"] <= b["ori"] and d["desc_miss"] <= b["desc"])
+        d["ranks_checked"] = world
+        d["what"] = ("4 timed frames of every rank re-run through the same PopSift object after the timed region, matched "
+                     "against oracle/ (tolerances 1e-3, budget 0 keypoints, 1 + n/10000 orientations / descriptors)")
+        return d
+
+    # ---- leg 1 (headline): the public C++ API, host frames in, FeaturesHost out; config 1's Config (VLFeat mode) ----
+    be.e2e_open("headline")
+    dt_e2e, kps_e2e, descs_e2e = timed(e2e_step, e2e_drain, desc_probe)
 
     # ---- outside the timed region, same PopSift object: parity of timed frames, sustained run, sparse frame set ----
-    parity = sustained = sparse = None
-    if hasattr(be, "e2e_parity") and not args.no_extras:
-        if rank == 0 and not args.no_parity:
-            parity = be.e2e_parity([0, NDISTINCT // 4 + 1, NDISTINCT // 2 + 2, 3 * NDISTINCT // 4 + 3])
+    parity = sustained = sparse = popsift_leg = caller_leg = None
+    extra_legs = hasattr(be, "e2e_parity") and not args.no_extras
+    if extra_legs:
+        if not args.no_parity:
+            parity = parity_all_ranks()
         if world == 1 and SUSTAINED_S > 0:
             wins, clk, n_s, kp_s = [], [], 0, 0
             t_s0 = tw = time.perf_counter()
             while n_s < SUSTAINED_FRAMES or time.perf_counter() - t_s0 < SUSTAINED_S:
-                kp_s += e2e_step()
-                n_s += BATCH
+                kp_s += e2e_step(SUB)
+                n_s += SUB
                 if n_s % WINDOW == 0:
                     now = time.perf_counter()
                     wins.append(WINDOW * W * H / (now - tw) / 1e6)
@@ -335,16 +397,43 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
                          "sclk_mhz_first": clk[0] if clk else None, "sclk_mhz_last": clk[-1] if clk else None,
                          "sclk_mhz_min": min(clk) if clk else None, "sclk_mhz_max": max(clk) if clk else None,
                          "keypoints_per_s": round(kp_s / dt_s, 1)}
+        n_leg = world * per_rank * args.steps
         be.e2e_select("sparse")
         e2e["i"] = 0
-        dt_sp, kps_sp = timed(e2e_step, e2e_drain)
+        dt_sp, kps_sp, _ = timed(e2e_step, e2e_drain)
         be.e2e_select("dense")
-        sparse = {"value": round(world * BATCH * args.steps * W * H / dt_sp / 1e6, 1), "unit": "Mpix/s",
-                  "keypoints_per_frame": round(kps_sp / (world * BATCH * args.steps), 1),
-                  "keypoints_per_1000px": round(kps_sp / (world * BATCH * args.steps) / (W * H / 1000.0), 2),
+        sparse = {"value": round(n_leg * W * H / dt_sp / 1e6, 1), "unit": "Mpix/s",
+                  "keypoints_per_frame": round(kps_sp / n_leg, 1),
+                  "keypoints_per_1000px": round(kps_sp / n_leg / (W * H / 1000.0), 2),
                   "keypoints_per_s": round(kps_sp / dt_sp, 1),
                   "what": "the end-to-end leg on frames with ~2 keypoints / 1000 px (popsift_amd/synth.py sparse=True)"}
     be.e2e_close()
+
+    if extra_legs:
+        # ---- the same leg with setMode(PopSift): the Config rounds 1-3 quoted as `value` ----
+        be.e2e_open("popsift")
+        e2e["i"] = 0
+        dt_pm, kps_pm, _ = timed(e2e_step, e2e_drain)
+        be.e2e_close()
+        popsift_leg = {"value": round(n_leg * W * H / dt_pm / 1e6, 1), "unit": "Mpix/s",
+                       "keypoints_per_frame": round(kps_pm / n_leg, 1), "keypoints_per_s": round(kps_pm / dt_pm, 1),
+                       "what": "the end-to-end leg with setMode(PopSift) (rounds 1-3 quoted this Config as `value`)"}
+        # ---- the external caller's profile: FloatImages + grid filter (LargestScaleFirst) + 2^9 descriptors ----
+        be.e2e_open("caller")
+        e2e["i"] = 0
+        dt_cp, kps_cp, descs_cp = timed(e2e_step, e2e_drain, desc_probe)
+        caller_leg = {"value": round(n_leg * W * H / dt_cp / 1e6, 1), "unit": "Mpix/s",
+                      "config": "PopSift(config, ExtractingMode, FloatImages), octaves=5, setFilterMaxExtrema(%d), "
+                                "setFilterSorting(LargestScaleFirst), setNormalizationMultiplier(%d), float32 frames in [0,1)"
+                                % (CALLER_KW["filter_max_extrema"], CALLER_KW["norm_multi"]),
+                      "jobs_outstanding_per_gpu": MAX_OUT,
+                      "keypoints_per_frame": round(kps_cp / n_leg, 1), "keypoints_per_s": round(kps_cp / dt_cp, 1),
+                      "pcie_gbs": {"h2d": round(n_leg * W * H * 4 / dt_cp / 1e9, 2),
+                                   "d2h": round((kps_cp * 52 + descs_cp * 512 * (world if world > 1 else 1)) / dt_cp / 1e9, 2)},
+                      "parity_checked": None if args.no_parity else parity_all_ranks(),
+                      "what": "the end-to-end leg as the external caller of SURVEY.md 8b drives it: 4 bytes / pixel over PCIe, "
+                              "the grid filter's host-side counter read once per frame (stalls one worker, not the pipe)"}
+        be.e2e_close()
 
     # ---- legs 2 and 3: C-ABI, inputs already resident in HBM ----
     be.abi_open()
@@ -353,12 +442,12 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
 
     def abi_step():
         kp = 0
-        for i in range(BATCH):
+        for i in range(per_rank):
             if len(inflight) == NCTX:
                 kp += be.abi_collect(inflight.popleft())
             c = state["next"]
             state["next"] = (c + 1) % NCTX
-            be.abi_submit(c, i)
+            be.abi_submit(c, i % NDISTINCT)
             inflight.append(c)
         return kp
 
@@ -369,35 +458,40 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
         return kp
 
     be.abi_export(False)
-    dt_dev, kps_dev = timed(abi_step, abi_drain)
+    dt_dev, kps_dev, _ = timed(abi_step, abi_drain)
     be.abi_export(True)
-    dt_x, _ = timed(abi_step, abi_drain)
+    dt_x, _, _ = timed(abi_step, abi_drain)
     be.abi_export(False)
 
-    n_frames = world * BATCH * args.steps
+    n_frames = world * per_rank * args.steps
     rate = lambda dt: round(n_frames * W * H / dt / 1e6, 1)
 
     result = None
     if rank == 0:
+        mode_name = SIFT_MODE_NAMES[HEADLINE_KW.get("sift_mode", 0)]
         result = {
             "metric": "Mpixels/sec end-to-end SIFT (5 oct, 3 lvl/oct) + keypoints/sec",
             "value": rate(dt_e2e), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt_e2e / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "1920x1080 u8 host frames (%d distinct per GPU) -> PopSift::enqueue -> SiftJob::get -> "
+            "config": {"workload": "BASELINE config 2: 1920x1080 u8 host frames (%d distinct per GPU) -> PopSift::enqueue -> SiftJob::get -> "
                                    "FeaturesHost (C++ API of libpopsift.so, upload and result delivery inside the timed "
-                                   "region); default Config, octaves=5, levels=3, upscale x2 (octave 0 = 3840x2160), full "
-                                   "pipe (pyramid, extrema, orientation, descriptors)" % NDISTINCT,
-                       "frames_per_step_per_gpu": BATCH, "frames_timed": n_frames,
+                                   "region); config 1's Config: setOctaves(5), levels=3, setMode(%s), ByteImages, grid filter off, "
+                                   "RootSift x1, upscale x2 (octave 0 = 3840x2160), full pipe (pyramid, extrema, orientation, "
+                                   "descriptors)" % (NDISTINCT, mode_name),
+                       "sift_mode": mode_name, "input": "u8 (ByteImages)", "grid_filter": "off",
+                       "frames_per_step_per_gpu": per_rank, "frames_timed": n_frames,
                        "jobs_outstanding_per_gpu": MAX_OUT,
                        "pipe_depth": os.environ.get("POPSIFT_PIPE_DEPTH", "clamp(usable cores / local replicas, 4, 8)"),
-                       "parallelism": "replicas x%d (frame i -> GPU i mod N, no collective)" % world},
+                       "parallelism": "replicas x%d (frame i -> GPU i mod N, no collective)%s" % (
+                           world, "; --strong: %d frames per step in total (BASELINE config 4's shape)" % (per_rank * world) if args.strong else "")},
             "keypoints_per_s": round(kps_e2e / dt_e2e, 1),
             "keypoints_per_frame": round(kps_e2e / n_frames, 1),
-            "ms_per_frame": round(dt_e2e / (BATCH * args.steps) * 1e3, 4),
+            "ms_per_frame": round(dt_e2e / (per_rank * args.steps) * 1e3, 4),
             "keypoints_per_1000px": round(kps_e2e / n_frames / (W * H / 1000.0), 2),
             "parity_checked": parity, "sustained": sustained, "sparse_frames": sparse,
+            "popsift_mode": popsift_leg, "caller_profile": caller_leg,
             "device_resident": {"value": rate(dt_dev), "unit": "Mpix/s", "ms_per_step": round(dt_dev / args.steps * 1e3, 4),
                                 "keypoints_per_s": round(kps_dev / dt_dev, 1), "contexts_per_gpu": NCTX,
                                 "what": "C-ABI psx_extract, inputs and results resident in HBM (no PCIe in the timed region)"},
@@ -405,11 +499,12 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
                             "what": "C-ABI, inputs resident in HBM, Feature records + descriptors streamed into pinned host memory"},
         }
         if hasattr(be, "desc_total"):
-            # PCIe inside the timed region of `value`: the u8 frame up, 52-byte records + 512-byte descriptors down
+            # PCIe inside the timed region of `value` (warm-up excluded): the u8 frame up, 52-byte records + 512-byte
+            # descriptors down
             h2d = n_frames * W * H
             d2h = kps_e2e * 52 + descs_e2e * 512 * (world if world > 1 else 1)
             result["pcie_gbs"] = {"h2d": round(h2d / dt_e2e / 1e9, 2), "d2h": round(d2h / dt_e2e / 1e9, 2),
-                                  "what": "host<->device bytes of the end-to-end leg / its time (all GPUs; D2H from rank 0's descriptor count)"}
+                                  "what": "host<->device bytes of the end-to-end leg's timed steps / its time (all GPUs; D2H from rank 0's descriptor count)"}
         stage_b, pipe_b = algorithmic_bytes(W, H, 5)
         result["pipe_roofline"] = {
             "algorithmic_bytes_per_frame": pipe_b, "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -431,8 +526,10 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE config 4's literal shape: BATCH frames per step in TOTAL (BATCH / N per GPU) instead of per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of 4 timed frames")
     ap.add_argument("--no-extras", action="store_true", help="only the three timed legs")
@@ -522,7 +619,7 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
                          ("gauss_fixed15", dict(gauss_mode=5)), ("scale_direct", dict(scaling_mode=0)),
                          ("desc_iloop", dict(desc_mode=1)), ("desc_grid", dict(desc_mode=2)),
                          ("desc_igrid", dict(desc_mode=3)), ("desc_notile", dict(desc_mode=4))):
-            ca = capi.Context(capi.default_config(octaves=5, **kw), device=device)
+            ca = capi.Context(capi.default_config(**dict(HEADLINE_KW, **kw)), device=device)
             ca.set_input_tensor(frames[0])
             ts = []
             for i in range(7):
@@ -541,7 +638,7 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
     try:
         from popsift_amd.synth import synth
         big = torch.from_numpy(np.ascontiguousarray(np.tile(frames_np[0], (4, 3))[:4096, :4096])).to(frames[0].device)
-        c3 = capi.Context(capi.default_config(octaves=6), device=device)
+        c3 = capi.Context(capi.default_config(octaves=6, sift_mode=HEADLINE_KW.get("sift_mode", 0)), device=device)
         c3.set_input_tensor(big)
         for _ in range(3):
             c3.extract()
@@ -576,17 +673,25 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
     # ---- CPU baseline (bounded sample) ----
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as po
-        ocfg = po.default_config(octaves=5)
+        ocfg = po.default_config(**HEADLINE_KW)
         ncores = usable_cores()
         po.run(ocfg, frames_np[0], threads=ncores).close()     # warm
         n_s = 0
         t1 = time.perf_counter()
-        while n_s < NBASE and (n_s < 2 or time.perf_counter() - t1 < 12.0):
+        while n_s < NBASE and (n_s < 2 or time.perf_counter() - t1 < 8.0):
             po.run(ocfg, frames_np[n_s], threads=ncores).close()
             n_s += 1
         cdt = time.perf_counter() - t1
-        cpu = {"value": round(n_s * W * H / cdt / 1e6, 2), "unit": "Mpix/s", "cores": ncores,
-               "kind": "port", "sample": "%d frames 1920x1080, oracle/liboracle.so with OpenMP" % n_s}
+        strict = round(n_s * W * H / cdt / 1e6, 2)
+        # the oracle built -O3 -march=native (contraction allowed) ON THIS HOST is the CPU
+        # baseline; the strict IEEE build (-O2 -ffp-contract=off, the parity checker) is stated beside it
+        fdt = po.time_fast_build(ocfg, frames_np[:n_s], ncores)
+        fast = round(n_s * W * H / fdt / 1e6, 2) if fdt else None
+        cpu = {"value": fast if fast else strict, "unit": "Mpix/s", "cores": ncores, "kind": "port",
+               "build": "-O3 -march=native -ffp-contract=fast -fopenmp (oracle/_fast, built on this host)" if fast
+                        else "-O2 -ffp-contract=off -fopenmp (the checker build; the tuned build failed here)",
+               "strict_checker_build": {"value": strict, "unit": "Mpix/s", "build": "-O2 -mavx2 -ffp-contract=off -fopenmp (oracle/liboracle.so)"},
+               "sample": "%d frames 1920x1080 (config 1's Config, VLFeat mode), OpenMP over %d threads" % (n_s, ncores)}
         try:
             import cv2
             cv2.setNumThreads(ncores)

@@ -43,6 +43,11 @@ const float* popsift_c_descriptors(const popsift_c_features* f);
 void popsift_c_free(popsift_c_features* f);
 /* message of the last failure on the calling thread */
 const char* popsift_c_last_error(void);
+/* Diagnostics (no reference counterpart): counters of the library's pinned result / job-image pool of one device
+ * (device < 0: all pools summed): out[0] = buffers ever allocated (hipHostMalloc), out[1] = buffers really freed
+ * (hipHostFree), out[2] = requests served from the free list, out[3] = buffers on the free list, out[4] = bytes on the
+ * free list, out[5] = bytes handed out.  A steady stream of frames must not move out[0] / out[1] after warm-up. */
+void popsift_c_pool_stats(int device, long long out[6]);
 
 #ifdef __cplusplus
 }

@@ -133,6 +133,12 @@ float psx_peak_threshold(const psx_config* cfg);
  * Error cases of gauss_filter.cu:131-144 (sigma > 2, too many levels) return PSX_ERR_INVALID. */
 int psx_gauss_tables(const psx_config* cfg, float* inc_filter, int* inc_span, float* inc_sigma,
                      float* dd_filter, int* dd_span, float* dd_sigma);
+/* Config::setPrintGaussTables / --print-gauss-tables: prints to stdout what the reference's init_filter prints
+ * (gauss_filter.cu:146-161) and what print_gauss_filter_symbol<<<1,1>>>(columns) prints from the device copy of the
+ * tables (gauss_filter.cu:24-120, 247-256; the reference passes columns = 10): the inc, interpolated inc, abs_o0,
+ * abs_oN and dd tables, same layout and number formats, computed on the host. */
+int psx_print_gauss_tables(const psx_config* cfg, int columns);
+
 
 /* ---- context -------------------------------------------------------------------------- */
 

@@ -120,6 +120,30 @@ def lib():
     return _LIB
 
 
+def time_fast_build(cfg, imgs, threads):
+    """bench.py's cpu_baseline only: the same source built -O3 -march=native -ffp-contract=fast on THIS host
+    (oracle/_fast/liboracle_fast.so, `make fast`; not the checker -- the strict build above stays the checker) and
+    timed over imgs.  Returns seconds, or None when the build is not possible here."""
+    import time
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "fast"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        F = C.CDLL(os.path.join(_HERE, "_fast", "liboracle_fast.so"))
+    except Exception:
+        return None
+    F.osift_run.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int, C.c_int, C.c_int]
+    F.osift_run.restype = C.c_void_p
+    F.osift_free.argtypes = [C.c_void_p]
+    F.osift_set_threads.argtypes = [C.c_int]
+    F.osift_set_threads(threads)
+    prepared = [_img_args(i) for i in imgs]
+    im, w, h, fl = prepared[0]
+    F.osift_free(F.osift_run(C.byref(cfg), im.ctypes.data_as(C.c_void_p), w, h, fl))       # warm
+    t0 = time.perf_counter()
+    for im, w, h, fl in prepared:
+        F.osift_free(F.osift_run(C.byref(cfg), im.ctypes.data_as(C.c_void_p), w, h, fl))
+    return time.perf_counter() - t0
+
+
 def default_config(**kw):
     c = Config()
     lib().osift_config_default(C.byref(c))

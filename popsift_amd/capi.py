@@ -62,6 +62,7 @@ SYMBOLS = [
     "psx_set_wait_mode", "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
     "psx_host_alloc", "psx_host_free", "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_dev_write", "psx_clone_results", "psx_match", "psx_match_release", "psx_device_count", "psx_device_info", "psx_device_pci",
     "psx_enable_blur_probe", "psx_blur_probe_times", "psx_copy_bench", "psx_upload_pinned", "psx_attach_export_mapped",
+    "psx_print_gauss_tables",
 ]
 
 _LIB = None
@@ -403,7 +404,7 @@ def copy_bench(device=0, nbytes=0, reps=10):
 HOST_LIB_PATH = os.environ.get("POPSIFT_HOST_LIB") or os.path.join(_HERE, "lib", "libpopsift.so")
 HOST_SYMBOLS = ["popsift_c_create", "popsift_c_destroy", "popsift_c_enqueue_u8", "popsift_c_enqueue_f32",
                 "popsift_c_get", "popsift_c_feature_count", "popsift_c_descriptor_count", "popsift_c_copy",
-                "popsift_c_descriptors", "popsift_c_free", "popsift_c_last_error"]
+                "popsift_c_descriptors", "popsift_c_free", "popsift_c_last_error", "popsift_c_pool_stats"]
 _HOST = None
 
 
@@ -432,8 +433,17 @@ def host_lib():
         H.popsift_c_free.argtypes = [vp]
         H.popsift_c_free.restype = None
         H.popsift_c_last_error.restype = C.c_char_p
+        H.popsift_c_pool_stats.argtypes = [C.c_int, C.POINTER(C.c_longlong)]
+        H.popsift_c_pool_stats.restype = None
         _HOST = H
     return _HOST
+
+
+def pool_stats(device=-1):
+    """Counters of libpopsift's pinned pool (popsift_c_pool_stats): dict(allocs, frees, hits, free_buffers, free_bytes, in_use)."""
+    out = (C.c_longlong * 6)()
+    host_lib().popsift_c_pool_stats(device, out)
+    return dict(zip(("allocs", "frees", "hits", "free_buffers", "free_bytes", "in_use"), [int(v) for v in out]))
 
 
 class PopSift:

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 
@@ -235,7 +236,7 @@ int compute_tables(const psx_config* cfg, float* inc_filter, int* inc_span, floa
 }
 
 // abs_o0, abs_oN and the interpolated (ratio, multiplier) form of the inc table
-void compute_alt_tables(psx_ctx* n)
+void compute_alt_tables(psx_ctx* n, float* abs0_sigma = nullptr, float* absN_sigma = nullptr)
 {
     const psx_config& c = n->cfg;
     const float sigma0 = c.sigma;
@@ -249,6 +250,8 @@ void compute_alt_tables(psx_ctx* n)
     }
     blur_table(c.gauss_mode, PSX_GAUSS_LEVELS, s0, n->abs0_span, n->abs0_filter);
     blur_table(c.gauss_mode, PSX_GAUSS_LEVELS, sN, n->absN_span, n->absN_filter);
+    if (abs0_sigma) memcpy(abs0_sigma, s0, sizeof(s0));
+    if (absN_sigma) memcpy(absN_sigma, sN, sizeof(sN));
     for (int level = 0; level < PSX_GAUSS_LEVELS; level++) {       // GaussTable::transformBlurTable
         int isp = n->inc_span[level];
         if (!(isp & 1)) isp += 1;
@@ -321,6 +324,55 @@ int psx_gauss_tables(const psx_config* cfg, float* inc_filter, int* inc_span, fl
     if (!cfg || !inc_filter || !inc_span || !inc_sigma || !dd_filter || !dd_span || !dd_sigma)
         return PSX_ERR_INVALID;
     return compute_tables(cfg, inc_filter, inc_span, inc_sigma, dd_filter, dd_span, dd_sigma, nullptr);
+}
+
+// Config::setPrintGaussTables: what init_filter prints (gauss_filter.cu:146-161) and what its device-side
+// print_gauss_filter_symbol<<<1,1>>>(10) prints (gauss_filter.cu:24-120), from the host tables.
+int psx_print_gauss_tables(const psx_config* cfg, int columns)
+{
+    if (!cfg) return PSX_ERR_INVALID;
+    std::unique_ptr<psx_ctx> n(new psx_ctx);
+    n->cfg = *cfg;
+    const int rc = compute_tables(cfg, n->inc_filter, n->inc_span, n->inc_sigma, n->dd_filter, n->dd_span, n->dd_sigma, nullptr);
+    if (rc != PSX_OK) return rc;
+    float s0[PSX_GAUSS_LEVELS], sN[PSX_GAUSS_LEVELS];
+    compute_alt_tables(n.get(), s0, sN);
+    printf("\n"
+           "Upscaling factor: %f (i.e. original image is scaled by a factor of %f)\n"
+           "\n"
+           "Sigma computations\n"
+           "    Initial sigma is %f\n"
+           "    Input blurriness is assumed to be %f (scaled to %f)\n",
+           cfg->upscale_factor, pow(2.0f, cfg->upscale_factor), cfg->sigma, cfg->initial_blur,
+           cfg->initial_blur * pow(2.0f, cfg->upscale_factor));
+    const int stages = cfg->levels + 3;
+    auto table = [&](int rows, const int* span, const float* sigma, const float* filter, bool split_sigma) {
+        for (int lvl = 0; lvl < rows; lvl++) {
+            if (split_sigma) { printf("      %d %d ", lvl, span[lvl] + span[lvl] - 1); printf("%2.6f: ", sigma[lvl]); }
+            else             printf("      %d %d %2.6f: ", lvl, span[lvl] + span[lvl] - 1, sigma[lvl]);
+            const int m = span[lvl] < columns ? span[lvl] : columns;
+            for (int x = 0; x < m; x++) printf("%0.8f ", filter[lvl * PSX_GAUSS_ALIGN + x]);
+            printf(m < span[lvl] ? "...\n" : "\n");
+        }
+    };
+    printf("\nGauss tables\n      level span sigma : center value -> edge value\n    relative sigma\n");
+    table(stages, n->inc_span, n->inc_sigma, n->inc_filter, true);
+    printf("\n");
+    printf("\nGauss tables for hardware interpolation\n"
+           "      level span sigma : center value -> ( interpolation value, multiplier ) [one edge value] \n");
+    table(stages, n->inc_ispan, n->inc_sigma, n->inc_ifilter, true);
+    printf("\n");
+    printf("\nGauss tables\n      level span sigma : center value -> edge value\n"
+           "      absolute filters octave 0 (compute level 0, all other levels directly from level 0)\n");
+    table(stages, n->abs0_span, s0, n->abs0_filter, false);
+    printf("\n      absolute filters other octaves\n      (level 0 via downscaling, all other levels directly from level 0)\n");
+    table(stages, n->absN_span, sN, n->absN_filter, false);
+    printf("\n");
+    printf("    level 0-filters for direct downscaling\n");
+    table(PSX_MAX_OCTAVES, n->dd_span, n->dd_sigma, n->dd_filter, false);
+    printf("\n");
+    fflush(stdout);
+    return PSX_OK;
 }
 
 const char* psx_last_error(const psx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }

@@ -133,10 +133,13 @@ struct MatchScratch {
     void release()
     {
         if (device < 0) return;
+        int cur = -1;                                        // the caller's current device is left as it was
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
         (void)hipSetDevice(device);
         for (int i = 0; i < 4; i++) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr; device = -1;
+        if (cur >= 0) (void)hipSetDevice(cur);
     }
     bool need(int i, size_t bytes)
     {
@@ -153,7 +156,8 @@ struct MatchScratch {
 thread_local MatchScratch t_scratch;
 } // namespace
 
-// frees the calling thread's matcher scratch (stream + up to 4 device buffers); PopSift::uninit calls it
+// frees the calling thread's matcher scratch (stream + up to 4 device buffers); an explicit user call -- PopSift::uninit
+// does NOT call it: the scratch belongs to the thread, not to one PopSift object (another replica may be using it)
 extern "C" int psx_match_release(void)
 {
     t_scratch.release();

@@ -1111,8 +1111,11 @@ template <int R>
 hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
 {
     if constexpr (R <= 8) {
-        // the default x2 upsampling: W = 2w, H = 2h exactly
-        if (level0_fused_enabled() && h.W == 2 * h.w && h.H == 2 * h.h && h.w >= 4) {
+        // the default x2 upsampling: W = 2w, H = 2h exactly, with the sampling shift of a SiftMode (1.0 PopSift / VLFeat,
+        // 0.5 OpenCV).  The kernel's staging assumes what holds for exactly these: the 8 texel columns of 4 adjacent
+        // outputs lie within 4 consecutive texels and a 32-row step touches at most NTX texel rows (checked for both
+        // shifts incl. the al = 1 knife edge); any other shift or scale keeps k_upscale, which tests the condition itself
+        if (level0_fused_enabled() && h.W == 2 * h.w && h.H == 2 * h.h && h.w >= 4 && (h.shift == 1.0f || h.shift == 0.5f)) {
             L0Args f;
             f.img = h.img; f.w = h.w; f.h = h.h; f.dst = h.dst; f.W = h.W; f.H = h.H; f.pitch = h.pitch; f.shift = h.shift;
             f.nstrips = (h.W + TW - 1) / TW;

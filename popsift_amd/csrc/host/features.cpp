@@ -11,6 +11,13 @@
 #include <algorithm>
 #include <cerrno>
 #include <mutex>
+#include <thread>
+#include <string>
+#include <unordered_map>
+#include <cstring>
+#include <cctype>
+#include <cstdint>
+#include <sched.h>
 #include <utility>
 #include <vector>
 #include <cmath>
@@ -45,13 +52,79 @@ FeaturesBase::~FeaturesBase( ) = default;
 // ---- buffer pools (host_pool.h) -------------------------------------------------------------------
 namespace pool {
 namespace {
+const int MAX_POOLS = 33;                       // devices 0..31, and one pool for "no device named"
+
+// pinned bytes a pool may keep on its free list (POPSIFT_POOL_FREE_MB, default 2048): the list is bounded by BYTES,
+// sized for `jobs outstanding x (image + result)` of a replica with head-room, not by a buffer count -- a count of 32
+// made a replica with 24 jobs outstanding (~40 live buffers) hipHostFree / hipHostMalloc its surplus on every
+// drain / refill burst
+size_t free_limit()
+{
+    static const size_t lim = []{ const char* e = getenv( "POPSIFT_POOL_FREE_MB" ); return (size_t)( e ? atol( e ) : 2048 ) << 20; }();
+    return lim;
+}
+
+// CPUs local to the device's PCIe root, "" when unknown or when the host has a single NUMA node
+std::string local_cpulist( int device )
+{
+    if( device < 0 || access( "/sys/devices/system/node/node1", F_OK ) != 0 ) return "";
+    const char* e = getenv( "POPSIFT_NUMA_PIN" );
+    if( e != nullptr && e[0] == '0' ) return "";
+    char bus[64];
+    if( psx_device_pci( device, bus, sizeof(bus) ) != PSX_OK || bus[0] == 0 ) return "";
+    for( char* c = bus; *c; c++ ) *c = (char)tolower( *c );
+    FILE* f = fopen( ( std::string( "/sys/bus/pci/devices/" ) + bus + "/local_cpulist" ).c_str(), "r" );
+    if( f == nullptr ) return "";
+    char line[4096] = { 0 };
+    const bool got = fgets( line, sizeof(line), f ) != nullptr;
+    fclose( f );
+    return got ? std::string( line ) : std::string();
+}
+
+bool pin_to_cpulist( const std::string& list )
+{
+    cpu_set_t allowed, want;
+    if( list.empty() || sched_getaffinity( 0, sizeof(allowed), &allowed ) != 0 ) return false;
+    CPU_ZERO( &want );
+    int n = 0;
+    std::vector<char> buf( list.begin(), list.end() ); buf.push_back( 0 );
+    for( char* tok = strtok( buf.data(), ",\n" ); tok != nullptr; tok = strtok( nullptr, ",\n" ) ) {
+        int a = 0, b = 0;
+        const int k = sscanf( tok, "%d-%d", &a, &b );
+        if( k < 1 ) continue;
+        if( k == 1 ) b = a;
+        for( int c = a; c <= b && c < CPU_SETSIZE; c++ )
+            if( CPU_ISSET( c, &allowed ) ) { CPU_SET( c, &want ); n++; }
+    }
+    return n > 0 && sched_setaffinity( 0, sizeof(want), &want ) == 0;
+}
+
 struct Pool
 {
     std::mutex                            m;
     std::vector<std::pair<void*, size_t>> free_list;
-    bool                                  pinned;
+    const bool                            pinned;
+    const int                             device;          // -1: none
     size_t                                in_use = 0;      // bytes handed out
-    explicit Pool( bool p ) : pinned( p ) { }
+    size_t                                free_bytes = 0;  // bytes on the free list
+    Stats                                 st;
+    std::string                           cpus;            // CPUs of the device's NUMA node ("" = do not care)
+    std::once_flag                        cpus_once;
+    Pool( bool p, int d ) : pinned( p ), device( d ) { }
+
+    // hipHostMalloc places the pages on the NUMA node of the CALLING thread.  The caller of enqueue() runs anywhere,
+    // so on a multi-socket host a pool miss allocates from a short-lived helper thread bound to the CPUs of the
+    // device's PCIe root: socket-1 GPUs then DMA to socket-1 memory.  Only pool misses pay for it (warm-up).
+    void* alloc_pinned( size_t c )
+    {
+        std::call_once( cpus_once, [this]{ cpus = local_cpulist( device ); } );
+        void* p = nullptr;
+        if( cpus.empty() ) { if( psx_host_alloc( c, &p ) != PSX_OK ) return nullptr; return p; }
+        const std::string list = cpus;
+        std::thread t( [&p, c, &list]{ pin_to_cpulist( list ); if( psx_host_alloc( c, &p ) != PSX_OK ) p = nullptr; } );
+        t.join();
+        return p;
+    }
 
     void* get( size_t bytes, size_t* cap )
     {
@@ -64,18 +137,18 @@ struct Pool
                     ( best < 0 || free_list[i].second < free_list[best].second ) ) best = (int)i;
             if( best >= 0 ) {
                 void* p = free_list[best].first; *cap = free_list[best].second;
-                free_list.erase( free_list.begin() + best );
-                in_use += *cap;
+                free_list[best] = free_list.back(); free_list.pop_back();
+                in_use += *cap; free_bytes -= *cap; st.hits++;
                 return p;
             }
         }
         const size_t mb = (size_t)1 << 20;
         const size_t c = ( ( bytes + bytes / 4 + mb - 1 ) / mb ) * mb;       // 25 % slack, whole megabytes
         void* p = nullptr;
-        if( pinned ) { if( psx_host_alloc( c, &p ) != PSX_OK ) return nullptr; }
+        if( pinned ) { p = alloc_pinned( c ); if( p == nullptr ) return nullptr; }
         else         { if( posix_memalign( &p, 4096, c ) != 0 ) return nullptr; }
         *cap = c;
-        { std::lock_guard<std::mutex> g( m ); in_use += c; }
+        { std::lock_guard<std::mutex> g( m ); in_use += c; st.allocs++; }
         return p;
     }
     void put( void* p, size_t cap )
@@ -84,19 +157,69 @@ struct Pool
         {
             std::lock_guard<std::mutex> g( m );
             in_use -= std::min( in_use, cap );
-            if( free_list.size() < 32 ) { free_list.emplace_back( p, cap ); return; }
+            if( free_bytes + cap <= free_limit() ) { free_list.emplace_back( p, cap ); free_bytes += cap; return; }
+            st.frees++;
         }
-        if( pinned ) psx_host_free( p ); else free( p );
+        if( pinned ) psx_host_free( p ); else free( p );      // only beyond the byte bound: never in a steady stream
+    }
+    Stats stats()
+    {
+        std::lock_guard<std::mutex> g( m );
+        Stats s = st; s.free_bytes = free_bytes; s.in_use = in_use; s.free_buffers = (long)free_list.size();
+        return s;
     }
 };
-Pool& plain()  { static Pool* p = new Pool( false ); return *p; }     // never destroyed: objects may outlive main()
-Pool& pinned() { static Pool* p = new Pool( true );  return *p; }
+
+Pool& plain()  { static Pool* p = new Pool( false, -1 ); return *p; }     // never destroyed: objects may outlive main()
+// one pinned pool per device: replicas on different devices share neither a mutex nor buffers (a buffer allocated
+// next to GPU 0 is never handed to GPU 5)
+Pool& pinned( int device )
+{
+    static Pool** pools = []{ Pool** a = new Pool*[MAX_POOLS]; for( int i = 0; i < MAX_POOLS; i++ ) a[i] = new Pool( true, i < MAX_POOLS - 1 ? i : -1 ); return a; }();
+    return *pools[ ( device >= 0 && device < MAX_POOLS - 1 ) ? device : MAX_POOLS - 1 ];
+}
+
+// which pool a live pinned buffer belongs to: objects (SiftJob, FeaturesHost) outlive the thread that got the buffer and
+// do not carry a device; 16 shards, each a tiny critical section
+struct Registry
+{
+    std::mutex m[16];
+    std::unordered_map<void*, int> map[16];
+    static int shard( void* p ) { return (int)( ( (uintptr_t)p >> 12 ) & 15 ); }
+    void set( void* p, int dev ) { const int s = shard( p ); std::lock_guard<std::mutex> g( m[s] ); map[s][p] = dev; }
+    int  get( void* p )          { const int s = shard( p ); std::lock_guard<std::mutex> g( m[s] ); auto it = map[s].find( p ); return it == map[s].end() ? -1 : it->second; }
+};
+Registry& registry() { static Registry* r = new Registry; return *r; }
+thread_local int t_device = -1;
 } // namespace
+
+void  set_thread_device( int device )         { t_device = device; }
+int   thread_device( )                        { return t_device; }
 void* get_plain( size_t bytes, size_t* cap )  { return plain().get( bytes, cap ); }
 void  put_plain( void* p, size_t cap )        { plain().put( p, cap ); }
-void* get_pinned( size_t bytes, size_t* cap ) { return pinned().get( bytes, cap ); }
-void  put_pinned( void* p, size_t cap )       { pinned().put( p, cap ); }
-size_t pinned_in_use( )                       { std::lock_guard<std::mutex> g( pinned().m ); return pinned().in_use; }
+void* get_pinned( size_t bytes, size_t* cap )
+{
+    const int dev = t_device;
+    void* p = pinned( dev ).get( bytes, cap );
+    if( p != nullptr ) registry().set( p, dev );
+    return p;
+}
+void  put_pinned( void* p, size_t cap )       { if( p != nullptr ) pinned( registry().get( p ) ).put( p, cap ); }
+size_t pinned_in_use( )
+{
+    // of the calling thread's device: the limit is a per-replica allowance
+    return pinned( t_device ).stats().in_use;
+}
+Stats pinned_stats( int device )
+{
+    if( device >= 0 ) return pinned( device ).stats();
+    Stats sum;
+    for( int i = 0; i < MAX_POOLS; i++ ) {
+        const Stats s = pinned( i < MAX_POOLS - 1 ? i : -1 ).stats();
+        sum.allocs += s.allocs; sum.frees += s.frees; sum.hits += s.hits; sum.free_bytes += s.free_bytes; sum.in_use += s.in_use; sum.free_buffers += s.free_buffers;
+    }
+    return sum;
+}
 } // namespace pool
 
 FeaturesHost::FeaturesHost( ) : _ext( nullptr ), _ori( nullptr ), _ext_cap( 0 ), _ori_cap( 0 ) { }

@@ -35,6 +35,7 @@
 #include <sched.h>
 #include <cctype>
 #include <cstdio>
+#include <ctime>
 
 using namespace std;
 
@@ -189,6 +190,7 @@ struct PopSift::Impl
     std::mutex                   prof_mutex;
     std::mutex                   log_mutex;              // LogMode::All dumps share fixed file names: one frame at a time
     double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0, t_pool = 0;
+    double t_cpu = 0;                                    // CPU seconds the worker threads burnt (CLOCK_THREAD_CPUTIME_ID)
     int    n_done = 0;
 };
 
@@ -228,6 +230,11 @@ bool PopSift::configure( const popsift::Config& config, bool /*force*/ )
     _config = config;
     _config.levels = std::max( 2, config.levels );     // popsift.cpp:86
     _impl->octaves_resolved = -1;
+    if( _config.ifPrintGaussTables() ) {                // init_filter's debug output (gauss_filter.cu:146-161, 247-256)
+        psx_config pc;
+        to_psx( _config, pc );
+        psx_print_gauss_tables( &pc, 10 );
+    }
     return true;
 }
 
@@ -256,13 +263,18 @@ void PopSift::uninit( )
     }
     if( getenv( "POPSIFT_PROFILE" ) != nullptr && _impl->n_done > 0 ) {
         const double k = 1e3 / _impl->n_done;
-        fprintf( stderr, "[popsift profile] %d frames, host ms per frame (per worker thread): attach %.3f (pool %.3f) upload %.3f launch %.3f "
-                         "wait-for-frame %.3f wrap %.3f\n", _impl->n_done, _impl->t_attach * k, _impl->t_pool * k, _impl->t_upload * k,
-                 _impl->t_submit * k, _impl->t_frame * k, _impl->t_wrap * k );
+        const popsift::pool::Stats ps = popsift::pool::pinned_stats( _device );
+        fprintf( stderr, "[popsift profile] device %d: %d frames, host ms per frame (per worker thread): attach %.3f (pool %.3f) upload %.3f launch %.3f "
+                         "wait-for-frame %.3f wrap %.3f; host CPU ms per frame (all workers) %.3f; pinned pool: %ld allocations, %ld frees, %ld hits, "
+                         "%ld buffers / %.0f MB free\n", _device, _impl->n_done, _impl->t_attach * k, _impl->t_pool * k, _impl->t_upload * k,
+                 _impl->t_submit * k, _impl->t_frame * k, _impl->t_wrap * k, _impl->t_cpu * k,
+                 ps.allocs, ps.frees, ps.hits, ps.free_buffers, ps.free_bytes / 1048576.0 );
     }
     _impl->contexts_exist = false;
     _isInit = false;
-    psx_match_release();                                // matcher scratch of the calling thread, if it ever matched
+    // the calling thread's matcher scratch (psx_match) is NOT released here: it belongs to the thread, another PopSift
+    // on the same thread may be using it, and releasing it would switch the caller's current device;
+    // it goes at thread exit or on an explicit psx_match_release()
 }
 
 PopSift::AllocTest PopSift::testTextureFit( int width, int height )
@@ -313,6 +325,7 @@ SiftJob* PopSift::enqueue( int w, int h, const unsigned char* imageData )
         return nullptr;
     }
     resolveOctaves( w, h );
+    popsift::pool::DeviceScope pool_of( _device );      // the job image comes from THIS device's pinned pool
     SiftJob* job = new SiftJob( w, h, imageData );
     _impl->queue.push( job );
     return job;
@@ -329,6 +342,7 @@ SiftJob* PopSift::enqueue( int w, int h, const float* imageData )
         return nullptr;
     }
     resolveOctaves( w, h );
+    popsift::pool::DeviceScope pool_of( _device );
     SiftJob* job = new SiftJob( w, h, imageData );
     _impl->queue.push( job );
     return job;
@@ -369,6 +383,13 @@ popsift::FeaturesHost* collect_host( Slot& s, std::atomic<int>& want_desc, doubl
     // also a frame with keypoints and no descriptors: s.xfeat holds nothing the GPU wrote unless an export was attached.
     const bool exported = s.xdesc != nullptr && s.desc_cap > 0 && ne <= EXPORT_FEATURES && no <= s.desc_cap;
     const bool hoarding = popsift::pool::pinned_in_use() > pinned_limit();
+    if( !exported && s.xdesc != nullptr && no > s.desc_cap ) {
+        // export was attached but this frame did not fit: without this the too-small buffer would stay attached and
+        // every later large frame would pay the PCIe stores AND a download.  Hand it back; the next
+        // frame attaches a want_desc-sized one.
+        popsift::pool::put_pinned( s.xdesc, s.xdesc_cap );
+        s.xdesc = nullptr; s.xdesc_cap = 0; s.desc_cap = 0;
+    }
     if( !exported ) {
         psx_feature* ftarget = s.xfeat;                       // pinned: the D2H copy stays asynchronous
         if( ftarget == nullptr || ne > EXPORT_FEATURES ) { tmp.resize( std::max( ne, 1 ) ); ftarget = tmp.data(); }
@@ -468,6 +489,7 @@ void PopSift::dispatchLoop( )
     Impl& p = *_impl;
     Slot s;
     pin_to_device_numa_node( _device );
+    popsift::pool::set_thread_device( _device );        // result and export buffers: this device's pinned pool
     double t_attach = 0, t_upload = 0, t_submit = 0, t_frame = 0, t_wrap = 0, t_pool = 0; int n_done = 0;
 
     for( ;; ) {
@@ -555,5 +577,7 @@ void PopSift::dispatchLoop( )
         std::lock_guard<std::mutex> g( p.prof_mutex );
         p.t_pool += t_pool; p.t_attach += t_attach; p.t_upload += t_upload; p.t_submit += t_submit; p.t_frame += t_frame; p.t_wrap += t_wrap;
         p.n_done += n_done;
+        struct timespec ts;
+        if( clock_gettime( CLOCK_THREAD_CPUTIME_ID, &ts ) == 0 ) p.t_cpu += (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
     }
 }

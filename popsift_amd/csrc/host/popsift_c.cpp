@@ -1,5 +1,6 @@
 // popsift_c.cpp -- flat C binding of PopSift / SiftJob / FeaturesHost (include/popsift_c.h).
 #include "popsift_c.h"
+#include "host_pool.h"
 
 #include "popsift/features.h"
 #include "popsift/popsift.h"
@@ -120,6 +121,14 @@ int popsift_c_copy( const popsift_c_features* f, psx_feature* features, float* d
 void popsift_c_free( popsift_c_features* f )
 {
     delete reinterpret_cast<popsift::FeaturesHost*>( f );
+}
+
+void popsift_c_pool_stats( int device, long long out[6] )
+{
+    if( out == nullptr ) return;
+    const popsift::pool::Stats s = popsift::pool::pinned_stats( device );
+    out[0] = s.allocs; out[1] = s.frees; out[2] = s.hits; out[3] = s.free_buffers;
+    out[4] = (long long)s.free_bytes; out[5] = (long long)s.in_use;
 }
 
 } // extern "C"

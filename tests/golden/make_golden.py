@@ -58,12 +58,50 @@ CASES = {
     "adv_composite_240x160": (240, 160, "composite", False, dict(octaves=4)),
     "adv_grating_128x96": (128, 96, "grating", False, dict(octaves=3)),
     "adv_ramp_128x96": (128, 96, "ramp", False, dict(octaves=3)),
+    # scale factors other than -1 / 0 / +1 (popsift.cpp:109-126, s_pyramid_build.cu:96-126): x4 upsampling, x4
+    # downsampling and a fractional factor (k_upscale + k_blur<R, true> path of the HIP side); round 4
+    "up2_vlfeat_72x56": (72, 56, 301, False, dict(octaves=3, upscale_factor=2.0, sift_mode=po.MODE_VLFEAT)),
+    "down2_200x152": (200, 152, 302, False, dict(octaves=2, upscale_factor=-2.0)),
+    "up_half_opencv_120x90": (120, 90, 303, False, dict(octaves=3, upscale_factor=0.5, sift_mode=po.MODE_OPENCV)),
+    "up_1p5_float_96x72": (96, 72, 304, True, dict(octaves=3, upscale_factor=1.5, sift_mode=po.MODE_VLFEAT)),
 }
+
+# BASELINE config 2 at full size in the mode the north_star quotes parity on: the bench frame (seed 1000), VLFeat
+# mode, through the reference's own code (about half an hour in the fiber emulation).  Too large to store whole:
+# the image is regenerated from its seed, every plane is a SHA-1, all Feature records are kept and every
+# DESC_STRIDE-th descriptor.
+BIG_CASES = {
+    "config2_vlfeat_1920x1080": (1920, 1080, 1000, dict(octaves=5, sift_mode=po.MODE_VLFEAT)),
+}
+DESC_STRIDE = 8
+
+
+def make_big(out_dir, only):
+    for name, (w, h, seed, kw) in BIG_CASES.items():
+        path = os.path.join(out_dir, "bigref_%s.npz" % name)      # not ref_*: its layout differs (golden_util.load_big)
+        if name not in only:
+            continue                                   # only on request: python make_golden.py config2_vlfeat_1920x1080
+        img = synth(w, h, seed)
+        r = pr.run(po.default_config(**kw), img)
+        planes = {}
+        for o in range(r.num_octaves):
+            for l in range(r.num_levels):
+                planes["g_%d_%d" % (o, l)] = hashlib.sha1(np.ascontiguousarray(r.gauss(o, l)).tobytes()).hexdigest()
+        d = r.descriptors()
+        data = dict(seed=seed, size=np.array([w, h], np.int32), image_sha1=hashlib.sha1(img.tobytes()).hexdigest(),
+                    config=json.dumps(kw), dims=np.array(r.dims, dtype=np.int32), num_levels=r.num_levels,
+                    plane_sha1=json.dumps(planes), features=r.features(), desc_stride=DESC_STRIDE,
+                    desc_count=len(d), descriptors_sub=d[::DESC_STRIDE].copy())
+        for o in range(r.num_octaves):
+            data["iext_%d" % o] = r.iext(o)
+        np.savez_compressed(path, **data)
+        print(name, "octaves", r.num_octaves, "features", r.ext_total, "descriptors", r.ori_total)
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     only = set(sys.argv[1:])
+    make_big(out_dir, only)
     for name, (w, h, seed, is_float, kw) in CASES.items():
         path = os.path.join(out_dir, "ref_%s.npz" % name)
         if (only and name not in only) or (not only and os.path.exists(path)):

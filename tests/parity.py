@@ -73,10 +73,12 @@ def _assign_keypoints(fa, fb, k=6):
     return partner
 
 
-def match_features(fa, da, fb, db, norm_scale=1.0, max_report=25):
+def match_features(fa, da, fb, db, norm_scale=1.0, max_report=25, da_rows=None):
     """fa/fb: structured feature arrays (debug_octave,xpos,ypos,sigma,num_ori,orientation,desc_idx);
     da/db: (n,128) descriptor arrays.  Returns parity fractions (of set A), exact mismatch counts
-    (kp_miss, ori_miss, desc_miss) and `misses`: printable records of the first mismatches."""
+    (kp_miss, ori_miss, desc_miss) and `misses`: printable records of the first mismatches.
+    da_rows: optional boolean mask of the rows of da that hold data (fixtures that keep a subset of the descriptors);
+    descriptor comparisons are restricted to those rows."""
     res = {"n_a": len(fa), "n_b": len(fb)}
     if len(fa) == 0 or len(fb) == 0:
         res.update(kp_match=float(len(fa) == len(fb)), ori_match=1.0, desc_match=1.0, max_desc_dist=0.0,
@@ -129,6 +131,8 @@ def match_features(fa, da, fb, db, norm_scale=1.0, max_report=25):
     da_idx = fa["desc_idx"][ia[rr], pp].astype(np.int64)
     db_idx = fb["desc_idx"][ib[rr], qq].astype(np.int64)
     have = (da_idx >= 0) & (db_idx >= 0) & (da_idx < len(da)) & (db_idx < len(db))
+    if da_rows is not None:
+        have &= np.asarray(da_rows, bool)[np.clip(da_idx, 0, len(da) - 1)]
     rr, da_idx, db_idx = rr[have], da_idx[have], db_idx[have]
     n_desc = len(rr)
     if n_desc:

@@ -110,8 +110,11 @@ def test_product_does_not_reference_the_oracle():
     btxt = open(os.path.join(ROOT, "bench.py")).read()
     assert btxt.count("from oracle import pyoracle") == 2
     assert "def e2e_parity" in btxt and "from oracle import pyoracle as po" in btxt.split("def e2e_parity")[1].split("def ")[0]
-    timed_body = btxt.split("def timed(step, drain):")[1].split("# ---- leg 1")[0]
-    assert "oracle" not in timed_body
+    timed_body = btxt.split("def timed(step, drain, probe=None):")[1].split("def reduce_sum_dict")[0]
+    assert "oracle" not in timed_body and "parity" not in timed_body
+    # the step / drain closures the timed region runs: nothing but enqueue / get
+    steps_body = btxt.split("def e2e_step(n=None):")[1].split("desc_probe =")[0]
+    assert "oracle" not in steps_body and "parity" not in steps_body
 
 
 def test_bench_frame_rule_is_round_robin_over_gpus():
@@ -185,3 +188,29 @@ def test_bench_has_no_undefined_names():
             known.add(n.name)
     loaded = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
     assert loaded <= known, sorted(loaded - known)
+
+
+def test_print_gauss_tables_prints_the_tables(capfd):
+    """--print-gauss-tables / Config::setPrintGaussTables (gauss_filter.cu:24-120, 146-161): the five tables in the
+    reference's layout; the numbers are those of psx_gauss_tables."""
+    import ctypes as C
+    from popsift_amd import capi
+    L = capi.lib()
+    L.psx_print_gauss_tables.argtypes = [C.POINTER(capi.Config), C.c_int]
+    cfg = capi.default_config()
+    assert L.psx_print_gauss_tables(C.byref(cfg), 10) == 0
+    out = capfd.readouterr().out
+    t = capi.gauss_tables(cfg)
+    assert "Upscaling factor: 1.000000 (i.e. original image is scaled by a factor of 2.000000)" in out
+    assert "    Initial sigma is 1.600000" in out and "Gauss tables for hardware interpolation" in out
+    assert "absolute filters octave 0" in out and "level 0-filters for direct downscaling" in out
+    rel = out.split("    relative sigma\n")[1].split("\n\n")[0].splitlines()
+    assert len(rel) == cfg.levels + 3
+    for lvl, line in enumerate(rel):
+        head, vals = line.split(": ")
+        assert head.split() == [str(lvl), str(2 * t["inc_span"][lvl] - 1), "%2.6f" % t["inc_sigma"][lvl]]
+        want = ["%0.8f" % v for v in t["inc_filter"][lvl][:min(10, t["inc_span"][lvl])]]
+        assert vals.split()[:len(want)] == want
+        assert vals.rstrip().endswith("...") == (t["inc_span"][lvl] > 10)
+    dd = out.split("level 0-filters for direct downscaling\n")[1].strip().splitlines()
+    assert len(dd) == capi.MAX_OCTAVES and dd[0].split()[2] == "%2.6f:" % t["dd_sigma"][0]

@@ -45,12 +45,21 @@ def _stub_backend(bench, log):
         def _kp(self, i):
             return self.seeds[i % bench.BATCH] % 7 + 1
 
-        def e2e_open(self):
-            log.append("e2e_open")
+        def e2e_open(self, profile="headline"):
+            log.append("e2e_open " + profile)
+
+        def e2e_select(self, which):
+            log.append("select " + which)
+
+        def e2e_parity(self, indices):
+            # rank r "checks" len(indices) frames and reports r + 1 orientation mismatches
+            return {"frames": len(indices), "keypoints": 1000 * (self.rank + 1), "descriptors": 1200, "kp_miss": 0,
+                    "ori_miss": self.rank + 1, "desc_miss": 0, "max_desc_dist": 1e-4 * (self.rank + 1),
+                    "frame_indices": list(indices)}
 
         def e2e_enqueue(self, i):
             self.submitted.append(("e2e", i))
-            time.sleep(0.0005 * (self.rank + 1))
+            time.sleep(0.0001 * (self.rank + 1))
             return i
 
         def e2e_get(self, job):
@@ -82,16 +91,25 @@ def _stub_backend(bench, log):
     return Stub
 
 
-def _worker(rank, world, port, steps, warmup, q):
+def _worker(rank, world, port, steps, warmup, q, extra=()):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
     import bench
     log = []
     buf = io.StringIO()
-    args = bench.parse_args(["--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup)])
-    res = bench.run(args, backend_cls=_stub_backend(bench, log), out=buf)
-    q.put((rank, res, buf.getvalue(), log))
+    args = bench.parse_args(["--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup)] + list(extra))
+    stub = _stub_backend(bench, log)
+    holder = {}
+    orig_init = stub.__init__
+
+    def init(self, *a):
+        orig_init(self, *a)
+        holder["be"] = self
+    stub.__init__ = init
+    res = bench.run(args, backend_cls=stub, out=buf)
+    q.put((rank, res, buf.getvalue(), log, [t for t in holder["be"].submitted if t[0] == "e2e"][:1] and
+           len([t for t in holder["be"].submitted if t[0] == "e2e"])))
 
 
 @pytest.mark.parametrize("steps,warmup", [(3, 1), (5, 0)])
@@ -107,7 +125,7 @@ def test_bench_control_flow_two_ranks(steps, warmup):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, r0, out0, log0), (_, r1, out1, log1) = res
+    (_, r0, out0, log0, _), (_, r1, out1, log1, _) = res
     # only rank 0 reports, exactly one JSON line
     assert r1 is None and out1 == ""
     lines = [l for l in out0.splitlines() if l.strip()]
@@ -118,9 +136,9 @@ def test_bench_control_flow_two_ranks(steps, warmup):
     n_frames = world * bench.BATCH * steps
     assert j["n_gpus"] == world and j["steps"] == steps and j["warmup"] == warmup and j["scaling"] == "weak"
     assert j["config"]["frames_timed"] == n_frames
-    # whole-job value: all ranks' pixels over the max-over-ranks time (rank 1 is the slower one: 1 ms per frame)
+    # whole-job value: all ranks' pixels over the max-over-ranks time (rank 1 is the slower one: 0.2 ms per frame)
     t = n_frames * bench.W * bench.H / (j["value"] * 1e6)
-    assert t >= bench.BATCH * steps * 0.001 * 0.9
+    assert t >= bench.BATCH * steps * 0.0002 * 0.9
     assert abs(j["ms_per_step"] - t / steps * 1e3) < 0.05 * j["ms_per_step"] + 1e-3
     # keypoints are summed over ranks: every timed frame of both ranks is collected inside the timed region
     seeds = {r: [bench.frame_seed(k, r, world) for k in range(bench.BATCH)] for r in range(world)}
@@ -132,4 +150,34 @@ def test_bench_control_flow_two_ranks(steps, warmup):
     assert abs(j["device_resident"]["keypoints_per_s"] * (n_frames * bench.W * bench.H / (j["device_resident"]["value"] * 1e6))
                - 3 * n_frames) < 0.02 * 3 * n_frames + 1
     # leg order and the export switch
-    assert log0 == log1 == ["e2e_open", "e2e_close", "abi_open", "export False", "export True", "export False", "abi_close"]
+    assert log0 == log1 == ["e2e_open headline", "select sparse", "select dense", "e2e_close", "e2e_open popsift", "e2e_close",
+                            "e2e_open caller", "e2e_close", "abi_open", "export False", "export True", "export False", "abi_close"]
+    # parity counts of EVERY rank are summed (rank r reports r + 1 orientation mismatches), the worst distance is the max
+    for pc in (j["parity_checked"], j["caller_profile"]["parity_checked"]):
+        assert pc["ranks_checked"] == world and pc["frames"] == 4 * world and pc["ori_miss"] == 3
+        assert pc["keypoints"] == 3000 and abs(pc["max_desc_dist"] - 2e-4) < 1e-9 and pc["within_budget"] is False
+    assert j["popsift_mode"]["value"] > 0 and j["caller_profile"]["value"] > 0 and j["sparse_frames"]["value"] > 0
+
+
+def test_bench_strong_scaling_shape_two_ranks():
+    """--strong = BASELINE config 4's literal shape: BATCH frames per step in TOTAL, BATCH / N per rank; value is still
+    all ranks' pixels over the max-over-ranks time."""
+    world, steps, warmup = 2, 2, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, warmup, q, ("--strong", "--no-extras"))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import bench
+    j = res[0][1]
+    assert j["scaling"] == "strong" and j["n_gpus"] == world
+    assert j["config"]["frames_per_step_per_gpu"] == bench.BATCH // world
+    assert j["config"]["frames_timed"] == bench.BATCH * steps
+    # every rank enqueued (warmup + steps) * BATCH / world frames on the end-to-end leg
+    for r in res:
+        assert r[4] == (warmup + steps) * bench.BATCH // world

@@ -71,6 +71,78 @@ def test_config3_4096sq_6_octaves(oracle, capi):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,kw", [("VLFeat", dict(sift_mode=2)), ("OpenCV", dict(sift_mode=1, gauss_mode=3))])
+def test_config2_1080p_other_sift_modes(oracle, capi, name, kw):
+    """BASELINE config 2 in the mode the north_star quotes parity on (configs 2 / 3 use config
+    1's setMode(VLFeat)) and in OpenCV mode (config 5's Config at the 1080p size).  Mode-specific code: the refinement
+    rules of s_extrema.cu:155-284 (VLFeat: the level never moves; OpenCV: round(d) moves, 5 px border, iteration 5
+    rejects), the octave-0 sampling shift of s_pyramid_build.cu:109-114 (OpenCV: 0.5 instead of 0.5 * 2^up).  Planes
+    bit-exact, extrema identical, the full feature set matched one to one within budget()."""
+    img = synth(1920, 1080, 1000)
+    ref = oracle.run(oracle.default_config(octaves=5, **kw), img)
+    ctx = capi.Context(capi.default_config(octaves=5, **kw))
+    ctx.upload(img)
+    ctx.extract()
+    _planes_and_extrema_equal(ctx, capi, ref)
+    fb, db = ctx.download()
+    assert len(fb) > 8000
+    _features_within_budget(ref, fb, db, "config 2 (1080p) %s mode" % name)
+    ctx.close()
+
+
+def test_config3_4096sq_6_octaves_vlfeat_mode(oracle, capi):
+    """BASELINE config 3 with config 1's Config: 4096x4096, 6 octaves, x2 upsample, setMode(VLFeat)."""
+    img = synth(4096, 4096, 3001)
+    kw = dict(octaves=6, sift_mode=2)
+    ref = oracle.run(oracle.default_config(**kw), img)
+    ctx = capi.Context(capi.default_config(**kw))
+    ctx.upload(img)
+    ctx.extract()
+    assert ctx.octave_dims(0) == (8192, 8192)
+    _planes_and_extrema_equal(ctx, capi, ref)
+    fb, db = ctx.download()
+    assert len(fb) > 50000
+    _features_within_budget(ref, fb, db, "config 3 (4096^2, 6 octaves) VLFeat mode")
+    ctx.close()
+
+
+def test_config2_1080p_vlfeat_against_the_reference_itself(capi):
+    """The bench frame (seed 1000) in VLFeat mode against a fixture produced by the REFERENCE's own sources at full
+    size (tests/golden/make_golden.py BIG_CASES, half an hour in the CUDA emulation): every plane's SHA-1, the initial
+    extrema, every Feature record, and every 8th descriptor (the fixture keeps a subset to stay small)."""
+    from tests import golden_util as gu
+    names = gu.big_cases()
+    if "config2_vlfeat_1920x1080" not in names:
+        pytest.skip("tests/golden/bigref_config2_vlfeat_1920x1080.npz not generated")
+    g = gu.load_big("config2_vlfeat_1920x1080")
+    ctx = capi.Context(capi.default_config(**g["config"]))
+    ctx.upload(g["image"])
+    ctx.extract()
+    assert [ctx.octave_dims(o) for o in range(ctx.num_octaves)] == g["dims"]
+    for o in range(ctx.num_octaves):
+        for l in range(ctx.num_levels):
+            assert gu.sha1(ctx.dump_plane(capi.PLANE_GAUSS, o, l)) == g["plane_sha1"]["g_%d_%d" % (o, l)], (o, l)
+    for o in range(ctx.num_octaves):
+        b = ctx.dump_iext(o)
+        a, b = sort_iext(g["iext_%d" % o]), sort_iext(b[b["ignore"] == 0])
+        assert len(a) == len(b)
+        assert np.array_equal(a["lpos"], b["lpos"])
+        for f in ("xpos", "ypos"):     # the reference's solve() is FMA-contracted by its compiler: 2e-5 px or 2 ulp
+            assert np.all(np.abs(a[f] - b[f]) <= np.maximum(2e-5, 2 * np.spacing(np.abs(a[f])))), f
+    fb, db = ctx.download()
+    fa = g["features"]
+    assert len(fa) == len(fb) and g["desc_count"] == len(db)
+    da = np.full((g["desc_count"], 128), np.nan, np.float32)
+    da[::g["desc_stride"]] = g["descriptors_sub"]
+    rows = np.zeros(g["desc_count"], bool)
+    rows[::g["desc_stride"]] = True
+    m = match_features(fa, da, fb, db, da_rows=rows)
+    print("reference fixture 1080p VLFeat:", {k: v for k, v in m.items() if k != "misses"})
+    assert m["desc_compared"] > 1500
+    assert_parity(m, what="reference 1080p VLFeat fixture -> HIP", **budget(len(fa)))
+    ctx.close()
+
+
 # a mild perspective warp: rotation ~8 degrees, scale 0.9, shear and a small projective term
 _H5 = np.array([[0.891, -0.125, 60.0],
                 [0.125, 0.891, -20.0],

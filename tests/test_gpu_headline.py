@@ -21,24 +21,24 @@ NFRAMES = 32
 _REF = {}
 
 
-def _ref(oracle, frames, i):
-    """oracle result of bench frame i (features, descriptors), computed once per session"""
-    if i not in _REF:
-        r = oracle.run(oracle.default_config(octaves=5), frames[i])
-        _REF[i] = (r.features().copy(), r.descriptors().copy())
+def _ref(oracle, frames, i, profile="default", kw=None):
+    """oracle result of bench frame i (features, descriptors) under a Config profile, computed once per session"""
+    if (profile, i) not in _REF:
+        r = oracle.run(oracle.default_config(**(kw or dict(octaves=5))), frames[i])
+        _REF[(profile, i)] = (r.features().copy(), r.descriptors().copy())
         r.close()
-    return _REF[i]
+    return _REF[(profile, i)]
 
 
-def _check_all(oracle, frames, results, what):
+def _check_all(oracle, frames, results, what, profile="default", kw=None, norm_scale=1.0):
     n = len(frames)
     tot = dict(kp=0, ori=0, desc=0, n=0)
     assert len(results) % n == 0 and len(results) >= n
     for j, (fb, db) in enumerate(results):
-        fa, da = _ref(oracle, frames, j % n)
+        fa, da = _ref(oracle, frames, j % n, profile, kw)
         assert len(fb) == len(fa) and len(db) == len(da), "%s: job %d (frame %d) has %d / %d features, oracle %d / %d" % (
             what, j, j % n, len(fb), len(db), len(fa), len(da))
-        m = match_features(fa, da, fb, db)
+        m = match_features(fa, da, fb, db, norm_scale=norm_scale)
         assert_parity(m, what="%s job %d (frame %d)" % (what, j, j % n), **budget(len(fa)))
         tot["kp"] += m["kp_miss"]; tot["ori"] += m["ori_miss"]; tot["desc"] += m["desc_miss"]; tot["n"] += len(fa)
     b = budget(tot["n"])
@@ -54,6 +54,39 @@ def test_headline_path_distinct_1080p_frames_24_outstanding(oracle, capi):
     ps.close()
     tot = _check_all(oracle, frames, results, "e2e")
     assert tot["n"] > 2 * NFRAMES * 5000
+
+
+def test_headline_path_vlfeat_mode(oracle, capi):
+    """The headline of round 4 runs config 1's Config (setMode(VLFeat)): the same streaming
+    shape in VLFeat mode, every result against the oracle."""
+    import bench
+    frames = bench_frames(16)
+    ps = capi.PopSift(capi.default_config(**bench.HEADLINE_KW))
+    results = stream(ps, frames, outstanding=24, passes=2)
+    ps.close()
+    assert bench.HEADLINE_KW.get("sift_mode") == 2
+    tot = _check_all(oracle, frames, results, "e2e VLFeat", profile="vlfeat", kw=bench.HEADLINE_KW)
+    assert tot["n"] > 2 * 16 * 5000
+
+
+def test_caller_profile_float_images_grid_filter_norm9(oracle, capi):
+    """The profile of the external caller SURVEY.md 8b names (AliceVision's popSIFT describer):
+    PopSift(config, ExtractingMode, FloatImages), setFilterMaxExtrema(N) + setFilterSorting(LargestScaleFirst),
+    setNormalizationMultiplier(9), float frames in [0, 1) through enqueue(w, h, const float*) (popsift.cpp:243-291),
+    24 jobs outstanding.  The grid filter reads the extrema counters on the host in mid-chain (s_orientation.cu:378-383,
+    s_filtergrid.cu:36-325), i.e. every frame stalls its worker once.  Every result against the oracle."""
+    import bench
+    frames = bench.caller_frames(bench_frames(12))
+    assert frames[0].dtype == np.float32 and 0.0 <= float(frames[0].min()) and float(frames[0].max()) < 1.0
+    kw = bench.CALLER_KW
+    assert kw["filter_max_extrema"] > 0 and kw["grid_filter_mode"] == 1 and kw["norm_multi"] == 9
+    ps = capi.PopSift(capi.default_config(**kw), float_images=True)
+    results = stream(ps, frames, outstanding=24, passes=2)
+    ps.close()
+    unfiltered = oracle.run(oracle.default_config(octaves=5), frames[0])
+    tot = _check_all(oracle, frames, results, "caller profile", profile="caller", kw=kw, norm_scale=512.0)
+    assert len(results[0][0]) < unfiltered.ext_total, "the grid filter must have removed extrema"
+    assert tot["n"] > 2 * 12 * 3000
 
 
 @pytest.mark.parametrize("depth", [1, 16])
@@ -122,3 +155,50 @@ def test_two_popsift_replicas_on_one_device_round_robin(oracle, capi):
     for rp in reps:
         rp.close()
     _check_all(oracle, frames, res, "two replicas on device 0")
+
+
+def test_eight_replicas_in_one_process_pool_is_steady(oracle, capi, monkeypatch, capfd):
+    """The one-process N-device shape (popsift.h:158,166-168; main.cpp:305-326: one PopSift per device, frame i ->
+    replica i mod N) at N = 8 with every replica forced onto device 0 (no 8-GPU box here): after warm-up the pinned
+    pools must not allocate or free a single buffer (a free list capped at 32 buffers made
+    the surplus go through hipHostFree / hipHostMalloc on every drain / refill burst), every result is the oracle's,
+    and POPSIFT_PROFILE reports the host CPU time per frame."""
+    from collections import deque
+    monkeypatch.setenv("POPSIFT_LOCAL_REPLICAS", "8")
+    monkeypatch.setenv("POPSIFT_PROFILE", "1")
+    frames = bench_frames(8)
+    nrep = 8
+    reps = [capi.PopSift(capi.default_config(octaves=5)) for _ in range(nrep)]
+    jobs, res = deque(), []
+
+    def run(passes):
+        k = 0
+        for _ in range(passes):
+            for f in frames:
+                for r in range(nrep):                      # every replica sees every frame: 64 jobs per pass
+                    if len(jobs) >= 8 * nrep:
+                        rr, j = jobs.popleft()
+                        res.append(reps[rr].get(j))
+                    jobs.append((r, reps[r].enqueue(f)))
+                    k += 1
+        while jobs:
+            rr, j = jobs.popleft()
+            res.append(reps[rr].get(j))
+        return k
+    run(2)                                                 # warm-up: pools fill, contexts are created
+    before = capi.pool_stats(0)
+    n = run(3)
+    after = capi.pool_stats(0)
+    assert after["allocs"] == before["allocs"] and after["frees"] == before["frees"], (before, after)
+    assert after["hits"] - before["hits"] >= 2 * n         # job image + descriptor buffer of every frame came from the pool
+    for rp in reps:
+        rp.close()
+    err = capfd.readouterr().err
+    cpu = [float(l.split("host CPU ms per frame (all workers)")[1].split(";")[0]) for l in err.splitlines() if "[popsift profile]" in l]
+    assert len(cpu) == nrep, err
+    print("host CPU ms per frame, 8 replicas on one device:", cpu, "pool:", after)
+    assert max(cpu) < 5.0
+    # results in job order: pass p, frame i, replica r
+    assert len(res) == 5 * len(frames) * nrep
+    per_frame = [res[(p * len(frames) + i) * nrep + r] for p in range(5) for r in range(nrep) for i in range(len(frames))]
+    _check_all(oracle, frames, per_frame, "8 replicas on device 0")

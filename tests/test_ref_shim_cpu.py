@@ -112,6 +112,27 @@ def test_fuzz_oracle_vs_reference(oracle, ref, w, h, seed, kw):
         assert m["kp_match"] == 1.0 and m["ori_match"] == 1.0 and m["desc_match"] == 1.0, m
 
 
+@pytest.mark.parametrize("up,mode,is_float", [(2.0, 2, False), (-2.0, 0, False), (0.5, 1, False), (1.5, 2, True), (-0.5, 0, False)])
+def test_other_scale_factors_match_reference(oracle, ref, up, mode, is_float):
+    """setDownsampling values other than -1 / 0 / +1, fractional ones included (popsift.cpp:109-126: the octave-0 size
+    is ceil(w * 2^up), the texture coordinates of s_pyramid_build.cu:96-126 follow): planes bit-identical, same extrema,
+    identical feature sets."""
+    from popsift_amd.synth import synth_float
+    w, h = (200, 152) if up < -1 else (72, 56)
+    img = synth_float(w, h, 11) if is_float else synth(w, h, 11)
+    cfg = oracle.default_config(octaves=3 if up > -2 else 2, upscale_factor=up, sift_mode=mode)
+    r, o = ref.run(cfg, img), oracle.run(cfg, img)
+    assert r.dims == o.dims and r.num_levels == o.num_levels
+    for oc in range(r.num_octaves):
+        for l in range(r.num_levels):
+            assert np.array_equal(r.gauss(oc, l), o.gauss(oc, l)), (oc, l)
+        assert len(r.iext(oc)) == len(o.iext(oc))
+    assert r.ext_total == o.ext_total and r.ori_total == o.ori_total
+    if r.ext_total:
+        m = match_features(r.features(), r.descriptors(), o.features(), o.descriptors())
+        assert m["kp_match"] == 1.0 and m["ori_match"] == 1.0 and m["desc_match"] == 1.0, m
+
+
 # ---- alternative pyramid / descriptor modes (SURVEY.md 8f rank 3) --------------------------------------
 @pytest.mark.parametrize("kw", [dict(gauss_mode=1), dict(gauss_mode=2), dict(gauss_mode=4), dict(gauss_mode=5),
                                 dict(gauss_mode=1, levels=4, sigma=1.4, upscale_factor=0.0)])
