@@ -687,9 +687,9 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         # baseline; the strict IEEE build (-O2 -ffp-contract=off, the parity checker) is stated beside it
         fdt = po.time_fast_build(ocfg, frames_np[:n_s], ncores)
         fast = round(n_s * W * H / fdt / 1e6, 2) if fdt else None
-        cpu = {"value": fast if fast else strict, "unit": "Mpix/s", "cores": ncores, "kind": "port",
-               "build": "-O3 -march=native -ffp-contract=fast -fopenmp (oracle/_fast, built on this host)" if fast
-                        else "-O2 -ffp-contract=off -fopenmp (the checker build; the tuned build failed here)",
+        # value = the faster of the two builds (on the round-4 box the -O2 -mavx2 checker build was the faster one)
+        cpu = {"value": max(fast or 0.0, strict), "unit": "Mpix/s", "cores": ncores, "kind": "port",
+               "native_build": {"value": fast, "unit": "Mpix/s", "build": "-O3 -march=native -ffp-contract=fast -fopenmp (oracle/_fast, built on this host; None = build failed)"},
                "strict_checker_build": {"value": strict, "unit": "Mpix/s", "build": "-O2 -mavx2 -ffp-contract=off -fopenmp (oracle/liboracle.so)"},
                "sample": "%d frames 1920x1080 (config 1's Config, VLFeat mode), OpenMP over %d threads" % (n_s, ncores)}
         try:

@@ -189,7 +189,11 @@ def test_eight_replicas_in_one_process_pool_is_steady(oracle, capi, monkeypatch,
     before = capi.pool_stats(0)
     n = run(3)
     after = capi.pool_stats(0)
-    assert after["allocs"] == before["allocs"] and after["frees"] == before["frees"], (before, after)
+    # steady state: nothing is freed, and nothing is allocated beyond a new high-water mark of simultaneously live
+    # buffers (the 32 workers and the caller race for buffers: the peak can move by a buffer or two between passes;
+    # round 3's capped list re-allocated ~ (live - 32) buffers on EVERY drain / refill burst)
+    assert after["frees"] == before["frees"] == 0, (before, after)
+    assert after["allocs"] - before["allocs"] <= 3, (before, after)
     assert after["hits"] - before["hits"] >= 2 * n         # job image + descriptor buffer of every frame came from the pool
     for rp in reps:
         rp.close()
