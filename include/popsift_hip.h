@@ -295,6 +295,12 @@ int psx_stage_times(psx_ctx* ctx, float ms[4]);
  * of one launch (8 bytes per pixel: plane read once, written once). */
 int psx_time_blur(psx_ctx* ctx, int octave, int level, int reps, float* avg_ms, double* bytes);
 
+/* Measurement: one pyramid build with the whole-pyramid kernel (k_pyramid_flow) recording, per work item and in ticket
+ * order, six int64: the 100 MHz wall clock at dequeue / dependencies met / arithmetic done / published, a word
+ * (octave << 40 | level << 32 | chunk << 16 | strip) and the workgroup index.  *nitems = items of the current plan
+ * (0 when the launch-per-level schedule is in use); call with host_out = NULL to ask for the size. */
+int psx_flow_trace(psx_ctx* ctx, long long* host_out, int capacity_items, int* nitems);
+
 /* In-pipeline timing of the dominant kernel: when enabled, every separable-Gaussian launch of octave 0
  * (levels 1..L-1) INSIDE psx_extract / psx_build_pyramid carries a begin and an end event of its own
  * dispatch (hipExtLaunchKernel: the kernel's start / end timestamps, the quantity rocprofv3 --kernel-trace

@@ -71,7 +71,9 @@ void blur_table(int mode, int nlev, const float* sigma, int* span, float* filter
 
 } // namespace
 
-constexpr size_t CNT_BLOCK = 512;      // bytes reserved for PsxCounters in front of the candidate counters
+constexpr size_t CNT_BLOCK = 512;      // bytes reserved for PsxCounters in front of the flow state and the candidate counters
+constexpr size_t FLOW_MAX_BYTES = sizeof(int) * (size_t)(PSX_FLOW_HEAD_INTS + PSX_FLOW_MAX_COUNTERS * PSX_FLOW_CNT_STRIDE);
+constexpr size_t CAND_CT_BYTES = sizeof(int) * (size_t)PSX_MAX_OCTAVES * PSX_CAND_SUB * 32;
 
 struct psx_ctx {
     int         device = 0;
@@ -159,6 +161,16 @@ struct psx_ctx {
     hipEvent_t ev_blur[2 * PSX_GAUSS_LEVELS] = {};     // [2l], [2l+1]: begin / end of the level-(l+1) kernel
     int  blur_probe_n = 0;             // levels timed in the last extraction
     double blur_probe_bytes = 0.0;     // algorithmic bytes per timed launch (8 B per pixel of every plane the launch blurs), averaged
+    // k_pyramid_flow (POPSIFT_FLOW: 0 = one launch per level, 1 = every blur level of the frame in one launch,
+    // 2 = octave 0 by launches, octaves >= 1 in one launch)
+    int  flow_mode = 1, flow_ld = 2, flow_order = 0;
+    bool flow_on = false;              // a plan exists for the current size
+    int  flow_first = 0, flow_nitems = 0, flow_grid = 0, flow_ncnt = 0, flow_njobs = 0;
+    size_t flow_bytes = 0;             // ticket words + chunk counters, between PsxCounters and the candidate counters
+    double flow_algo_bytes = 0.0;      // algorithmic bytes of the launch (8 B per pixel and blurred plane + 4 B per decimated pixel)
+    PsxFlowJob*  d_flow_jobs = nullptr;  size_t flow_jobs_cap = 0;
+    PsxFlowItem* d_flow_items = nullptr; size_t flow_items_cap = 0;
+    long long*   d_flow_trace = nullptr;     // psx_flow_trace only
     int  resident_blocks = 1024;       // 4 x compute units
     bool batch_octaves = true;         // diagonal schedule: two octaves' levels in one launch (POPSIFT_BATCH_OCTAVES=0: one plane per launch)
 };
@@ -435,10 +447,15 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_params_pin), sizeof(PsxParams), hipHostMallocDefault));
     // frame counters and the candidate sub-list counters in ONE allocation: one fill kernel clears both per frame
     static_assert(sizeof(PsxCounters) <= CNT_BLOCK, "PsxCounters outgrew its slot");
-    PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), CNT_BLOCK + sizeof(int) * (size_t)PSX_MAX_OCTAVES * PSX_CAND_SUB * 32));
+    // layout: [PsxCounters | flow state (flow_bytes, set per size) | candidate counters]; the per-frame fill covers the
+    // used prefix of it
+    PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), CNT_BLOCK + FLOW_MAX_BYTES + CAND_CT_BYTES));
     n->d_cand_ct = reinterpret_cast<int*>(reinterpret_cast<char*>(n->d_cnt) + CNT_BLOCK);
+    { const char* g = getenv("POPSIFT_FLOW"); if (g != nullptr && g[0] >= '0' && g[0] <= '2') n->flow_mode = g[0] - '0'; }
+    { const char* g = getenv("POPSIFT_FLOW_LD"); if (g != nullptr && (g[0] == '1' || g[0] == '2')) n->flow_ld = g[0] - '0'; }
+    { const char* g = getenv("POPSIFT_FLOW_ORDER"); if (g != nullptr && g[0] >= '0' && g[0] <= '2') n->flow_order = g[0] - '0'; }
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_cnt), sizeof(PsxCounters), hipHostMallocDefault));
-    PSX_HIPC(hipMemset(n->d_cnt, 0, CNT_BLOCK + sizeof(int) * (size_t)PSX_MAX_OCTAVES * PSX_CAND_SUB * 32));
+    PSX_HIPC(hipMemset(n->d_cnt, 0, CNT_BLOCK + FLOW_MAX_BYTES + CAND_CT_BYTES));
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_xcnt), 4 * sizeof(int), hipHostMallocDefault));
     n->h_xcnt[0] = n->h_xcnt[1] = n->h_xcnt[2] = n->h_xcnt[3] = 0;
     for (int i = 0; i < 5; i++) PSX_HIPC(hipEventCreate(&n->ev[i]));
@@ -462,6 +479,7 @@ int psx_destroy(psx_ctx* ctx)
     if (ctx->h_xcnt) (void)hipHostFree(ctx->h_xcnt);
     (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr); (void)hipFree(ctx->d_up);
     (void)hipFree(ctx->d_intm); (void)hipFree(ctx->d_vbuf);
+    (void)hipFree(ctx->d_flow_jobs); (void)hipFree(ctx->d_flow_items);
     (void)hipFree(ctx->d_gf_keys); (void)hipFree(ctx->d_gf_vals); (void)hipFree(ctx->d_gf_temp);
     (void)hipFree(ctx->d_gf_scratch);
     (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off); (void)hipFree(ctx->d_cand);
@@ -560,6 +578,33 @@ int psx_resize(psx_ctx* ctx, int w, int h)
     if ((rc = grow(ctx, &ctx->d_iext_off, &ctx->iext_off_cap, iext_need)) != PSX_OK) return rc;
     // candidates before refinement: ~1.3x the survivors on natural images; room for 4x the cap per octave,
     // split over PSX_CAND_SUB sub-lists; a candidate that finds its sub-list full is refined in place
+    // k_pyramid_flow: work list of this size (default pyramid modes only), and where the candidate counters start behind
+    // its ticket words and chunk counters
+    ctx->flow_on = false; ctx->flow_bytes = 0;
+    if (!ctx->alt_pyramid && ctx->flow_mode != 0) {
+        PsxFlowPlan plan{};
+        const int first = ctx->flow_mode == 2 ? 1 : 0;
+        if (first < P.num_octaves && psx_flow_plan(P, ctx->inc_filter, ctx->inc_span, first, ctx->resident_blocks, ctx->flow_order, &plan)) {
+            bool ok = grow(ctx, &ctx->d_flow_jobs, &ctx->flow_jobs_cap, (size_t)plan.njobs) == PSX_OK &&
+                      grow(ctx, &ctx->d_flow_items, &ctx->flow_items_cap, (size_t)plan.nitems) == PSX_OK;
+            ok = ok && hipMemcpy(ctx->d_flow_jobs, plan.jobs, sizeof(PsxFlowJob) * (size_t)plan.njobs, hipMemcpyHostToDevice) == hipSuccess &&
+                       hipMemcpy(ctx->d_flow_items, plan.items, sizeof(PsxFlowItem) * (size_t)plan.nitems, hipMemcpyHostToDevice) == hipSuccess;
+            if (ok) {
+                ctx->flow_on = true; ctx->flow_first = first; ctx->flow_nitems = plan.nitems; ctx->flow_grid = plan.grid;
+                ctx->flow_ncnt = plan.ncounters; ctx->flow_njobs = plan.njobs;
+                ctx->flow_bytes = sizeof(int) * ((size_t)PSX_FLOW_HEAD_INTS + (size_t)plan.ncounters * PSX_FLOW_CNT_STRIDE);
+                double by = 0.0;
+                for (int q = 0; q < plan.njobs; q++) {
+                    by += 8.0 * (double)plan.jobs[q].W * plan.jobs[q].H;
+                    if (plan.jobs[q].half_dst) by += 4.0 * (double)((plan.jobs[q].W + 1) / 2) * ((plan.jobs[q].H + 1) / 2);
+                }
+                ctx->flow_algo_bytes = by;
+            }
+            free(plan.jobs); free(plan.items);
+            if (!ok) return fail(ctx, PSX_ERR_HIP, "psx_resize: could not upload the pyramid work list");
+        }
+    }
+    ctx->d_cand_ct = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->d_cnt) + CNT_BLOCK + ctx->flow_bytes);
     P.cand_capacity = (4 * c.max_extrema + PSX_CAND_SUB - 1) / PSX_CAND_SUB;
     if ((rc = grow(ctx, &ctx->d_cand, &ctx->cand_cap, (size_t)P.num_octaves * PSX_CAND_SUB * P.cand_capacity)) != PSX_OK) return rc;
     P.cand_ct = ctx->d_cand_ct;
@@ -699,7 +744,7 @@ int psx_build_pyramid(psx_ctx* ctx)
     ctx->counts_valid = false;
     if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     // Pyramid::reset_extrema_mgmt, sift_pyramid.cu:364-371
-    PSX_HIP(hipMemsetAsync(ctx->d_cnt, 0, CNT_BLOCK + sizeof(int) * (size_t)P.num_octaves * PSX_CAND_SUB * 32, ctx->stream));
+    PSX_HIP(hipMemsetAsync(ctx->d_cnt, 0, CNT_BLOCK + ctx->flow_bytes + sizeof(int) * (size_t)P.num_octaves * PSX_CAND_SUB * 32, ctx->stream));
 
     if (ctx->alt_pyramid) {
         PsxAltArgs q;
@@ -738,6 +783,27 @@ int psx_build_pyramid(psx_ctx* ctx)
 
     ctx->ext_launched = false;
     const bool probe = ctx->blur_probe;
+    if (ctx->flow_on) {
+        // k_pyramid_flow: octave 0's levels by launches first when the plan starts at octave 1 (POPSIFT_FLOW=2), then every
+        // remaining blur level of the frame in ONE launch with device-side dependencies; the extrema scans follow in
+        // psx_find_extrema
+        for (int level = 1; ctx->flow_first > 0 && level < P.L; level++) {
+            hipEvent_t e0 = probe ? ctx->ev_blur[2 * (level - 1)] : nullptr, e1 = probe ? ctx->ev_blur[2 * (level - 1) + 1] : nullptr;
+            const int rc = launch_blur_level(ctx, 0, level, e0, e1);
+            if (rc != PSX_OK) return rc;
+        }
+        const bool pf = probe && ctx->flow_first == 0;
+        int* state = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->d_cnt) + CNT_BLOCK);
+        PSX_HIP(psx_launch_flow(ctx->d_flow_jobs, ctx->d_flow_items, ctx->flow_nitems, state, &ctx->d_cnt->flow_error,
+                                ctx->flow_grid, ctx->flow_ld, ctx->stream, pf ? ctx->ev_blur[0] : nullptr, pf ? ctx->ev_blur[1] : nullptr,
+                                ctx->d_flow_trace));
+        if (probe) {
+            if (pf) { ctx->blur_probe_n = 1; ctx->blur_probe_bytes = ctx->flow_algo_bytes; }
+            else    { ctx->blur_probe_n = P.L - 1; ctx->blur_probe_bytes = 8.0 * (double)P.oct[0].w * P.oct[0].h; }
+        }
+        if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        return PSX_OK;
+    }
     // Diagonal schedule.  Level l of octave o only needs level l-1 of the same octave, and level 0 of octave o+1
     // is written by the launch of level D = L-3 of octave o; so octave o+1 may start D launch slots after octave
     // o, and (o+1, l) then shares ONE launch with (o, l+D) -- if the two planes fit one round of resident
@@ -1014,6 +1080,7 @@ static int fetch_counts(psx_ctx* ctx)
             ctx->h_cnt->ext_total = ctx->h_xcnt[0];
             ctx->h_cnt->ori_total = ctx->h_xcnt[1];
             raw = ctx->h_xcnt[2];
+            ctx->h_cnt->flow_error = ctx->h_xcnt[3];
             ctx->counts_partial = true;
         } else {
             PSX_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(PsxCounters), hipMemcpyDeviceToHost, ctx->stream));
@@ -1021,6 +1088,9 @@ static int fetch_counts(psx_ctx* ctx)
             raw = ctx->h_cnt->ori_raw;
             ctx->counts_partial = false;
         }
+        // k_pyramid_flow gave up on a dependency wait (never in a correct run): the planes, hence the features, are invalid
+        if (ctx->h_cnt->flow_error != 0)
+            return fail(ctx, PSX_ERR_STATE, "the pyramid kernel ran into the bound of a device-side dependency wait: the frame is invalid");
         if (raw <= ctx->hp.ori_capacity || attempt == 1) break;
         int rc = regrow_descriptors(ctx, raw);
         if (rc != PSX_OK) return rc;
@@ -1382,6 +1452,29 @@ int psx_blur_probe_times(psx_ctx* ctx, float* ms, int capacity, int* n, double* 
     for (int i = 0; i < ctx->blur_probe_n && i < capacity; i++)
         PSX_HIP(hipEventElapsedTime(&ms[i], ctx->ev_blur[2 * i], ctx->ev_blur[2 * i + 1]));
     if (bytes_per_launch) *bytes_per_launch = ctx->blur_probe_bytes;
+    return PSX_OK;
+}
+
+// Measurement: one pyramid build with k_pyramid_flow recording, per work item, the 100 MHz wall clock at dequeue /
+// dependencies met / arithmetic done / published, a word (octave << 40 | level << 32 | chunk << 16 | strip) and the
+// workgroup: 6 int64 per item, in ticket order.  *nitems = items of the plan (0: the flow kernel is not in use).
+int psx_flow_trace(psx_ctx* ctx, long long* host_out, int capacity_items, int* nitems)
+{
+    if (!ctx || !nitems) return PSX_ERR_INVALID;
+    *nitems = ctx->flow_on ? ctx->flow_nitems : 0;
+    if (!ctx->flow_on || host_out == nullptr || capacity_items < ctx->flow_nitems) return PSX_OK;
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t bytes = sizeof(long long) * 6 * (size_t)ctx->flow_nitems;
+    PSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_flow_trace), bytes));
+    (void)hipMemset(ctx->d_flow_trace, 0, bytes);
+    int rc = psx_build_pyramid(ctx);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(host_out, ctx->d_flow_trace, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(ctx->d_flow_trace);
+    ctx->d_flow_trace = nullptr;
+    if (rc != PSX_OK) return rc;
+    PSX_HIP(e);
     return PSX_OK;
 }
 

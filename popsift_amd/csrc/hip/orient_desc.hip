@@ -479,7 +479,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan(const PsxParams* __restrict__ 
         cnt->ext_total = total;
         cnt->ori_total = ori_total;
         cnt->ori_raw = min(grand, rule);           // what the frame needs: the host grows the descriptor buffers up to it
-        if (X.counts != nullptr) { X.counts[0] = total; X.counts[1] = ori_total; X.counts[2] = min(grand, rule); }
+        if (X.counts != nullptr) { X.counts[0] = total; X.counts[1] = ori_total; X.counts[2] = min(grand, rule); X.counts[3] = cnt->flow_error; }
     }
 }
 

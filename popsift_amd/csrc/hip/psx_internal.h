@@ -78,7 +78,7 @@ struct PsxCounters {
     int ext_total;
     int ori_total;
     int ori_raw;                   // orientations before the clamp to ori_capacity
-    int pad;
+    int flow_error;                // k_pyramid_flow: a dependency wait ran into its bound (the frame is invalid)
     int iext_ct[PSX_MAX_OCTAVES];  // initial extrema per octave before the grid filter (set by k_gf_apply)
 };
 
@@ -111,6 +111,42 @@ int psx_blur_grid(int W, int H, int span);
 bool psx_blur_pair_ok(int W1, int H1, int W2, int H2, int span, int resident_marching);
 hipError_t psx_launch_blur2(const PsxBlurJob& a, const PsxBlurJob& b, hipStream_t s,
                             hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// ---- k_pyramid_flow: every plane-to-plane blur of a frame in ONE launch (pyramid.hip) ----------------------------------
+// Work items = (job = (octave, level), 64-column strip, chunk of rows); a persistent grid takes tickets in a host-computed
+// topological order; an item may start when the chunks of the source plane that hold its input rows are complete (one
+// counter per (job, chunk), bumped by each strip's workgroup after it has drained its write-through stores).
+struct PsxFlowJob {                 // 256 bytes, device resident, read with scalar loads
+    const float* src; float* dst; float* half_dst;
+    int W, H, pitch, half_pitch;
+    int nstrips, chunk_rows, nchunks, rsel;     // rsel: index into the radii the kernel is instantiated for
+    int cnt_off;                    // first chunk counter of this job
+    int dep_cnt_off;                // first chunk counter of the job that writes src (-1: src is complete before the launch)
+    int dep_need;                   // counter value that means "chunk complete" (= strips of the producing job)
+    int octave, level;
+    int pad[13];
+    PsxTaps taps;
+};
+static_assert(sizeof(PsxFlowJob) == 256, "PsxFlowJob layout");
+struct PsxFlowItem { unsigned short job, strip, chunk, dep_c0, dep_c1, pad0, pad1, pad2; };   // 16 bytes
+#define PSX_FLOW_SHARDS 8           // ticket counters (one per workgroup class blockIdx & 7), each on its own 128-byte line
+#define PSX_FLOW_HEAD_INTS (PSX_FLOW_SHARDS * 32)
+#define PSX_FLOW_MAX_COUNTERS 4096
+#define PSX_FLOW_CNT_STRIDE 32      // ints between two chunk counters: one counter per 128-byte line
+struct PsxFlowPlan {
+    int njobs, nitems, ncounters, grid;
+    PsxFlowJob*  jobs;              // host arrays (malloc), owned by the caller
+    PsxFlowItem* items;
+};
+// jobs: the blur levels 1..L-1 of the octaves first_octave..; false when the configuration is outside what the kernel is
+// instantiated for (a radius above 13, too many chunk counters): the caller keeps the launch-per-level schedule
+bool psx_flow_plan(const PsxParams& P, const float* inc_filter, const int* inc_span, int first_octave,
+                   int resident_blocks, int order, PsxFlowPlan* out);
+// state: PSX_FLOW_HEAD_INTS ticket words + ncounters * PSX_FLOW_CNT_STRIDE ints of chunk counters, zeroed before the launch; err: set to 1 by a workgroup
+// whose dependency wait ran into its bound (never in a correct run)
+hipError_t psx_launch_flow(const PsxFlowJob* d_jobs, const PsxFlowItem* d_items, int nitems, int* d_state, int* d_err,
+                           int grid, int ldmode, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                           long long* trace = nullptr);
+
 // every non-default branch of Pyramid::build_pyramid (pyramid_alt.hip)
 struct PsxAltArgs {
     const PsxParams* hp;

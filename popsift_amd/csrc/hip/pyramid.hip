@@ -25,8 +25,13 @@
 
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <queue>
+#include <string>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -62,7 +67,9 @@ struct BlurArgs {
 // the same chain on two adjacent columns at once (v_pk_fma_f32): v[j] = (T[.][c], T[.][c+1])
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 #define LDS_AS __attribute__((address_space(3)))
+#define GLOBAL_AS __attribute__((address_space(1)))
 __device__ __forceinline__ v2f pk_fma(v2f a, float g, v2f c)
 {
     return __builtin_elementwise_fma(a, (v2f){g, g}, c);
@@ -135,18 +142,24 @@ __device__ __forceinline__ void vfilter2x4_km(const v2f* v, const PsxTaps& tp, v
     for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i], tp.g[0], o[i]);
 }
 
-template <int R, bool LEVEL0, bool DEFER>
-__device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
+// FLOW (k_pyramid_flow, the whole-pyramid kernel with device-side dependencies): 0 = an ordinary launch; 1 = every store is a
+// system-scope (write-through) store, so that a dependent workgroup of the SAME launch may read the rows once this
+// workgroup has drained its stores and bumped the chunk counter, plain loads; 2 = as 1 and the staging loads bypass the
+// vector L1 (buffer_load ... sc1: MI355X_MICROARCH.md "Valid forms": sc0 sc1 stores + sc1 loads on both sides).
+template <int R, bool LEVEL0, bool DEFER, int FLOW = 0>
+__device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid, float* const s_stage, float* const s_ring, const int t)
 {
     using G = Geom2<R>;
     constexpr int HALO = G::HALO, SW4 = G::SW4, NLD = G::NLD, SWA = G::SWA, RING = G::RING;
     constexpr int VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS;
     constexpr bool LAST_PARTIAL = (BR * SW4) % NT != 0;     // only the last staging slot can be empty
     constexpr bool FAST_ROWS = R < 13;
-    __shared__ __attribute__((aligned(16))) float s_stage[BR * SWA];
-    __shared__ __attribute__((aligned(16))) float s_ring[(RING + MIRROR) * RS];
 
-    const int t     = threadIdx.x;
+    // explicitly global: in k_pyramid_flow the pointers come out of a job record in memory and would otherwise be
+    // generic (flat_load / flat_store); for kernel arguments the casts change nothing
+    const GLOBAL_AS float* const gsrc = (const GLOBAL_AS float*)a.src;
+    GLOBAL_AS float* const gdst = (GLOBAL_AS float*)a.dst;
+    GLOBAL_AS float* const ghalf = (GLOBAL_AS float*)a.half_dst;
     const int strip = lid % a.nstrips;
     const int chunk = lid / a.nstrips;
     const int x0    = strip * TW;
@@ -199,12 +212,15 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
     auto run = [&](auto interior_c) {
         constexpr bool INTERIOR = decltype(interior_c)::value;
         v4f pre[NLD];
+        float pre_l[INTERIOR ? 1 : NLD], pre_r[INTERIOR ? 1 : NLD];     // edge strips: the staged rows' first / last valid pixel
+        // FLOW == 2: the source plane as a raw buffer (base = plane, 32-bit byte offsets), loads with cache policy sc1
+        auto src_rsrc = [&]() { return __builtin_amdgcn_make_buffer_rsrc((float*)gsrc, 0, 0x7fffffff, 0x00020000); };
         auto issue = [&](int k) {
             const int ybase = Y0 - R + k * BR;
             // workgroup uniform: every staged row of this step exists (all but the first / last chunk of a plane).
             // Not at R >= 13: the extra per-thread offsets do not fit into 128 VGPRs there.
             const bool rows_exist = FAST_ROWS && ybase >= 0 && ybase + BR <= a.H;
-            const char* step_base = reinterpret_cast<const char*>(a.src + (ptrdiff_t)ybase * a.src_pitch);
+            const GLOBAL_AS char* step_base = reinterpret_cast<const GLOBAL_AS char*>(gsrc + (ptrdiff_t)ybase * a.src_pitch);
 #pragma unroll
             for (int j = 0; j < NLD; j++) {
                 if (j < NLD - 1 || last_on) {
@@ -215,18 +231,36 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
                     if (INTERIOR) {
                         if (rows_exist) {
                             // no clamp: uniform row base (scalar) + the thread's step-invariant byte offset
-                            pre[j] = *reinterpret_cast<const v4f*>(step_base + st_off[j]);
+                            if constexpr (FLOW == 2) {
+                                const v4u q = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc(), st_off[j], ybase * a.src_pitch * 4, 16);
+                                __builtin_memcpy(&pre[j], &q, 16);
+                            } else pre[j] = *reinterpret_cast<const GLOBAL_AS v4f*>(step_base + st_off[j]);
                         } else {
                             const unsigned off = (unsigned)(y * a.src_pitch + st_x[j]) * 4u;
-                            pre[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(a.src) + off);
+                            if constexpr (FLOW == 2) {
+                                const v4u q = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc(), off, 0, 16);
+                                __builtin_memcpy(&pre[j], &q, 16);
+                            } else pre[j] = *reinterpret_cast<const GLOBAL_AS v4f*>(reinterpret_cast<const GLOBAL_AS char*>(gsrc) + off);
                         }
                     } else {
-                        const float* rp = a.src + (size_t)y * a.src_pitch;
-                        const int x = st_x[j];
-                        pre[j].x = rp[psx_clampi(x + 0, 0, a.src_width - 1)];
-                        pre[j].y = rp[psx_clampi(x + 1, 0, a.src_width - 1)];
-                        pre[j].z = rp[psx_clampi(x + 2, 0, a.src_width - 1)];
-                        pre[j].w = rp[psx_clampi(x + 3, 0, a.src_width - 1)];
+                        // Edge strip (the first / last of a plane): the 16-byte slot at the clamped in-row position, plus
+                        // the row's first / last valid pixel (one address per row: broadcast loads); the columns outside the
+                        // plane are patched in commit(), when the loads have landed -- nothing here waits.  (Four clamped
+                        // dword loads per slot made the two edge strips, for which every dependent workgroup of the
+                        // whole-pyramid kernel waits and with which a level ends, ~1.5-2x slower than the other 58.)
+                        const int xc = psx_clampi(st_x[j], 0, a.src_pitch - 4);
+                        const unsigned rb = (unsigned)(y * a.src_pitch) * 4u;
+                        if constexpr (FLOW == 2) {
+                            const v4u u = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc(), rb + (unsigned)xc * 4u, 0, 16);
+                            __builtin_memcpy(&pre[j], &u, 16);
+                            const unsigned ul = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc(), rb, 0, 16);
+                            const unsigned ur = __builtin_amdgcn_raw_buffer_load_b32(src_rsrc(), rb + (unsigned)(a.src_width - 1) * 4u, 0, 16);
+                            __builtin_memcpy(&pre_l[j], &ul, 4); __builtin_memcpy(&pre_r[j], &ur, 4);
+                        } else {
+                            pre[j] = *reinterpret_cast<const GLOBAL_AS v4f*>(reinterpret_cast<const GLOBAL_AS char*>(gsrc) + rb + (unsigned)xc * 4u);
+                            const GLOBAL_AS float* rp = gsrc + (size_t)y * a.src_pitch;
+                            pre_l[j] = rp[0]; pre_r[j] = rp[a.src_width - 1];
+                        }
                     }
                 }
             }
@@ -234,7 +268,18 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
         auto commit = [&]() {
 #pragma unroll
             for (int j = 0; j < NLD; j++)
-                if (j < NLD - 1 || last_on) *reinterpret_cast<v4f*>(&s_stage[st_lds[j]]) = pre[j];
+                if (j < NLD - 1 || last_on) {
+                    v4f q = pre[j];
+                    if constexpr (!INTERIOR) {
+                        // xc == x whenever any of the slot's four columns is inside the plane (x is a multiple of 4)
+                        const int x = st_x[j];
+                        q.x = x + 0 < 0 ? pre_l[j] : (x + 0 > a.src_width - 1 ? pre_r[j] : q.x);
+                        q.y = x + 1 < 0 ? pre_l[j] : (x + 1 > a.src_width - 1 ? pre_r[j] : q.y);
+                        q.z = x + 2 < 0 ? pre_l[j] : (x + 2 > a.src_width - 1 ? pre_r[j] : q.z);
+                        q.w = x + 3 < 0 ? pre_l[j] : (x + 3 > a.src_width - 1 ? pre_r[j] : q.w);
+                    }
+                    *reinterpret_cast<v4f*>(&s_stage[st_lds[j]]) = q;
+                }
         };
 
         // Results of the vertical pass are not stored at once: on gfx950 loads and stores share one counter
@@ -251,26 +296,34 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid)
             if (a.dbg & 2) return;
 #endif
             const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
-            char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
+            GLOBAL_AS char* drow = reinterpret_cast<GLOBAL_AS char*>(gdst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
 #ifdef PSX_PHASE_TIMING
-            if (a.dbg & 4) drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(64 + (blockIdx.x & 7) * 40) * a.pitch);   // stores stay in L2
+            if (a.dbg & 4) drow = reinterpret_cast<GLOBAL_AS char*>(gdst + (ptrdiff_t)(64 + (blockIdx.x & 7) * 40) * a.pitch);   // stores stay in L2
 #endif
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int r_out = r_out0 + i;
                 if (r_out >= Y0 && r_out < Y1 && v_xok) {
-                    char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
+                    GLOBAL_AS char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
                     if (v_pair) {
                         // system-scope store (sc0 sc1): written through the XCD's L2 while the kernel runs.  Plain
                         // stores left ~33 MB of dirty lines to be written back after the last wave, inside the
                         // kernel's duration (17.6 -> 16.9 us per octave-0 launch); agent scope measured the same,
                         // non-temporal stores 4 % slower (the next level reads these rows).
                         unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
-                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    } else *reinterpret_cast<float*>(di) = pend[i].x;
+                        __hip_atomic_store(reinterpret_cast<GLOBAL_AS unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else if constexpr (FLOW != 0) {
+                        const float px_ = pend[i].x; unsigned bits; __builtin_memcpy(&bits, &px_, 4);
+                        __hip_atomic_store(reinterpret_cast<GLOBAL_AS unsigned*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else *reinterpret_cast<GLOBAL_AS float*>(di) = pend[i].x;
                     // get_by_2_pick_every_second: rows and columns 0,2,4,.. (v_x is even)
-                    if (a.half_dst != nullptr && (r_out & 1) == 0)
-                        a.half_dst[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
+                    if (a.half_dst != nullptr && (r_out & 1) == 0) {
+                        GLOBAL_AS float* hd = ghalf + (size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1);
+                        if constexpr (FLOW != 0) {
+                            const float px_ = pend[i].x; unsigned bits; __builtin_memcpy(&bits, &px_, 4);
+                            __hip_atomic_store(reinterpret_cast<GLOBAL_AS unsigned*>(hd), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        } else *hd = pend[i].x;
+                    }
                 }
             }
         };
@@ -589,7 +642,10 @@ __global__ __launch_bounds__(NT, (dma_wg_per_cu<R, NBUF, RINGROWS>())) void k_bl
 template <int R, bool LEVEL0, bool DEFER = true>
 __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur(BlurArgs a)
 {
-    blur_body<R, LEVEL0, DEFER>(a, xcd_remap(blockIdx.x, gridDim.x));
+    using G = Geom2<R>;
+    __shared__ __attribute__((aligned(16))) float s_stage[BR * G::SWA];
+    __shared__ __attribute__((aligned(16))) float s_ring[(G::RING + G::MIRROR) * G::RS];
+    blur_body<R, LEVEL0, DEFER>(a, xcd_remap(blockIdx.x, gridDim.x), s_stage, s_ring, threadIdx.x);
 }
 
 // Two independent planes in one launch (the diagonal schedule of psx_build_pyramid: level l of octave o
@@ -598,11 +654,148 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
 template <int R>
 __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur2(BlurArgs a, BlurArgs b, int na)
 {
+    using G = Geom2<R>;
+    __shared__ __attribute__((aligned(16))) float s_stage[BR * G::SWA];
+    __shared__ __attribute__((aligned(16))) float s_ring[(G::RING + G::MIRROR) * G::RS];
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     // two inlined copies: selecting the arguments through a pointer moves the taps out of the preloaded
     // kernel-argument SGPRs (120 bytes of VGPR spills at R = 13)
-    if (lid < na) blur_body<R, false, true>(a, lid);
-    else          blur_body<R, false, true>(b, lid - na);
+    if (lid < na) blur_body<R, false, true>(a, lid, s_stage, s_ring, threadIdx.x);
+    else          blur_body<R, false, true>(b, lid - na, s_stage, s_ring, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pyramid_flow: every plane-to-plane blur of a frame (levels 1..L-1 of every octave, the decimations riding on the
+// level L-3 stores as before) in ONE launch.  The launch-per-level schedule pays a kernel boundary per level -- ~19 of
+// them per 1080p frame, and octaves 1-4 (a third of the pixels) are a chain of ~14 launches of ~5 us each that cannot fill
+// the chip.  Here a persistent grid (4 workgroups per CU) pulls work items
+//     (job = (octave, level), 64-column strip, chunk of rows)            -- exactly the (strip, chunk) of one k_blur workgroup
+// from a list the host has sorted topologically (psx_flow_plan); an item starts when the chunks of its SOURCE plane that
+// hold its input rows (+- R) are complete.  Mechanics (MI355X_MICROARCH.md, "Workgroup dispatch ... inter-workgroup
+// visibility" and the price list):
+//   * tickets: PSX_FLOW_SHARDS counters, one per class blockIdx & 7, each on its own 128-byte line (a single word
+//     saturates at ~88 dequeues / us; 1024 workgroups starting together would queue for 12 us); class c owns the items
+//     c, c + 8, c + 16, .. of the ONE global order and takes them in order.  Deadlock freedom needs no co-residency of
+//     the whole grid: the smallest unfinished item is either running (its dependencies are smaller, hence done) or the
+//     next ticket of its class, which the class's oldest workgroup takes as soon as it finishes a smaller item.  The
+//     next ticket is requested before the current item is worked on (its latency hides behind the item).
+//   * publish: the body's stores are system-scope (write-through, FLOW != 0); every thread drains its stores
+//     (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one lane bumps the chunk counter (agent-scope atomic).
+//   * wait: lanes of wave 0 poll the <= 64 chunk counters of the item with agent-scope relaxed loads (+ s_sleep), the
+//     workgroup meets at a barrier, then reads the plane: sc1 loads (LD = 2) or plain loads (LD = 1: no line of the
+//     source rows can be resident in this CU's L1 or this XCD's L2 before they were complete -- a frame writes every
+//     plane address once, lines are never shared between producers, and caches are invalidated at kernel start).
+//   * every wait is bounded; a workgroup that runs into the bound raises PsxCounters::flow_error and carries on, so a
+//     protocol bug ends in an error code from psx_counts, never in a hung GPU.
+// The arithmetic is blur_body's, instruction for instruction: planes stay bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int FLOW_NR = 5;
+constexpr int flow_radius(int i) { return i == 0 ? 5 : i == 1 ? 7 : i == 2 ? 8 : i == 3 ? 10 : 13; }
+constexpr int FLOW_LDS_FLOATS = BR * Geom2<13>::SWA + (Geom2<13>::RING + Geom2<13>::MIRROR) * Geom2<13>::RS;
+constexpr int FLOW_SPIN_LIMIT = 1 << 19;           // polls of ~2 us each: about a second
+
+template <int R, int LD>
+__device__ __forceinline__ void flow_run(const PsxFlowJob* __restrict__ jb, const int lid, float* s_lds)
+{
+    using G = Geom2<R>;
+    static_assert(BR * G::SWA + (G::RING + G::MIRROR) * G::RS <= FLOW_LDS_FLOATS, "flow LDS too small");
+    BlurArgs a;
+    // pointers loaded from memory are generic to the compiler (flat_load / flat_store, which also count on lgkmcnt);
+    // the round trip through address space 1 tells it they are global, like kernel arguments
+    a.src = (const float*)(const GLOBAL_AS float*)jb->src;
+    a.dst = (float*)(GLOBAL_AS float*)jb->dst;
+    a.half_dst = (float*)(GLOBAL_AS float*)jb->half_dst;
+    a.W = jb->W; a.H = jb->H; a.pitch = jb->pitch; a.half_pitch = jb->half_pitch;
+    a.src_pitch = jb->pitch; a.src_xoff = 0; a.src_width = jb->W;
+    a.nstrips = jb->nstrips; a.chunk_rows = jb->chunk_rows;
+#pragma unroll
+    for (int i = 0; i <= R; i++) a.taps.g[i] = jb->taps.g[i];
+#ifdef PSX_PHASE_TIMING
+    a.dbg = 0;
+#endif
+    // the thread index is laundered per item: otherwise the compiler hoists the thread-invariant geometry of ALL five
+    // bodies out of the persistent loop and spills it (200 bytes of scratch per thread)
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    blur_body<R, false, true, LD>(a, lid, s_lds, s_lds + BR * G::SWA, t);
+}
+
+template <int LD>
+__global__ __launch_bounds__(NT, 4) void k_pyramid_flow(const PsxFlowJob* __restrict__ jobs, const PsxFlowItem* __restrict__ items,
+                                                        int nitems, int* __restrict__ state, int* __restrict__ err, int dbg,
+                                                        long long* __restrict__ trace)
+{
+    __shared__ __attribute__((aligned(16))) float s_lds[FLOW_LDS_FLOATS];
+    __shared__ int s_ticket;
+    const int cls = blockIdx.x & (PSX_FLOW_SHARDS - 1);
+    int* const head = state + cls * 32;
+    int* const cnt = state + PSX_FLOW_HEAD_INTS;
+    int next = 0;
+    if (threadIdx.x == 0) next = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (threadIdx.x == 0) {
+            s_ticket = next * PSX_FLOW_SHARDS + cls;
+            if (s_ticket < nitems) next = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next round
+        }
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+        if (ticket >= nitems) break;
+        long long tr0 = 0, tr1 = 0, tr2 = 0;
+        if (trace != nullptr) tr0 = wall_clock64();
+        const PsxFlowItem it = items[ticket];
+        const PsxFlowJob* jb = jobs + it.job;
+        const int pub = __builtin_amdgcn_readfirstlane(jb->cnt_off + (int)it.chunk);   // kept across the body: no reload in front of the publish
+        // ---- wait for the source rows ----
+        const int dep0 = jb->dep_cnt_off;
+        if (dep0 >= 0 && !(dbg & 1)) {
+            if (threadIdx.x < 64) {
+                const int nd = (int)it.dep_c1 - (int)it.dep_c0 + 1;
+                const int need = jb->dep_need;
+                const bool mine = (int)threadIdx.x < nd;
+                // every counter has a 128-byte line to itself: a thousand workgroups polling (and sixty publishing into)
+                // counters that share a line serialise on it at ~11 ns per access -- tens of microseconds per level
+                const int* c = cnt + (size_t)(dep0 + it.dep_c0 + (mine ? (int)threadIdx.x : 0)) * PSX_FLOW_CNT_STRIDE;
+                int spins = 0;
+                for (;;) {
+                    const int v = mine ? __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                    if (__ballot(v < need) == 0ull) break;
+                    // back off: the first polls come quickly (a producer that is about to finish), later ones every ~2 us
+                    if (spins < 4) __builtin_amdgcn_s_sleep(8); else if (spins < 16) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(80);
+                    ++spins;
+                    // bounded: ~1 s on this wait, or another workgroup has already given up (then everybody does at once)
+                    if ((spins & 255) == 0 &&
+                        (spins > FLOW_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        if (threadIdx.x == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (trace != nullptr) tr1 = wall_clock64();
+        // ---- the item: one (strip, chunk) of the job's plane, as one k_blur workgroup would do it ----
+        const int lid = (int)it.chunk * jb->nstrips + (int)it.strip;
+        if (!(dbg & 2))
+        switch (jb->rsel) {
+            case 0:  flow_run<flow_radius(0), LD>(jb, lid, s_lds); break;
+            case 1:  flow_run<flow_radius(1), LD>(jb, lid, s_lds); break;
+            case 2:  flow_run<flow_radius(2), LD>(jb, lid, s_lds); break;
+            case 3:  flow_run<flow_radius(3), LD>(jb, lid, s_lds); break;
+            default: flow_run<flow_radius(4), LD>(jb, lid, s_lds); break;
+        }
+        if (trace != nullptr) tr2 = wall_clock64();
+        // ---- publish: my stores have reached memory; everybody's have; one lane tells the world ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt + (size_t)pub * PSX_FLOW_CNT_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (trace != nullptr && threadIdx.x == 0) {
+            // measurement only (psx_flow_trace): 100 MHz wall clock at dequeue / dependencies met / arithmetic done / published
+            long long* r = trace + (size_t)ticket * 6;
+            r[0] = tr0; r[1] = tr1; r[2] = tr2; r[3] = wall_clock64();
+            r[4] = ((long long)jb->octave << 40) | ((long long)jb->level << 32) | ((long long)it.chunk << 16) | it.strip;
+            r[5] = (long long)blockIdx.x;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1206,6 +1399,312 @@ hipError_t psx_launch_blur2(const PsxBlurJob& a, const PsxBlurJob& b, hipStream_
     if (R <= 22) return launch_blur2_r<22>(a, b, s, ev0, ev1);
     if (R <= 30) return launch_blur2_r<30>(a, b, s, ev0, ev1);
     return hipErrorInvalidValue;
+}
+
+// ---- k_pyramid_flow: host side ------------------------------------------------------------------------------------
+// marching steps per work item of octave o (0 = the chunking of the launch-per-level schedule)
+static int flow_steps(int o)
+{
+    static const std::vector<int> tab = [] {
+        std::vector<int> v;
+        const char* e = getenv("POPSIFT_FLOW_STEPS");
+        std::string t = e ? e : "0,0,1";
+        size_t p = 0;
+        while (p <= t.size()) {
+            const size_t q = t.find(',', p);
+            v.push_back(atoi(t.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
+            if (q == std::string::npos) break;
+            p = q + 1;
+        }
+        if (v.empty()) v.push_back(0);
+        return v;
+    }();
+    return tab[(size_t)std::min<int>(o, (int)tab.size() - 1)];
+}
+
+bool psx_flow_plan(const PsxParams& P, const float* inc_filter, const int* inc_span, int first_octave,
+                   int resident_blocks, int order, PsxFlowPlan* out)
+{
+    const int L = P.L, nlev = L - 1;
+    const int noct = P.num_octaves - first_octave;
+    if (noct <= 0 || nlev <= 0) return false;
+    int rsel[PSX_GAUSS_LEVELS];
+    for (int l = 1; l < L; l++) {
+        const int R = inc_span[l] - 1;
+        int i = 0;
+        while (i < FLOW_NR && flow_radius(i) < R) i++;
+        if (i == FLOW_NR) return false;                       // a radius the flow kernel is not instantiated for
+        rsel[l] = i;
+    }
+    const int njobs = noct * nlev;
+    std::vector<PsxFlowJob> jobs((size_t)njobs);
+    int ncnt = 0;
+    size_t nitems = 0;
+    for (int o = first_octave; o < P.num_octaves; o++)
+        for (int l = 1; l < L; l++) {
+            PsxFlowJob& j = jobs[(size_t)(o - first_octave) * nlev + (l - 1)];
+            memset(&j, 0, sizeof(j));
+            const PsxOctave& oc = P.oct[o];
+            j.src = oc.data + (size_t)(l - 1) * oc.plane;
+            j.dst = oc.data + (size_t)l * oc.plane;
+            if (l == L - 3 && o + 1 < P.num_octaves) { j.half_dst = P.oct[o + 1].data; j.half_pitch = P.oct[o + 1].pitch; }
+            j.W = oc.w; j.H = oc.h; j.pitch = oc.pitch;
+            j.nstrips = (oc.w + TW - 1) / TW;
+            j.rsel = rsel[l];
+            chunking(oc.w, oc.h, flow_radius(j.rsel), j.chunk_rows, j.nchunks);
+            // The octaves that cannot fill the chip are a CHAIN of dependent levels (o+1 starts when level L-3 of o is
+            // done): what counts there is the latency of one item, i.e. its number of marching steps, not the warm-up rows
+            // it recomputes.  POPSIFT_FLOW_STEPS="s0,s1,s2,.." overrides the steps per item of octave 0, 1, 2, .. (0 = keep)
+            {
+                const int so = flow_steps(o - 0);
+                if (so > 0) {
+                    int cr = so * BR - 2 * flow_radius(j.rsel);
+                    if (cr < 4) cr = 4;
+                    if (cr > oc.h) cr = oc.h;
+                    j.chunk_rows = cr; j.nchunks = (oc.h + cr - 1) / cr;
+                }
+            }
+            j.cnt_off = ncnt; ncnt += j.nchunks;
+            j.dep_cnt_off = -1; j.dep_need = 0;
+            j.octave = o; j.level = l;
+            for (int k = 0; k < PSX_GAUSS_ALIGN; k++) j.taps.g[k] = inc_filter[l * PSX_GAUSS_ALIGN + k];
+            nitems += (size_t)j.nstrips * j.nchunks;
+            if (j.nstrips > 65535 || j.nchunks > 65535) return false;
+        }
+    if (ncnt > PSX_FLOW_MAX_COUNTERS || njobs > 65535 || nitems > (size_t)1 << 30) return false;
+
+    // dependencies at (job, chunk) granularity, and each node's earliest start: in hops (order 0) or in estimated
+    // item durations (order 1), for the ticket order
+    struct Node { int c0, c1, dep; float t0, dur; };
+    std::vector<std::vector<Node>> node((size_t)njobs);
+    for (int ji = 0; ji < njobs; ji++) {
+        PsxFlowJob& j = jobs[(size_t)ji];
+        const int o = j.octave, l = j.level;
+        const int Rt = flow_radius(j.rsel);
+        int dep = -1, scale = 1;
+        if (l >= 2) dep = ji - 1;
+        else if (o > first_octave) { dep = (o - 1 - first_octave) * nlev + (L - 3 - 1); scale = 2; }
+        if (dep >= 0) { j.dep_cnt_off = jobs[(size_t)dep].cnt_off; j.dep_need = jobs[(size_t)dep].nstrips; }
+        node[(size_t)ji].resize((size_t)j.nchunks);
+        for (int c = 0; c < j.nchunks; c++) {
+            Node& n = node[(size_t)ji][(size_t)c];
+            const int Y0 = c * j.chunk_rows, Y1 = std::min(Y0 + j.chunk_rows, j.H);
+            const int nsteps = (Y1 - Y0 + 2 * Rt + BR - 1) / BR;
+            // every row the workgroup LOADS (the staged rows of all its steps), not only the rows its outputs need: a
+            // line must never enter a cache before it is complete
+            const int lo = std::max(Y0 - Rt, 0), hi = std::min(Y0 - Rt + nsteps * BR - 1, j.H - 1);
+            n.dep = dep; n.c0 = n.c1 = 0; n.t0 = 0.0f;
+            n.dur = order == 1 ? (float)nsteps * (1.0f + (float)Rt / 16.0f) + 1.0f : 1.0f;
+            if (dep >= 0) {
+                const PsxFlowJob& d = jobs[(size_t)dep];
+                n.c0 = std::min(lo * scale, d.H - 1) / d.chunk_rows;
+                n.c1 = std::min(hi * scale, d.H - 1) / d.chunk_rows;
+                if (n.c1 - n.c0 + 1 > 64) return false;
+                for (int q = n.c0; q <= n.c1; q++) {
+                    const Node& dn = node[(size_t)dep][(size_t)q];
+                    n.t0 = std::max(n.t0, dn.t0 + dn.dur);
+                }
+            }
+        }
+    }
+    struct Key { float t; int octave, job, chunk; };
+    std::vector<Key> groups;
+    if (order == 2) {
+        // Ticket order = a simulated list schedule: `grid` processors, every item of a node (job, chunk) takes dur
+        // (a per-step cost model calibrated on MI355X traces), a node is ready when all of its producer nodes have
+        // finished, and among the ready nodes the one with the longest chain of dependents behind it goes first -- the
+        // small octaves (a chain of ~14 dependent levels) then run as soon as their rows exist instead of queueing behind
+        // octave 0's bulk.  The order of the simulated starts is topological (a consumer starts after its producers end).
+        int P_ = std::min(resident_blocks, (int)std::min<size_t>(nitems, 1u << 20));
+        if (const char* e = getenv("POPSIFT_FLOW_GRID")) { const int v = atoi(e); if (v >= PSX_FLOW_SHARDS) P_ = v; }
+        std::vector<int> base((size_t)njobs + 1, 0);
+        for (int ji = 0; ji < njobs; ji++) base[(size_t)ji + 1] = base[(size_t)ji] + jobs[(size_t)ji].nchunks;
+        const int nn = base[(size_t)njobs];
+        std::vector<std::vector<int>> rev((size_t)nn);
+        std::vector<int> pending((size_t)nn, 0), left((size_t)nn, 0);
+        std::vector<float> dur((size_t)nn), bl((size_t)nn, 0.0f), ready((size_t)nn, 0.0f), fin((size_t)nn, 0.0f);
+        for (int ji = 0; ji < njobs; ji++)
+            for (int c = 0; c < jobs[(size_t)ji].nchunks; c++) {
+                const Node& n = node[(size_t)ji][(size_t)c];
+                const int id = base[(size_t)ji] + c;
+                const PsxFlowJob& j = jobs[(size_t)ji];
+                const int Rt = flow_radius(j.rsel);
+                const int Y0 = c * j.chunk_rows, Y1 = std::min(Y0 + j.chunk_rows, j.H);
+                const int nsteps = (Y1 - Y0 + 2 * Rt + BR - 1) / BR;
+                dur[(size_t)id] = 1.6f + (1.7f + 0.02f * (float)Rt) * (float)nsteps;       // us, 4 workgroups per CU
+                left[(size_t)id] = j.nstrips;
+                if (n.dep >= 0)
+                    for (int q = n.c0; q <= n.c1; q++) { rev[(size_t)(base[(size_t)n.dep] + q)].push_back(id); pending[(size_t)id]++; }
+            }
+        for (int id = nn - 1; id >= 0; id--) {          // producers have smaller ids than their consumers
+            float m = 0.0f;
+            for (int d : rev[(size_t)id]) m = std::max(m, bl[(size_t)d]);
+            bl[(size_t)id] = dur[(size_t)id] + m;
+        }
+        typedef std::pair<float, int> FI;
+        std::priority_queue<FI, std::vector<FI>, std::greater<FI>> procs, future;      // (free time, proc) / (ready time, node)
+        std::priority_queue<FI> avail;                                               // (bottom level, node)
+        for (int p = 0; p < P_; p++) procs.push(FI(0.0f, p));
+        for (int id = 0; id < nn; id++) if (pending[(size_t)id] == 0) future.push(FI(0.0f, id));
+        size_t done = 0;
+        std::vector<int> job_of((size_t)nn), chunk_of((size_t)nn);
+        for (int ji = 0; ji < njobs; ji++) for (int c = 0; c < jobs[(size_t)ji].nchunks; c++) { job_of[(size_t)(base[(size_t)ji] + c)] = ji; chunk_of[(size_t)(base[(size_t)ji] + c)] = c; }
+        std::vector<char> emitted((size_t)nn, 0);
+        while (done < nitems) {
+            FI pr = procs.top(); procs.pop();
+            float tau = pr.first;
+            while (!future.empty() && future.top().first <= tau) { avail.push(FI(bl[(size_t)future.top().second], future.top().second)); future.pop(); }
+            if (avail.empty()) {
+                if (future.empty()) return false;            // cannot happen: the graph is acyclic
+                tau = future.top().first;
+                while (!future.empty() && future.top().first <= tau) { avail.push(FI(bl[(size_t)future.top().second], future.top().second)); future.pop(); }
+            }
+            const int id = avail.top().second;
+            // the whole node goes out as one group of consecutive tickets (its strips are spread over the classes
+            // below); its items start on the processors that free up next
+            if (!emitted[(size_t)id]) { emitted[(size_t)id] = 1; groups.push_back(Key{tau, jobs[(size_t)job_of[(size_t)id]].octave, job_of[(size_t)id], chunk_of[(size_t)id]}); }
+            const float f = tau + dur[(size_t)id];
+            fin[(size_t)id] = std::max(fin[(size_t)id], f);
+            procs.push(FI(f, pr.second));
+            done++;
+            if (--left[(size_t)id] == 0) {
+                avail.pop();
+                for (int d : rev[(size_t)id]) {
+                    ready[(size_t)d] = std::max(ready[(size_t)d], fin[(size_t)id]);
+                    if (--pending[(size_t)d] == 0) future.push(FI(ready[(size_t)d], d));
+                }
+            }
+        }
+    } else {
+    for (int ji = 0; ji < njobs; ji++)
+        for (int c = 0; c < jobs[(size_t)ji].nchunks; c++)
+            groups.push_back(Key{node[(size_t)ji][(size_t)c].t0, jobs[(size_t)ji].octave, ji, c});
+    // earliest first; among equals the deeper octave first (its chain of dependent levels is the longer one)
+    std::stable_sort(groups.begin(), groups.end(), [](const Key& a, const Key& b) {
+        if (a.t != b.t) return a.t < b.t;
+        if (a.octave != b.octave) return a.octave > b.octave;
+        if (a.job != b.job) return a.job < b.job;
+        return a.chunk < b.chunk;
+    });
+    }
+    std::vector<PsxFlowItem> items(nitems);
+    size_t base = 0;
+    for (const Key& g : groups) {
+        const PsxFlowJob& j = jobs[(size_t)g.job];
+        const Node& n = node[(size_t)g.job][(size_t)g.chunk];
+        // ticket base + p belongs to class (base + p) & 7, which is (observed) the XCD the workgroup runs on: give every
+        // class a contiguous run of strips, so that neighbouring strips -- they share halo columns -- meet in one L2
+        int per[PSX_FLOW_SHARDS] = {0}, start[PSX_FLOW_SHARDS], used[PSX_FLOW_SHARDS] = {0};
+        for (int p = 0; p < j.nstrips; p++) per[(base + (size_t)p) & (PSX_FLOW_SHARDS - 1)]++;
+        int acc = 0;
+        for (int q = 0; q < PSX_FLOW_SHARDS; q++) { start[q] = acc; acc += per[q]; }
+        for (int p = 0; p < j.nstrips; p++) {
+            const int q = (int)((base + (size_t)p) & (PSX_FLOW_SHARDS - 1));
+            PsxFlowItem& it = items[base + (size_t)p];
+            it.job = (unsigned short)g.job; it.strip = (unsigned short)(start[q] + used[q]++); it.chunk = (unsigned short)g.chunk;
+            it.dep_c0 = (unsigned short)n.c0; it.dep_c1 = (unsigned short)n.c1; it.pad0 = it.pad1 = it.pad2 = 0;
+        }
+        base += (size_t)j.nstrips;
+    }
+    out->njobs = njobs; out->nitems = (int)nitems; out->ncounters = ncnt;
+    int grid = std::min(resident_blocks, (int)((nitems + PSX_FLOW_SHARDS - 1) / PSX_FLOW_SHARDS) * PSX_FLOW_SHARDS);
+    if (const char* e = getenv("POPSIFT_FLOW_GRID")) { const int v = atoi(e); if (v >= PSX_FLOW_SHARDS) grid = v; }
+    out->grid = (grid / PSX_FLOW_SHARDS) * PSX_FLOW_SHARDS;
+    out->jobs = static_cast<PsxFlowJob*>(malloc(sizeof(PsxFlowJob) * (size_t)njobs));
+    out->items = static_cast<PsxFlowItem*>(malloc(sizeof(PsxFlowItem) * nitems));
+    if (!out->jobs || !out->items) { free(out->jobs); free(out->items); out->jobs = nullptr; out->items = nullptr; return false; }
+    memcpy(out->jobs, jobs.data(), sizeof(PsxFlowJob) * (size_t)njobs);
+    memcpy(out->items, items.data(), sizeof(PsxFlowItem) * nitems);
+    return true;
+}
+
+// Host-only self check of a plan (no device needed; tests/test_capi_cpu.py): every (job, strip, chunk) exactly once, every
+// item behind ALL items of the chunks it waits for (the ticket order is topological: the deadlock-freedom argument of
+// k_pyramid_flow rests on it), the waited-for chunks cover every source row the workgroup loads.  Returns the number of
+// items, or a negative code naming the violated invariant.  stats (optional, 4 ints): jobs, counters, grid, largest wait list.
+extern "C" int psx_flow_selfcheck(int w0, int h0, int num_octaves, int levels, const int* spans, int first_octave,
+                                  int resident_blocks, int order, int* stats)
+{
+    PsxParams P;
+    memset(&P, 0, sizeof(P));
+    P.num_octaves = num_octaves; P.levels = levels; P.L = levels + 3;
+    if (num_octaves < 1 || num_octaves > PSX_MAX_OCTAVES || P.L > PSX_GAUSS_LEVELS) return -1;
+    size_t off = 4096;
+    int w = w0, h = h0;
+    for (int o = 0; o < num_octaves; o++) {
+        PsxOctave& oc = P.oct[o];
+        oc.w = w; oc.h = h; oc.pitch = (w + 63) & ~63; oc.plane = (size_t)oc.pitch * h;
+        oc.data = reinterpret_cast<float*>(off * 4);
+        off += oc.plane * P.L;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    std::vector<float> filt((size_t)PSX_GAUSS_LEVELS * PSX_GAUSS_ALIGN, 0.0f);
+    PsxFlowPlan plan{};
+    if (!psx_flow_plan(P, filt.data(), spans, first_octave, resident_blocks, order, &plan)) return -2;
+    int rc = plan.nitems, maxwait = 0;
+    std::vector<std::vector<int>> last_pos((size_t)plan.njobs), seen((size_t)plan.njobs);
+    for (int j = 0; j < plan.njobs; j++) {
+        last_pos[(size_t)j].assign((size_t)plan.jobs[j].nchunks, -1);
+        seen[(size_t)j].assign((size_t)plan.jobs[j].nchunks * plan.jobs[j].nstrips, 0);
+    }
+    for (int p = 0; p < plan.nitems && rc > 0; p++) {
+        const PsxFlowItem& it = plan.items[p];
+        if (it.job >= plan.njobs) { rc = -3; break; }
+        const PsxFlowJob& j = plan.jobs[it.job];
+        if (it.strip >= j.nstrips || it.chunk >= j.nchunks) { rc = -3; break; }
+        int& s = seen[it.job][(size_t)it.chunk * j.nstrips + it.strip];
+        if (s++) { rc = -4; break; }
+        last_pos[it.job][it.chunk] = p;                       // positions are visited in increasing order
+    }
+    for (int j = 0; j < plan.njobs && rc > 0; j++)
+        for (int v : seen[(size_t)j]) if (v != 1) { rc = -4; break; }
+    const int nlev = P.L - 1;
+    for (int p = 0; p < plan.nitems && rc > 0; p++) {
+        const PsxFlowItem& it = plan.items[p];
+        const PsxFlowJob& j = plan.jobs[it.job];
+        const int Rt = flow_radius(j.rsel);
+        if (spans[j.level] - 1 > Rt) { rc = -5; break; }
+        const int Y0 = it.chunk * j.chunk_rows, Y1 = std::min(Y0 + j.chunk_rows, j.H);
+        const int nsteps = (Y1 - Y0 + 2 * Rt + BR - 1) / BR;
+        const int lo = std::max(Y0 - Rt, 0), hi = std::min(Y0 - Rt + nsteps * BR - 1, j.H - 1);
+        int dep = -1, scale = 1;
+        if (j.level >= 2) dep = it.job - 1;
+        else if (j.octave > first_octave) { dep = (j.octave - 1 - first_octave) * nlev + (P.L - 3 - 1); scale = 2; }
+        if ((dep >= 0) != (j.dep_cnt_off >= 0)) { rc = -6; break; }
+        if (dep < 0) continue;
+        const PsxFlowJob& d = plan.jobs[dep];
+        if (j.dep_cnt_off != d.cnt_off || j.dep_need != d.nstrips || j.src != d.dst + 0) {
+            // the source plane of a level-1 job of octave o > first is the half plane of (o - 1, L - 3), not its dst
+            if (!(scale == 2 && j.dep_cnt_off == d.cnt_off && j.dep_need == d.nstrips && j.src == d.half_dst)) { rc = -6; break; }
+        }
+        // rows lo..hi of the source = rows scale*lo .. scale*hi of the producing job's OUTPUT
+        const int need0 = std::min(lo * scale, d.H - 1) / d.chunk_rows, need1 = std::min(hi * scale, d.H - 1) / d.chunk_rows;
+        if (it.dep_c0 > need0 || it.dep_c1 < need1 || it.dep_c1 >= d.nchunks) { rc = -7; break; }
+        maxwait = std::max(maxwait, it.dep_c1 - it.dep_c0 + 1);
+        for (int c = it.dep_c0; c <= it.dep_c1; c++)
+            if (last_pos[(size_t)dep][(size_t)c] >= p) { rc = -8; break; }     // a producer sits behind its consumer
+    }
+    if (plan.grid < PSX_FLOW_SHARDS || plan.grid % PSX_FLOW_SHARDS != 0) rc = rc > 0 ? -9 : rc;
+    if (stats) { stats[0] = plan.njobs; stats[1] = plan.ncounters; stats[2] = plan.grid; stats[3] = maxwait; }
+    free(plan.jobs); free(plan.items);
+    return rc;
+}
+
+hipError_t psx_launch_flow(const PsxFlowJob* d_jobs, const PsxFlowItem* d_items, int nitems, int* d_state, int* d_err,
+                           int grid, int ldmode, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, long long* trace)
+{
+    const dim3 g(grid), b(NT);
+    const bool ext = ev0 != nullptr || ev1 != nullptr;
+    // measurement switch (results are wrong with it): 1 = no dependency waits, 2 = no arithmetic (tickets, waits and publishes only)
+    static const int dbg = [] { const char* e = getenv("POPSIFT_FLOW_DEBUG"); return e ? atoi(e) : 0; }();
+    if (ldmode == 2) {
+        if (ext) hipExtLaunchKernelGGL((k_pyramid_flow<2>), g, b, 0, s, ev0, ev1, 0, d_jobs, d_items, nitems, d_state, d_err, dbg, trace);
+        else     hipLaunchKernelGGL((k_pyramid_flow<2>), g, b, 0, s, d_jobs, d_items, nitems, d_state, d_err, dbg, trace);
+    } else {
+        if (ext) hipExtLaunchKernelGGL((k_pyramid_flow<1>), g, b, 0, s, ev0, ev1, 0, d_jobs, d_items, nitems, d_state, d_err, dbg, trace);
+        else     hipLaunchKernelGGL((k_pyramid_flow<1>), g, b, 0, s, d_jobs, d_items, nitems, d_state, d_err, dbg, trace);
+    }
+    return hipGetLastError();
 }
 
 hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s)

@@ -214,3 +214,37 @@ def test_print_gauss_tables_prints_the_tables(capfd):
         assert vals.rstrip().endswith("...") == (t["inc_span"][lvl] > 10)
     dd = out.split("level 0-filters for direct downscaling\n")[1].strip().splitlines()
     assert len(dd) == capi.MAX_OCTAVES and dd[0].split()[2] == "%2.6f:" % t["dd_sigma"][0]
+
+
+@pytest.mark.parametrize("w0,h0,octaves,first", [(3840, 2160, 5, 0), (3840, 2160, 5, 1), (8192, 8192, 6, 0), (1280, 960, 5, 0),
+                                                 (640, 480, 4, 0), (150, 122, 3, 0), (64, 64, 2, 0), (4097, 33, 3, 0), (9, 3000, 4, 0),
+                                                 (2, 2, 1, 0), (1, 128, 2, 0), (667, 503, 4, 1)])
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_pyramid_flow_plan_is_a_topological_order(w0, h0, octaves, first, order):
+    """k_pyramid_flow's host-side plan (pyramid.hip psx_flow_plan), checked without a device: every (job, strip, chunk)
+    exactly once, every consumer behind all of its producers in the ticket order (what the kernel's deadlock-freedom
+    argument rests on), wait lists that cover every source row a workgroup loads, at most 64 counters per wait."""
+    import ctypes as C
+    from popsift_amd import capi
+    L = capi.lib()
+    L.psx_flow_selfcheck.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] + [C.c_int] * 3 + [C.POINTER(C.c_int)]
+    t = capi.gauss_tables(capi.default_config())
+    spans = (C.c_int * capi.GAUSS_LEVELS)(*[int(v) for v in t["inc_span"]])
+    stats = (C.c_int * 4)()
+    n = L.psx_flow_selfcheck(w0, h0, octaves, 3, spans, first, 1024, order, stats)
+    assert n > 0, "psx_flow_selfcheck code %d" % n
+    njobs, ncnt, grid, maxwait = list(stats)
+    assert njobs == (octaves - first) * 5 and grid % 8 == 0 and 8 <= grid <= 1024 and 0 <= maxwait <= 64
+
+
+def test_pyramid_flow_plan_refuses_large_radii():
+    """A level whose radius exceeds 13 (the largest the flow kernel is instantiated for): the plan is refused and
+    psx_build_pyramid keeps the launch-per-level schedule."""
+    import ctypes as C
+    from popsift_amd import capi
+    L = capi.lib()
+    L.psx_flow_selfcheck.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] + [C.c_int] * 3 + [C.POINTER(C.c_int)]
+    spans = (C.c_int * capi.GAUSS_LEVELS)(*([6, 6, 8, 9, 11, 17] + [0] * (capi.GAUSS_LEVELS - 6)))
+    assert L.psx_flow_selfcheck(640, 480, 3, 3, spans, 0, 1024, 0, None) == -2
+    spans[5] = 14
+    assert L.psx_flow_selfcheck(640, 480, 3, 3, spans, 0, 1024, 0, None) > 0
