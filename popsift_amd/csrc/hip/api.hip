@@ -161,9 +161,10 @@ struct psx_ctx {
     hipEvent_t ev_blur[2 * PSX_GAUSS_LEVELS] = {};     // [2l], [2l+1]: begin / end of the level-(l+1) kernel
     int  blur_probe_n = 0;             // levels timed in the last extraction
     double blur_probe_bytes = 0.0;     // algorithmic bytes per timed launch (8 B per pixel of every plane the launch blurs), averaged
-    // k_pyramid_flow (POPSIFT_FLOW: 0 = one launch per level, 1 = every blur level of the frame in one launch,
-    // 2 = octave 0 by launches, octaves >= 1 in one launch)
-    int  flow_mode = 1, flow_ld = 2, flow_order = 0;
+    // k_pyramid_flow (POPSIFT_FLOW: 0 = one launch per level -- the default: the one-launch kernel measured 172 us against
+    // 190 us of launches for a single 1080p frame but -10 % throughput with several frames in flight, DESIGN.md 3.1b --,
+    // 1 = every blur level of the frame in one launch, 2 = octave 0 by launches, octaves >= 1 in one launch)
+    int  flow_mode = 0, flow_ld = 2, flow_order = 0;
     bool flow_on = false;              // a plan exists for the current size
     int  flow_first = 0, flow_nitems = 0, flow_grid = 0, flow_ncnt = 0, flow_njobs = 0;
     size_t flow_bytes = 0;             // ticket words + chunk counters, between PsxCounters and the candidate counters

@@ -1408,7 +1408,7 @@ static int flow_steps(int o)
     static const std::vector<int> tab = [] {
         std::vector<int> v;
         const char* e = getenv("POPSIFT_FLOW_STEPS");
-        std::string t = e ? e : "0,0,1";
+        std::string t = e ? e : "3,2,1";
         size_t p = 0;
         while (p <= t.size()) {
             const size_t q = t.find(',', p);

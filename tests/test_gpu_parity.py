@@ -714,3 +714,35 @@ def test_extreme_shapes(oracle, capi, w, h):
         fb, db = ctx.download()
         assert len(fb) == ref.ext_total and abs(len(db) - ref.ori_total) <= 1
         ctx.close()
+
+
+# ---- k_pyramid_flow: every blur level of a frame in one launch with device-side dependencies (opt-in, POPSIFT_FLOW) --------
+@pytest.mark.parametrize("flow,ld,steps", [("1", "2", "3,2,1"), ("1", "1", "3,2,1"), ("1", "2", "0"), ("2", "2", "0,2,1"), ("1", "2", "1,1,1")])
+def test_pyramid_flow_kernel_bit_exact(oracle, capi, monkeypatch, flow, ld, steps):
+    """The whole-pyramid kernel (pyramid.hip k_pyramid_flow; the switches are read at psx_create): a persistent grid takes
+    (octave, level, strip, chunk) items in a topological ticket order and waits on per-chunk counters for its source rows.
+    Same arithmetic as the launches: every plane bit-identical to the oracle, also when the contexts' frames alternate
+    (counters and tickets are cleared per frame) and with several contexts in flight (uneven load on the chip)."""
+    monkeypatch.setenv("POPSIFT_FLOW", flow)
+    monkeypatch.setenv("POPSIFT_FLOW_LD", ld)
+    monkeypatch.setenv("POPSIFT_FLOW_STEPS", steps)
+    cases = [(1920, 1080, 1000, dict(octaves=5, sift_mode=2)), (640, 480, 1001, dict(octaves=5, sift_mode=1, gauss_mode=3)),
+             (333, 251, 7, dict(octaves=4)), (257, 190, 3, dict(octaves=3, upscale_factor=0.0)), (65, 65, 9, dict(octaves=3)),
+             (4097, 33, 5, dict(octaves=3)), (200, 150, 21, dict(octaves=4, upscale_factor=2.0))]
+    for w, h, seed, kw in cases:
+        imgs = [synth(w, h, seed), synth(w, h, seed + 100)]
+        refs = [oracle.run_pyramid(oracle.default_config(**kw), im) for im in imgs]
+        ctxs = [capi.Context(capi.default_config(**kw)) for _ in range(3)]
+        for rep in range(3):
+            for k, ctx in enumerate(ctxs):                     # three contexts in flight, frames alternating
+                ctx.upload(imgs[(rep + k) % 2])
+                ctx.extract()
+            for k, ctx in enumerate(ctxs):
+                ref = refs[(rep + k) % 2]
+                ctx.counts()                                   # raises if a device-side wait ran into its bound
+                for o in range(ref.num_octaves):
+                    for l in range(ref.num_levels):
+                        g = ctx.dump_plane(capi.PLANE_GAUSS, o, l)
+                        assert np.array_equal(g.view(np.uint32), ref.gauss(o, l).view(np.uint32)), (w, h, rep, k, o, l)
+        for ctx in ctxs:
+            ctx.close()
