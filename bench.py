@@ -552,13 +552,17 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
     c0.set_input_tensor(frames[0])
     per_level = None
     nrep = 0
+    l0_ms = x0_ms = 0.0
     for it in range(24):
         c0.extract()
         ms, by = c0.blur_probe_times()
         if it >= 4:                                         # first frames warm caches / clocks
             per_level = ms if per_level is None else [a + b for a, b in zip(per_level, ms)]
+            a_ms, l0_by, b_ms, x0_by = c0.probe_extra_times()
+            l0_ms += a_ms; x0_ms += b_ms
             nrep += 1
     c0.enable_blur_probe(False)
+    l0_ms /= nrep; x0_ms /= nrep
     per_level = [m / nrep for m in per_level]
     avg_ms = sum(per_level) / len(per_level)
     achieved = by / (avg_ms * 1e-3) / 1e9                   # GB/s, algorithmic 8 B/pixel
@@ -584,6 +588,13 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
         "measured_copy_what": "hand-written 16 B/lane copy kernel, 1 GiB read + 1 GiB written (psx_copy_bench)",
         "isolated_replay_avg_ms": round(sum(iso) / len(iso), 5),
+        # the other two HBM-bound kernels of octave 0, the same way (stream events around the launch, in the pipeline)
+        "level0": {"kernel": "k_level0_fused (u8 input -> level 0 of octave 0)", "bytes": l0_by, "ms": round(l0_ms, 5),
+                   "achieved": round(l0_by / (l0_ms * 1e-3) / 1e9, 1) if l0_ms > 0 else None, "unit": "GB/s",
+                   "frac": round(l0_by / (l0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if l0_ms > 0 else None},
+        "extrema": {"kernel": "k_extrema (octave 0: six planes read once, DoG in registers)", "bytes": x0_by, "ms": round(x0_ms, 5),
+                    "achieved": round(x0_by / (x0_ms * 1e-3) / 1e9, 1) if x0_ms > 0 else None, "unit": "GB/s",
+                    "frac": round(x0_by / (x0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if x0_ms > 0 else None},
     }
 
     # ---- one frame at a time on one context (BASELINE config 2, "single frame") ----

@@ -295,6 +295,17 @@ int psx_stage_times(psx_ctx* ctx, float ms[4]);
  * of one launch (8 bytes per pixel: plane read once, written once). */
 int psx_time_blur(psx_ctx* ctx, int octave, int level, int reps, float* avg_ms, double* bytes);
 
+/* With the blur probe enabled: in-pipeline durations (stream events around the launch) of octave 0's level 0 and of its
+ * extrema scan in the last extraction, and their algorithmic bytes (4 B per octave-0 pixel + the input image;
+ * 4 B x (levels + 3) planes per octave-0 pixel read by the scan).  extrema_ms = 0 when the scan shared a launch. */
+int psx_probe_extra_times(psx_ctx* ctx, float* level0_ms, double* level0_bytes, float* extrema_ms, double* extrema_bytes);
+
+/* Diagnostic (tests): `rounds` hand-overs of one plain device-memory word from a kernel on one stream -- busy with
+ * pcie_words_per_thread stores per thread into mapped host memory -- to a kernel on a second stream behind an event, and
+ * back.  *stale = number of rounds in which the reader saw another round's value (0 on a stack where stream order across
+ * an event carries plain stores between kernels; the assumption every multi-stream use of this library rests on). */
+int psx_debug_cross_stream(int device, int rounds, int pcie_words_per_thread, int* stale);
+
 /* Measurement: one pyramid build with the whole-pyramid kernel (k_pyramid_flow) recording, per work item and in ticket
  * order, six int64: the 100 MHz wall clock at dequeue / dependencies met / arithmetic done / published, a word
  * (octave << 40 | level << 32 | chunk << 16 | strip) and the workgroup index.  *nitems = items of the current plan

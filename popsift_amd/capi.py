@@ -62,7 +62,7 @@ SYMBOLS = [
     "psx_set_wait_mode", "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
     "psx_host_alloc", "psx_host_free", "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_dev_write", "psx_clone_results", "psx_match", "psx_match_release", "psx_device_count", "psx_device_info", "psx_device_pci",
     "psx_enable_blur_probe", "psx_blur_probe_times", "psx_copy_bench", "psx_upload_pinned", "psx_attach_export_mapped",
-    "psx_print_gauss_tables", "psx_flow_trace",
+    "psx_print_gauss_tables", "psx_flow_trace", "psx_debug_cross_stream", "psx_probe_extra_times",
 ]
 
 _LIB = None
@@ -385,6 +385,14 @@ class Context:
         n, by = C.c_int(), C.c_double()
         self._chk(lib().psx_blur_probe_times(self._h, ms, GAUSS_LEVELS, C.byref(n), C.byref(by)))
         return [ms[i] for i in range(n.value)], by.value
+
+    def probe_extra_times(self):
+        """(level0 ms, level0 algorithmic bytes, octave-0 extrema ms, its bytes) of the last extraction (blur probe on)."""
+        L = lib()
+        L.psx_probe_extra_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        a, b, c, d = C.c_float(), C.c_double(), C.c_float(), C.c_double()
+        self._chk(L.psx_probe_extra_times(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
 
     @property
     def stream(self):

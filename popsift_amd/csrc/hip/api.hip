@@ -159,6 +159,8 @@ struct psx_ctx {
     // in-pipeline timing of the octave-0 separable-Gaussian launches (psx_enable_blur_probe)
     bool blur_probe = false;
     hipEvent_t ev_blur[2 * PSX_GAUSS_LEVELS] = {};     // [2l], [2l+1]: begin / end of the level-(l+1) kernel
+    hipEvent_t ev_x[4] = {};           // the probe also brackets octave 0's level 0 [0,1] and its extrema scan [2,3] (stream events)
+    bool probe_ext0 = false;           // octave 0's extrema scan was a launch of its own in the last extraction
     int  blur_probe_n = 0;             // levels timed in the last extraction
     double blur_probe_bytes = 0.0;     // algorithmic bytes per timed launch (8 B per pixel of every plane the launch blurs), averaged
     // k_pyramid_flow (POPSIFT_FLOW: 0 = one launch per level -- the default: the one-launch kernel measured 172 us against
@@ -490,6 +492,7 @@ int psx_destroy(psx_ctx* ctx)
     if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
     if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
     for (int i = 0; i < 2 * PSX_GAUSS_LEVELS; i++) if (ctx->ev_blur[i]) (void)hipEventDestroy(ctx->ev_blur[i]);
+    for (int i = 0; i < 4; i++) if (ctx->ev_x[i]) (void)hipEventDestroy(ctx->ev_x[i]);
     if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
     if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
@@ -780,7 +783,9 @@ int psx_build_pyramid(psx_ctx* ctx)
         a.shift = 0.5f * powf(2.0f, c.upscale_factor - 0);
     a.taps_h = taps_from(ctx->dd_filter); a.span_h = ctx->dd_span[0];
     a.taps_v = taps_from(ctx->inc_filter); a.span_v = ctx->inc_span[0];
+    if (ctx->blur_probe) PSX_HIP(hipEventRecord(ctx->ev_x[0], ctx->stream));
     PSX_HIP(psx_launch_level0(a, ctx->stream));
+    if (ctx->blur_probe) PSX_HIP(hipEventRecord(ctx->ev_x[1], ctx->stream));
 
     ctx->ext_launched = false;
     const bool probe = ctx->blur_probe;
@@ -860,9 +865,12 @@ int psx_build_pyramid(psx_ctx* ctx)
         // be.  The small octaves' scans (a few hundred tiles each, latency-bound launches) wait and share one launch.
         for (int q = 0; q < nj; q++)
             if (t - t0[jo[q]] == P.L - 1 && ctx->interleave) {
-                if (psx_extrema_tiles(P, jo[q]) >= ctx->resident_blocks)
+                if (psx_extrema_tiles(P, jo[q]) >= ctx->resident_blocks) {
+                    const bool px = probe && jo[q] == 0;
+                    if (px) PSX_HIP(hipEventRecord(ctx->ev_x[2], ctx->stream));
                     PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, jo[q], ctx->stream));
-                else
+                    if (px) { PSX_HIP(hipEventRecord(ctx->ev_x[3], ctx->stream)); ctx->probe_ext0 = true; }
+                } else
                     deferred[ndef++] = jo[q];
             }
     }
@@ -921,9 +929,12 @@ int psx_find_extrema(psx_ctx* ctx)
     if (!ctx->ext_launched) {
         int small[PSX_MAX_OCTAVES], ns = 0;
         for (int o = 0; o < ctx->hp.num_octaves; o++) {
-            if (psx_extrema_tiles(ctx->hp, o) >= ctx->resident_blocks)
+            if (psx_extrema_tiles(ctx->hp, o) >= ctx->resident_blocks) {
+                const bool px = ctx->blur_probe && o == 0;
+                if (px) PSX_HIP(hipEventRecord(ctx->ev_x[2], ctx->stream));
                 PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
-            else
+                if (px) { PSX_HIP(hipEventRecord(ctx->ev_x[3], ctx->stream)); ctx->probe_ext0 = true; }
+            } else
                 small[ns++] = o;
         }
         if (ns > 0) { int rc = launch_extrema_set(ctx, small, ns); if (rc != PSX_OK) return rc; }
@@ -1438,7 +1449,11 @@ int psx_enable_blur_probe(psx_ctx* ctx, int on)
     if (on)
         for (int i = 0; i < 2 * PSX_GAUSS_LEVELS; i++)
             if (!ctx->ev_blur[i]) PSX_HIP(hipEventCreate(&ctx->ev_blur[i]));
+    if (on)
+        for (int i = 0; i < 4; i++)
+            if (!ctx->ev_x[i]) PSX_HIP(hipEventCreate(&ctx->ev_x[i]));
     ctx->blur_probe = on != 0;
+    ctx->probe_ext0 = false;
     ctx->blur_probe_n = 0;
     return PSX_OK;
 }
@@ -1476,6 +1491,26 @@ int psx_flow_trace(psx_ctx* ctx, long long* host_out, int capacity_items, int* n
     ctx->d_flow_trace = nullptr;
     if (rc != PSX_OK) return rc;
     PSX_HIP(e);
+    return PSX_OK;
+}
+
+// The probe's two other HBM-bound kernels of octave 0, timed in the pipeline with stream events around the launch (they
+// include the gap in front of the kernel): level 0 (k_level0_fused, or k_upscale + k_blur<R, true>) and the extrema scan.
+// bytes: the algorithmic figures of SURVEY.md 8d (4 B per octave-0 pixel + the input; 24 B per octave-0 pixel).
+// extrema_ms = 0 when octave 0's scan shared a launch with other octaves (small images).
+int psx_probe_extra_times(psx_ctx* ctx, float* level0_ms, double* level0_bytes, float* extrema_ms, double* extrema_bytes)
+{
+    if (!ctx || !level0_ms || !extrema_ms) return PSX_ERR_INVALID;
+    if (!ctx->blur_probe) return fail(ctx, PSX_ERR_STATE, "the blur probe is not enabled");
+    PSX_HIP(hipSetDevice(ctx->device));
+    PSX_HIP(hipStreamSynchronize(ctx->stream));
+    const PsxParams& P = ctx->hp;
+    *level0_ms = 0.0f; *extrema_ms = 0.0f;
+    if (!ctx->alt_pyramid) PSX_HIP(hipEventElapsedTime(level0_ms, ctx->ev_x[0], ctx->ev_x[1]));
+    if (ctx->probe_ext0) PSX_HIP(hipEventElapsedTime(extrema_ms, ctx->ev_x[2], ctx->ev_x[3]));
+    const double n0 = (double)P.oct[0].w * P.oct[0].h;
+    if (level0_bytes) *level0_bytes = 4.0 * n0 + (double)ctx->in_w * ctx->in_h * (ctx->input_is_float ? 4.0 : 1.0);
+    if (extrema_bytes) *extrema_bytes = 4.0 * (double)P.L * n0;
     return PSX_OK;
 }
 

@@ -1405,20 +1405,18 @@ hipError_t psx_launch_blur2(const PsxBlurJob& a, const PsxBlurJob& b, hipStream_
 // marching steps per work item of octave o (0 = the chunking of the launch-per-level schedule)
 static int flow_steps(int o)
 {
-    static const std::vector<int> tab = [] {
-        std::vector<int> v;
-        const char* e = getenv("POPSIFT_FLOW_STEPS");
-        std::string t = e ? e : "3,2,1";
-        size_t p = 0;
-        while (p <= t.size()) {
-            const size_t q = t.find(',', p);
-            v.push_back(atoi(t.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
-            if (q == std::string::npos) break;
-            p = q + 1;
-        }
-        if (v.empty()) v.push_back(0);
-        return v;
-    }();
+    // read per plan (psx_resize), not once per process: tests switch it between contexts
+    std::vector<int> tab;
+    const char* e = getenv("POPSIFT_FLOW_STEPS");
+    std::string t = e ? e : "3,2,1";
+    size_t p = 0;
+    while (p <= t.size()) {
+        const size_t q = t.find(',', p);
+        tab.push_back(atoi(t.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
+        if (q == std::string::npos) break;
+        p = q + 1;
+    }
+    if (tab.empty()) tab.push_back(0);
     return tab[(size_t)std::min<int>(o, (int)tab.size() - 1)];
 }
 

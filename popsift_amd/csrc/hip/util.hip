@@ -90,3 +90,71 @@ done:
     (void)hipFree(src); (void)hipFree(dst);
     return rc;
 }
+
+// ---- cross-stream hand-over check (tests/test_gpu_api.py) ------------------------------------------------------------
+// Round 3's split-frame experiment (part 1 of a frame's orientation scan on stream B, part 2 on stream A behind an event,
+// both with zero-copy export) saw a result that carried only part 2's count and blamed "the cross-stream wait under load
+// with PCIe-bound stores".  This is that hand-over reduced to its mechanism: a kernel on stream A that is busy storing
+// into mapped host memory (slow PCIe stores) and whose LAST workgroup writes a word of device memory with a plain store;
+// an event; a one-workgroup kernel on stream B behind hipStreamWaitEvent that reads the word with a plain load and reports
+// it; an event back.  If every report is the value of its round, stream order across an event carries plain device-memory
+// stores between kernels on this stack (kernel-end release, kernel-start acquire), and the experiment's failure was a
+// missing edge in ITS launch order, not a scope problem of the export stores.
+namespace {
+__global__ void k_xs_producer(int* __restrict__ word, int* __restrict__ ticket, volatile int* __restrict__ host_sink, int words_per_thread, int round)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = 0; i < words_per_thread; i++) host_sink[(size_t)i * gridDim.x * blockDim.x + gid] = round + i;   // PCIe-bound
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int t = atomicAdd(ticket, 1);
+        if (t == (int)gridDim.x - 1) { *ticket = 0; *word = round; }                  // the last workgroup: a plain store
+    }
+}
+__global__ void k_xs_consumer(const int* __restrict__ word, int* __restrict__ out, int round)
+{
+    if (threadIdx.x == 0) out[round] = *word;                                          // a plain load
+}
+} // namespace
+
+extern "C" int psx_debug_cross_stream(int device, int rounds, int pcie_words_per_thread, int* stale)
+{
+    if (!stale || rounds < 1 || pcie_words_per_thread < 0) return PSX_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return PSX_ERR_HIP;
+    *stale = -1;
+    const int grid = 64, block = 256;
+    int *word = nullptr, *ticket = nullptr, *out = nullptr, *sink = nullptr, *h_out = nullptr;
+    hipStream_t sa = nullptr, sb = nullptr;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    int rc = PSX_ERR_HIP;
+    const size_t sink_words = (size_t)(pcie_words_per_thread > 0 ? pcie_words_per_thread : 1) * grid * block;
+    if (hipMalloc(reinterpret_cast<void**>(&word), 256) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&ticket), 256) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&out), sizeof(int) * (size_t)rounds) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&sink), sizeof(int) * sink_words, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h_out), sizeof(int) * (size_t)rounds, hipHostMallocDefault) != hipSuccess) goto done;
+    if (hipMemset(word, 0xff, 256) != hipSuccess || hipMemset(ticket, 0, 256) != hipSuccess || hipMemset(out, 0xff, sizeof(int) * (size_t)rounds) != hipSuccess) goto done;
+    if (hipStreamCreateWithFlags(&sa, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sb, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) goto done;
+    for (int r = 0; r < rounds; r++) {
+        if (r > 0 && hipStreamWaitEvent(sa, eb, 0) != hipSuccess) goto done;          // stream A continues behind stream B's reader
+        hipLaunchKernelGGL(k_xs_producer, dim3(grid), dim3(block), 0, sa, word, ticket, sink, pcie_words_per_thread, r);
+        if (hipEventRecord(ea, sa) != hipSuccess || hipStreamWaitEvent(sb, ea, 0) != hipSuccess) goto done;
+        hipLaunchKernelGGL(k_xs_consumer, dim3(1), dim3(64), 0, sb, word, out, r);
+        if (hipEventRecord(eb, sb) != hipSuccess) goto done;
+    }
+    if (hipStreamSynchronize(sa) != hipSuccess || hipStreamSynchronize(sb) != hipSuccess || hipGetLastError() != hipSuccess) goto done;
+    if (hipMemcpy(h_out, out, sizeof(int) * (size_t)rounds, hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    *stale = 0;
+    for (int r = 0; r < rounds; r++) if (h_out[r] != r) (*stale)++;
+    rc = PSX_OK;
+done:
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    if (sa) (void)hipStreamDestroy(sa);
+    if (sb) (void)hipStreamDestroy(sb);
+    (void)hipFree(word); (void)hipFree(ticket); (void)hipFree(out);
+    if (sink) (void)hipHostFree(sink);
+    if (h_out) (void)hipHostFree(h_out);
+    return rc;
+}

@@ -124,3 +124,108 @@ def test_auto_octaves_resolved_once_per_popsift(oracle, capi):
         assert len(fb) == ref.ext_total, (len(fb), ref.ext_total)
         assert fb["debug_octave"].max() <= first_oct - 1
         assert_parity(match_features(ref.features(), ref.descriptors(), fb, db), what="auto octaves", **budget(len(fb)))
+
+
+def _device_count(capi):
+    import ctypes as C
+    n = C.c_int()
+    capi.lib().psx_device_count.argtypes = [C.POINTER(C.c_int)]
+    assert capi.lib().psx_device_count(C.byref(n)) == 0
+    return n.value
+
+
+def test_second_device_when_present(oracle, capi):
+    """PopSift(config, mode, imode, device) with device != 0 (popsift.h:158,166-168): the C-ABI context, the C++ pipeline
+    and the per-device pinned pool on device 1, results against the oracle.  Skipped on a one-GPU box (the round-end
+    8-GPU node runs it)."""
+    if _device_count(capi) < 2:
+        pytest.skip("one GPU visible")
+    img = synth(640, 480, 77)
+    ref = oracle.run(oracle.default_config(octaves=4), img)
+    ctx = capi.Context(capi.default_config(octaves=4), device=1)
+    ctx.upload(img)
+    ctx.extract()
+    fb, db = ctx.download()
+    ctx.close()
+    from tests.parity import assert_parity, budget, match_features
+    assert len(fb) == ref.ext_total
+    assert_parity(match_features(ref.features(), ref.descriptors(), fb, db), what="C-ABI on device 1", **budget(len(fb)))
+    before = capi.pool_stats(1)
+    ps = capi.PopSift(capi.default_config(octaves=4), device=1)
+    res = [ps.get(ps.enqueue(img)) for _ in range(6)]
+    ps.close()
+    after = capi.pool_stats(1)
+    assert after["hits"] + after["allocs"] > before["hits"] + before["allocs"], "device 1 must use ITS pinned pool"
+    for f2, d2 in res:
+        assert len(f2) == ref.ext_total
+        assert_parity(match_features(ref.features(), ref.descriptors(), f2, d2), what="PopSift on device 1", **budget(len(f2)))
+
+
+def test_zero_copy_export_of_two_contexts_on_two_streams_stays_separate(oracle, capi):
+    """Two contexts (two HIP streams) exporting into their own pinned buffers while both are in flight
+    (psx_attach_export: k_scan deposits the three counters, k_descriptors the records and descriptors, straight into
+    mapped host memory).  Round 3's removed split-frame experiment saw a result that carried only its second part's
+    orientation count: two scan kernels of ONE frame wrote the SAME counter words from two streams without an order
+    between them (a missing cross-stream dependency of the experiment, not a scope problem of the stores).  What the
+    product relies on is checked here: a context's export words are written by exactly one scan kernel per frame, on
+    that context's stream, and the host reads them after that stream's frame event -- frames of different contexts
+    never share a word.  300 alternating frames, every count and every exported array is its own context's."""
+    import torch
+    imgs = [synth(512, 384, 11), synth(480, 360, 12)]
+    refs = [oracle.run(oracle.default_config(octaves=4), im) for im in imgs]
+    ctxs = [capi.Context(capi.default_config(octaves=4)) for _ in imgs]
+    bufs = []
+    for c in ctxs:
+        pf = torch.empty(20000 * capi.FEATURE_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+        pd = torch.empty(40000 * 128, dtype=torch.float32).pin_memory()
+        c.attach_export(pf, pd)
+        bufs.append((pf, pd))
+    for k, c in enumerate(ctxs):
+        c.upload(imgs[k])
+    for rep in range(150):
+        for c in ctxs:
+            c.extract()                                        # both frames in flight on their two streams
+        for k, c in enumerate(ctxs):
+            ne, no = c.counts()
+            assert (ne, no) == (refs[k].ext_total, refs[k].ori_total), (rep, k, ne, no)
+            if rep % 50 == 0:
+                f, d = c.exported()
+                from tests.parity import assert_parity, budget, match_features
+                assert_parity(match_features(refs[k].features(), refs[k].descriptors(), f.copy(), d.copy()),
+                              what="export of context %d, rep %d" % (k, rep), **budget(ne))
+    for c in ctxs:
+        c.attach_export(None, None)
+        c.close()
+
+
+def test_cross_stream_hand_over_of_plain_stores_under_pcie_load(capi):
+    """The mechanism behind round 3's unexplained split-frame failure, isolated (util.hip psx_debug_cross_stream): a kernel
+    busy with PCIe stores whose last workgroup writes a device word (plain store), an event, a reader kernel on a second
+    stream (plain load), an event back -- 3000 rounds, with other contexts extracting on their own streams meanwhile.  Not
+    one stale read: event order between streams carries plain stores on this stack, so the experiment lost its count to a
+    missing edge in its own launch order (its two scan parts wrote the same export words), not to the scope of the export
+    stores; the product never has two kernels of a frame on different streams."""
+    import ctypes as C
+    import threading
+    L = capi.lib()
+    L.psx_debug_cross_stream.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    stop = threading.Event()
+
+    def load():
+        ctx = capi.Context(capi.default_config(octaves=4))
+        ctx.upload(synth(1280, 720, 3))
+        while not stop.is_set():
+            ctx.extract(); ctx.counts()
+        ctx.close()
+    ts = [threading.Thread(target=load) for _ in range(3)]
+    for t in ts:
+        t.start()
+    try:
+        for words in (0, 8, 64):
+            stale = C.c_int(-2)
+            assert L.psx_debug_cross_stream(0, 1000, words, C.byref(stale)) == 0
+            assert stale.value == 0, "stale reads across the event with %d PCIe words per thread: %d of 1000" % (words, stale.value)
+    finally:
+        stop.set()
+        for t in ts:
+            t.join()
