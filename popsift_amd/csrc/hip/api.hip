@@ -1140,8 +1140,9 @@ int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity, floa
     if (no > 0 && !desc_exported)
         PSX_HIP(hipMemcpyAsync(descriptors, ctx->d_desc, (size_t)no * 128 * sizeof(float),
                                hipMemcpyDeviceToHost, ctx->stream));
-    PSX_HIP(hipStreamSynchronize(ctx->stream));
-    return PSX_OK;
+    // sleep on an event when the context is in blocking mode (the C++ pipeline's workers): hipStreamSynchronize spins, and
+    // the ~0.3 ms of a frame's result DMA -- several ms when replicas share a GPU -- were a busy core per worker
+    return wait_stream(ctx);
 }
 
 static int map_host(psx_ctx* ctx, void* host, size_t bytes, void** dev, bool* registered)
