@@ -1140,6 +1140,195 @@ __global__ __launch_bounds__(NT, 4) void k_level0_fused(L0Args a)
     level0_body<R, ISFLOAT>(a, xcd_remap(blockIdx.x, gridDim.x));
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_level0_x2 (round 4): level 0 at the x2 upsampling, specialised on what x2 means.  With W = 2w the texture
+// coordinate of output column X is X/2 (sampling shift 1.0: PopSift, VLFeat) or X/2 - 1/4 (shift 0.5: OpenCV), so the
+// 1.8 fixed-point filter weights are CONSTANTS: {0, 1/2} or {3/4, 1/4} alternating with the column's parity, and the
+// same for rows.  k_level0_fused computed index and weight per thread with l0_axis, converted 8 texels for 4 outputs,
+// ran 12 VALU for their 4 lerp_x and a generic lerp_y on all 24 values of every horizontal window -- 6.9 M wave
+// instructions per 1080p frame against 2.7 M for k_blur<5> with the same taps.  Here a thread owns a 4 x 4 block of
+// outputs (an aligned group of 4 rows x a quad of columns): 3 x 3 (shift 1) or 4 x 4 (shift 1/2) texels, each converted
+// once, lerp(p, q, 0) is p (+ 0 for float images, which keeps fma's -0 -> +0), lerp(p, q, 1/2) is one multiply and one
+// fma, and the block goes to LDS as finished rows of U: the H pass reads ONE window and runs the "dd" taps exactly as
+// k_blur<R, true>.  Same operations on the same operands as the texture model (lerp_x, then lerp_y; weights that the
+// general formula also arrives at, including its X-even knife edge where it lands on (i0 - 1, alpha = 1): the value is
+// T[i0] either way), so the plane is bit-identical (the GPU suite runs through it in every SiftMode).
+// Rows outside the plane (first / last chunk) replicate U(0) / U(H-1): patched in LDS on those steps only.
+// ---------------------------------------------------------------------------------------------
+template <int R, bool ISFLOAT, bool SHIFT1>
+__global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
+{
+    using G = Geom2<R>;
+    constexpr int HALO = G::HALO, SW4 = G::SW4, SWA = G::SWA, RING = G::RING, VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS;
+    constexpr int NRW = SHIFT1 ? 3 : 4;                  // texel rows / columns a 4 x 4 block of outputs needs
+    constexpr int NGRP = BR / 4 + 1;                     // aligned row groups that intersect a step of BR rows
+    static_assert(NGRP * SW4 <= NT, "one block per thread");
+    __shared__ __attribute__((aligned(16))) float s_u[BR * SWA];
+    __shared__ __attribute__((aligned(16))) float s_ring[(RING + MIRROR) * RS];
+
+    const int lid   = xcd_remap(blockIdx.x, gridDim.x);
+    const int t     = threadIdx.x;
+    const int strip = lid % a.nstrips;
+    const int chunk = lid / a.nstrips;
+    const int x0    = strip * TW;
+    const int Y0    = chunk * a.chunk_rows;
+    const int Y1    = min(Y0 + a.chunk_rows, a.H);
+    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
+
+    // ---- this thread's block: row group slot gs, column quad cq; the column side is step invariant ----
+    const int gs = t / SW4, cq = t - gs * SW4;
+    const bool active = gs < NGRP;
+    const int X0c = x0 - HALO + 4 * cq;                                  // first output column of the quad (a multiple of 4)
+    const int cfirst = (X0c >> 1) - (SHIFT1 ? 0 : 1);                    // first texel column the quad reads
+    const int cbase = psx_clampi(cfirst, 0, a.w - 4);                    // position of the 4-texel load (host: w >= 4)
+    int csel[NRW];                                                        // texel i of the quad within the loaded four (clamped texels)
+#pragma unroll
+    for (int i = 0; i < NRW; i++) csel[i] = psx_clampi(cfirst + i, 0, a.w - 1) - cbase;
+
+    // ---- horizontal / vertical geometry as blur_body ----
+    int h_row, h_seg;
+    {
+        const int blk = (t & 31) >> 2;
+        const int rq = (0x21120330 >> (4 * blk)) & 3;
+        const int sh = (0xCC >> blk) & 1;
+        h_row = (t >> 6) * 8 + ((t >> 5) & 1) * 4 + rq;
+        h_seg = sh * 4 + (t & 3);
+    }
+    const LDS_AS float* h_src = (const LDS_AS float*)&s_u[h_row * SWA + h_seg * 8];
+    const int v_pp = t & 31, v_rg = t >> 5;
+    const int v_x  = x0 + 2 * v_pp;
+    const unsigned v_doff = (unsigned)((v_rg * 4) * a.pitch + v_x) * 4u;
+    const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
+
+    typedef typename std::conditional<ISFLOAT, v4f, unsigned>::type texel4;
+    texel4 pre[NRW];
+    auto issue = [&](int k) {
+        if (!active) return;
+        const int ybase = Y0 - R + k * BR;
+        const int g = (ybase >> 2) + gs;                                 // rows 4g .. 4g+3
+        const int rfirst = 2 * g - (SHIFT1 ? 0 : 1);
+#pragma unroll
+        for (int i = 0; i < NRW; i++) {
+            const int jr = psx_clampi(rfirst + i, 0, a.h - 1);
+            if (ISFLOAT) __builtin_memcpy(&pre[i], static_cast<const float*>(a.img) + (size_t)jr * a.w + cbase, 16);
+            else         __builtin_memcpy(&pre[i], static_cast<const uint8_t*>(a.img) + (size_t)jr * a.w + cbase, 4);
+        }
+    };
+    // lerp with the constant weights of the x2 grid; w0 = 0 / 1/2 (SHIFT1) or 3/4 / 1/4
+    auto half_ = [](float p, float q) { return fmaf(0.5f, q, 0.5f * p); };                      // l0_lerp(p, q, 1/2)
+    auto q34_  = [](float p, float q) { return fmaf(0.75f, q, 0.25f * p); };                    // l0_lerp(p, q, 3/4)
+    auto q14_  = [](float p, float q) { return fmaf(0.25f, q, 0.75f * p); };                    // l0_lerp(p, q, 1/4)
+    auto same_ = [](float p) { return ISFLOAT ? p + 0.0f : p; };                                 // l0_lerp(p, q, 0) for finite q
+    auto commit = [&](int k) {
+        if (!active) return;
+        const int ybase = Y0 - R + k * BR;
+        const int g = (ybase >> 2) + gs;
+        float ux[NRW][4];                                                // lerp_x of the texel rows at the quad's 4 columns
+#pragma unroll
+        for (int i = 0; i < NRW; i++) {
+            float c[NRW];
+#pragma unroll
+            for (int q = 0; q < NRW; q++) {
+                if constexpr (ISFLOAT) c[q] = sel4(pre[i].x, pre[i].y, pre[i].z, pre[i].w, csel[q]);
+                else                   c[q] = l0_unorm8((pre[i] >> (8 * csel[q])) & 0xffu);
+            }
+            if constexpr (SHIFT1) { ux[i][0] = same_(c[0]); ux[i][1] = half_(c[0], c[1]); ux[i][2] = same_(c[1]); ux[i][3] = half_(c[1], c[2]); }
+            else                  { ux[i][0] = q34_(c[0], c[1]); ux[i][1] = q14_(c[1], c[2]); ux[i][2] = q34_(c[1], c[2]); ux[i][3] = q14_(c[2], c[3]); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 4 * g + q - ybase;                             // row of the step
+            if (r < 0 || r >= BR) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if constexpr (SHIFT1) o[e] = q == 0 ? same_(ux[0][e]) : q == 1 ? half_(ux[0][e], ux[1][e]) : q == 2 ? same_(ux[1][e]) : half_(ux[1][e], ux[2][e]);
+                else                  o[e] = q == 0 ? q34_(ux[0][e], ux[1][e]) : q == 1 ? q14_(ux[1][e], ux[2][e]) : q == 2 ? q34_(ux[1][e], ux[2][e]) : q14_(ux[2][e], ux[3][e]);
+            }
+            *reinterpret_cast<float4*>(&s_u[r * SWA + cq * 4]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+
+    v2f pend[4];
+    auto flush = [&](const int kk) {
+        const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
+        char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r_out = r_out0 + i;
+            if (r_out >= Y0 && r_out < Y1 && v_xok) {
+                char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
+                if (v_pair) {
+                    unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else *reinterpret_cast<float*>(di) = pend[i].x;
+            }
+        }
+    };
+
+    issue(0);
+    for (int k = 0; k < nsteps; k++) {
+        commit(k);
+        flush(k - 1);
+        const int ybase = Y0 - R + k * BR;
+        if (ybase < 0 || ybase + BR > a.H) {
+            // first / last chunk: the rows of the step outside the plane are copies of U(0) / U(H - 1) (the vertical
+            // filter clamps its row index), which the blocks above have just produced inside this step
+            __syncthreads();
+            for (int idx = t; idx < BR * SW4; idx += NT) {
+                const int r = idx / SW4, c4 = idx - r * SW4;
+                const int y = ybase + r;
+                if (y < 0 || y > a.H - 1) {
+                    const int rc = psx_clampi(y, 0, a.H - 1) - ybase;
+                    if (rc >= 0 && rc < BR)
+                        *reinterpret_cast<float4*>(&s_u[r * SWA + c4 * 4]) = *reinterpret_cast<const float4*>(&s_u[rc * SWA + c4 * 4]);
+                }
+            }
+        }
+        __syncthreads();
+        if (k + 1 < nsteps) issue(k + 1);
+
+        // ---- horizontal: the dd taps over one window of U ----
+        {
+            float win[8 + 2 * HALO];
+#pragma unroll
+            for (int q = 0; q < (8 + 2 * HALO) / 4; q++) {
+                const v4f v = ((const volatile LDS_AS v4f*)h_src)[q];
+                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+            }
+            float out[8];
+            hfilter8_km<R, HALO, true>(win, a.taps, out);
+            const int slot = (k * BR + h_row) & (RING - 1);
+            float* rp = &s_ring[slot * RS + h_seg * 8];
+            reinterpret_cast<float4*>(rp)[0] = make_float4(out[0], out[1], out[2], out[3]);
+            reinterpret_cast<float4*>(rp)[1] = make_float4(out[4], out[5], out[6], out[7]);
+            if (slot < MIRROR) {
+                reinterpret_cast<float4*>(rp + RING * RS)[0] = make_float4(out[0], out[1], out[2], out[3]);
+                reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
+            }
+        }
+        __syncthreads();
+
+        // ---- vertical ----
+        {
+            const int rel0 = k * BR - 2 * R + v_rg * 4;
+            const int r_out0 = Y0 + rel0;
+            if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
+                const LDS_AS float* vp = (const LDS_AS float*)&s_ring[(rel0 & (RING - 1)) * RS + 2 * v_pp];
+                v2f v[VWIN];
+#pragma unroll
+                for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
+                v2f o[4];
+                vfilter2x4_km<R>(v, a.taps_v, o);
+                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+#pragma unroll
+                for (int i = 0; i < 4; i++) pend[i] = o[i];
+            }
+        }
+    }
+    flush(nsteps - 1);
+}
+
 // make_dog (s_pyramid_build.cu:74-92) for one level pair; debug/dump use only
 __global__ void k_dog(const float* a, const float* b, float* d, int W, int H, int pitch)
 {
@@ -1316,6 +1505,14 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
             chunking(h.W, h.H, R, f.chunk_rows, nchunks);
             f.taps = h.taps_h; f.taps_v = h.taps_v;
             const dim3 grid(f.nstrips * nchunks), block(NT);
+            // POPSIFT_LEVEL0_X2=0: round 3's k_level0_fused (general weights) instead of the x2-specialised kernel
+            static const bool x2 = [] { const char* e = getenv("POPSIFT_LEVEL0_X2"); return !(e != nullptr && e[0] == '0'); }();
+            if (x2) {
+                const bool s1 = h.shift == 1.0f;
+                if (h.is_float) { if (s1) hipLaunchKernelGGL((k_level0_x2<R, true, true>), grid, block, 0, s, f);  else hipLaunchKernelGGL((k_level0_x2<R, true, false>), grid, block, 0, s, f); }
+                else            { if (s1) hipLaunchKernelGGL((k_level0_x2<R, false, true>), grid, block, 0, s, f); else hipLaunchKernelGGL((k_level0_x2<R, false, false>), grid, block, 0, s, f); }
+                return hipGetLastError();
+            }
             if (h.is_float) hipLaunchKernelGGL((k_level0_fused<R, true>), grid, block, 0, s, f);
             else            hipLaunchKernelGGL((k_level0_fused<R, false>), grid, block, 0, s, f);
             return hipGetLastError();
