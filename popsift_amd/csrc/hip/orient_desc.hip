@@ -538,6 +538,14 @@ __device__ __forceinline__ void normalize_store(const PsxParams* P, const PsxExp
 //     floor() and "& 7" wrap the bin index, the fractional part is the same.
 // ---------------------------------------------------------------------------------------------
 
+// DENORM (round 4): the fixed-point scale is folded into the Gaussian weight as 2^14 * 2^-149, so that every final
+// contribution (bin weight x tile weight x magnitude) is a DENORMAL float -- and the bit pattern of the denormal k * 2^-149 is
+// the integer k: the multiply itself rounds to the 18.14 grid (round to nearest even), the pair (this bin, next bin) comes
+// out of one v_pk_mul_f32 as the 64-bit word ds_add_u64 adds.  16 v_cvt_u32_f32 per pixel pair and the + 0.5 go away
+// (134 -> ~118 VALU per step).  f32 denormals are not flushed on gfx950 (HIP default) and run at the normal rate; the
+// intermediate weights are denormal too, i.e. rounded to the same grid before the last product: <= 2 units of 2^-14 per
+// contribution instead of 1/2, against descriptor sums of 10^2..10^3.
+template <bool DENORM>
 __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
 {
     // Histogram layout per copy: tiles (iy, ix), iy, ix in -1..4, at index (iy+1)*5 + (ix+1) (31 slots), 16 words
@@ -682,12 +690,33 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
 
                         const v2f un = u - splat(1.5f), vn = v - splat(1.5f);
                         const v2f d2 = pk_fma(un, un, vn * vn) * splat(-0.125f * 1.4426950408889634f);
-                        const v2f ww = (v2f){__builtin_amdgcn_exp2f(d2.x), __builtin_amdgcn_exp2f(d2.y)} * (mod * splat(DFIX));
+                        const v2f ww = (v2f){__builtin_amdgcn_exp2f(d2.x), __builtin_amdgcn_exp2f(d2.y)} * (mod * splat(DENORM ? 0x1p-135f : DFIX));
                         const v2f fu = (v2f){floorf(u.x), floorf(u.y)}, fv = (v2f){floorf(v.x), floorf(v.y)};
                         const v2f ax1 = u - fu, ay1 = v - fv;
                         const v2f ax0 = splat(1.0f) - ax1, ay0 = splat(1.0f) - ay1;
                         const v2f wy0 = ay0 * ww, wy1 = ay1 * ww;
                         const v2f w00 = wy0 * ax0, w01 = wy0 * ax1, w10 = wy1 * ax0, w11 = wy1 * ax1;
+                        if constexpr (DENORM) {
+                            // per pixel the pair (bin fo, bin fo + 1) = (wgt1, wgt2) x tile weight: the product's BITS are the word
+                            auto bits = [](v2f p) { fix64 b; __builtin_memcpy(&b, &p, 8); return b; };
+                            if (in0) {
+                                const v2f pw = (v2f){wgt1.x, wgt2.x};
+                                const unsigned fo = (unsigned)((int)ffo.x & 7);
+                                // tile (iy0, ix0) at 64-byte granules; pair view: even fo -> word fo, odd fo -> word 8 + fo - 1
+                                const unsigned tb = myacc + (unsigned)(((int)fv.x + 1) * 5 + ((int)fu.x + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                                fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
+                                lds_add(t, bits(pw * splat(w00.x)));      lds_add(t + 8, bits(pw * splat(w01.x)));       // +1 tile = 16 words = 8 u64
+                                lds_add(t + 40, bits(pw * splat(w10.x))); lds_add(t + 48, bits(pw * splat(w11.x)));      // +5 / +6 tiles
+                            }
+                            if (in1) {
+                                const v2f pw = (v2f){wgt1.y, wgt2.y};
+                                const unsigned fo = (unsigned)((int)ffo.y & 7);
+                                const unsigned tb = myacc + (unsigned)(((int)fv.y + 1) * 5 + ((int)fu.y + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                                fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
+                                lds_add(t, bits(pw * splat(w00.y)));      lds_add(t + 8, bits(pw * splat(w01.y)));
+                                lds_add(t + 40, bits(pw * splat(w10.y))); lds_add(t + 48, bits(pw * splat(w11.y)));
+                            }
+                        } else {
                         const v2f h = splat(0.5f);
                         const v2f a00 = pk_fma(wgt1, w00, h), b00 = pk_fma(wgt2, w00, h);
                         const v2f a01 = pk_fma(wgt1, w01, h), b01 = pk_fma(wgt2, w01, h);
@@ -708,6 +737,7 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                             fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                             lds_add(t, pack(a00.y, b00.y));      lds_add(t + 8, pack(a01.y, b01.y));
                             lds_add(t + 40, pack(a10.y, b10.y)); lds_add(t + 48, pack(a11.y, b11.y));
+                        }
                         }
                     }
                 }
@@ -1025,6 +1055,9 @@ hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* 
     // cus = compute units of the CONTEXT's device (one PopSift per GPU may sit on unequal devices).
     if (cus <= 0) cus = 256;
     const int grid = exporting ? 3 * cus : 10 * cus;
-    hipLaunchKernelGGL(k_descriptors, dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
+    // POPSIFT_DESC_DENORM=0: round 2's conversion path (v_cvt_u32_f32 of every contribution) instead of the denormal products
+    static const bool denorm = [] { const char* e = getenv("POPSIFT_DESC_DENORM"); return !(e != nullptr && e[0] == '0'); }();
+    if (denorm) hipLaunchKernelGGL(k_descriptors<true>, dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
+    else        hipLaunchKernelGGL(k_descriptors<false>, dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
     return hipGetLastError();
 }
