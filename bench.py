@@ -128,6 +128,29 @@ def usable_cores():
     return max(1, n)
 
 
+def pin_process_to_gpu_numa_node(capi, device):
+    """One process per GPU: run this rank (the caller thread that copies frames into pinned job buffers, the workers
+    inherit it) on the CPUs local to its GPU's PCIe root, so that on a two-socket 8-GPU host no frame crosses the socket
+    link on its way to the GPU.  Only on multi-node hosts, only when sysfs names the CPUs, never widening the affinity."""
+    try:
+        if not os.path.exists("/sys/devices/system/node/node1"):
+            return
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        if capi.lib().psx_device_pci(device, buf, 64) != 0 or not buf.value:
+            return
+        path = "/sys/bus/pci/devices/%s/local_cpulist" % buf.value.decode().lower()
+        cpus = set()
+        for tok in open(path).read().strip().split(","):
+            a, _, b = tok.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+    except Exception:
+        pass
+
+
 def frame_seed(j, rank, world):
     """Seed of this rank's j-th base frame: global frame i = j * world + rank goes to GPU i mod world."""
     return 1000 + j * world + rank
@@ -163,6 +186,7 @@ class GpuBackend:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
         torch.cuda.set_device(local_rank)
+        pin_process_to_gpu_numa_node(capi, local_rank)
         self.np, self.torch, self.capi = np, torch, capi
         self.device = local_rank
         self.dev = torch.device("cuda", local_rank)

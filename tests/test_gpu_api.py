@@ -170,14 +170,13 @@ def test_zero_copy_export_of_two_contexts_on_two_streams_stays_separate(oracle, 
     product relies on is checked here: a context's export words are written by exactly one scan kernel per frame, on
     that context's stream, and the host reads them after that stream's frame event -- frames of different contexts
     never share a word.  300 alternating frames, every count and every exported array is its own context's."""
-    import torch
     imgs = [synth(512, 384, 11), synth(480, 360, 12)]
     refs = [oracle.run(oracle.default_config(octaves=4), im) for im in imgs]
     ctxs = [capi.Context(capi.default_config(octaves=4)) for _ in imgs]
     bufs = []
     for c in ctxs:
-        pf = torch.empty(20000 * capi.FEATURE_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
-        pd = torch.empty(40000 * 128, dtype=torch.float32).pin_memory()
+        pf = np.zeros(20000 * capi.FEATURE_DTYPE.itemsize, dtype=np.uint8)       # registered (pinned + mapped) by psx_attach_export
+        pd = np.zeros(40000 * 128, dtype=np.float32)
         c.attach_export(pf, pd)
         bufs.append((pf, pd))
     for k, c in enumerate(ctxs):

@@ -69,11 +69,10 @@ def main():
         return
     w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
     F = {"POPSIFT_FLOW": "1"}
-    variants = [{"POPSIFT_FLOW": "0"},
-                dict(F, POPSIFT_FLOW_STEPS="0,0,1", POPSIFT_FLOW_ORDER="0"), dict(F, POPSIFT_FLOW_STEPS="3,2,1", POPSIFT_FLOW_ORDER="0"),
-                dict(F, POPSIFT_FLOW_STEPS="3,2,1", POPSIFT_FLOW_ORDER="2"), dict(F, POPSIFT_FLOW_STEPS="3,2,1", POPSIFT_FLOW_ORDER="2", POPSIFT_FLOW_GRID="768"),
-                dict(F, POPSIFT_FLOW_STEPS="4,2,1", POPSIFT_FLOW_ORDER="0"), dict(F, POPSIFT_FLOW_STEPS="3,2,1", POPSIFT_FLOW_ORDER="0", POPSIFT_FLOW_GRID="768"),
-                {"POPSIFT_FLOW": "2", "POPSIFT_FLOW_STEPS": "0,2,1"}, {"POPSIFT_FLOW": "0"}]
+    variants = [{"POPSIFT_FLOW": "0"}, {"POPSIFT_FLOW": "3", "POPSIFT_FLOW_GRID": "128"}, {"POPSIFT_FLOW": "3", "POPSIFT_FLOW_GRID": "256"},
+                {"POPSIFT_FLOW": "3", "POPSIFT_FLOW_GRID": "384"}, {"POPSIFT_FLOW": "3", "POPSIFT_FLOW_GRID": "256", "POPSIFT_FLOW_STEPS": "0,2,1"},
+                {"POPSIFT_FLOW": "3", "POPSIFT_FLOW_GRID": "256", "POPSIFT_FLOW_STEPS": "0,3,2"},
+                {"POPSIFT_FLOW": "3", "POPSIFT_FLOW_GRID": "192", "POPSIFT_FLOW_STEPS": "0,2,2"}, {"POPSIFT_FLOW": "0"}]
     if os.environ.get("FLOW_AB_ONLY"):
         variants = [v for i, v in enumerate(variants) if str(i) in os.environ["FLOW_AB_ONLY"].split(",")]
     for v in variants:
