@@ -613,7 +613,7 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         "measured_copy_what": "hand-written 16 B/lane copy kernel, 1 GiB read + 1 GiB written (psx_copy_bench)",
         "isolated_replay_avg_ms": round(sum(iso) / len(iso), 5),
         # the other two HBM-bound kernels of octave 0, the same way (stream events around the launch, in the pipeline)
-        "level0": {"kernel": "k_level0_fused (u8 input -> level 0 of octave 0)", "bytes": l0_by, "ms": round(l0_ms, 5),
+        "level0": {"kernel": "k_level0_x2 (u8 input -> level 0 of octave 0)", "bytes": l0_by, "ms": round(l0_ms, 5),
                    "achieved": round(l0_by / (l0_ms * 1e-3) / 1e9, 1) if l0_ms > 0 else None, "unit": "GB/s",
                    "frac": round(l0_by / (l0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if l0_ms > 0 else None},
         "extrema": {"kernel": "k_extrema (octave 0: six planes read once, DoG in registers)", "bytes": x0_by, "ms": round(x0_ms, 5),

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <memory>
 #include <new>
 #include <string>
@@ -884,10 +885,22 @@ int psx_build_pyramid(psx_ctx* ctx)
 static int wait_stream(psx_ctx* ctx)
 {
     if (ctx->blocking_wait) {
+        // The C++ pipeline's workers wait here for most of a frame's life.  hipEventSynchronize on a hipEventBlockingSync
+        // event still burnt the core on this stack (POPSIFT_PROFILE: 2.4 ms of thread CPU time per 0.35 ms frame, 8 workers
+        // 86 % busy -- 7 cores per GPU, 54 on an 8-GPU host); asking the event and sleeping in between costs a few
+        // microseconds of CPU per frame and, with several frames in flight per worker pool, no throughput.
+        // POPSIFT_WAIT_SLEEP_US (default 40; 0 = the runtime's blocking wait).
+        static const int sleep_us = [] { const char* e = getenv("POPSIFT_WAIT_SLEEP_US"); const int v = e ? atoi(e) : 40; return v < 0 ? 0 : v; }();
         if (!ctx->ev_wait) PSX_HIP(hipEventCreateWithFlags(&ctx->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
         PSX_HIP(hipEventRecord(ctx->ev_wait, ctx->stream));
-        PSX_HIP(hipEventSynchronize(ctx->ev_wait));
-        return PSX_OK;
+        if (sleep_us == 0) { PSX_HIP(hipEventSynchronize(ctx->ev_wait)); return PSX_OK; }
+        for (;;) {
+            const hipError_t q = hipEventQuery(ctx->ev_wait);
+            if (q == hipSuccess) return PSX_OK;
+            if (q != hipErrorNotReady) PSX_HIP(q);
+            struct timespec ts = {0, (long)sleep_us * 1000L};
+            nanosleep(&ts, nullptr);
+        }
     }
     PSX_HIP(hipStreamSynchronize(ctx->stream));
     return PSX_OK;

@@ -55,5 +55,5 @@ with open(out + "/pmc_hbm_traffic.txt", "w") as f:
         f.write("%-28s %6d %14.0f %14.0f %16.0f\n" % r)
 blur0 = [r[4] for r in rows if r[0].startswith("k_blur") and ", false," in r[0] and r[1] >= 900]
 json.dump({"k_blur_octave0_hbm_bytes_per_launch": sum(blur0) / max(1, len(blur0)), "n_launch_kinds": len(blur0),
-           "source": "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2xFETCH correction)"},
+           "source": "profiles/r04_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2xFETCH correction)"},
           open(out + "/pmc_summary.json", "w"), indent=1)
