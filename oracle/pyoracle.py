@@ -79,7 +79,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("OSIFT_LIB") or os.path.join(_HERE, "liboracle.so")     # OSIFT_LIB: a variant build (make plain)
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

@@ -1056,7 +1056,13 @@ static inline float rdata(const float* plane, int W, int H, int x, int y)
  * through roundf(36 (theta + pi) / 2 pi), and on exactly diagonal gradients (binary images, symmetric patterns) the
  * bin hangs on theta's last ulp.  All sides -- this file, the HIP kernels' exact path, the shim's stand-in --
  * therefore use the correctly rounded value: atan2 evaluated in double, rounded once. */
+#ifdef OSIFT_PLAIN_LIBM
+/* sensitivity build only (make plain; tests/test_oracle_cpu.py): glibc's own atan2f, which differs from the single-rounded
+ * value in the last ulp for some arguments -- how many orientation bins hang on that ulp is measured, not defined away */
+static inline float atan2f_1r(float y, float x) { return atan2f(y, x); }
+#else
 static inline float atan2f_1r(float y, float x) { return (float)atan2((double)y, (double)x); }
+#endif
 
 /* s_gradiant.h:56-69 (texture variant) */
 static inline void get_gradiant(float* grad, float* theta, int x, int y, const float* plane, int W, int H)

@@ -1,5 +1,5 @@
 """Exact mismatch counts of the HIP path against the oracle over a sweep (GPU box): the numbers behind
-tests/parity.py::budget().  Writes one JSON object (profiles/r03_parity_counts.json is a copy of its output).
+tests/parity.py::budget().  Writes one JSON object (profiles/r0N_parity_counts.json are copies of its output).
 
   python tools/parity_counts.py [n_fuzz] [out.json]
 
@@ -63,8 +63,26 @@ for i in range(8):
     one(synth(1920, 1080, 1000 + i), dict(octaves=5), acc)
 res["config2_1080p_8_frames"] = acc
 acc = fresh()
+for i in range(8):
+    one(synth(1920, 1080, 1000 + i), dict(octaves=5, sift_mode=2), acc)          # round 4: the mode the north_star quotes parity on
+res["config2_1080p_8_frames_vlfeat_mode"] = acc
+acc = fresh()
+for i in range(4):                                                                 # round 4: the external caller's profile
+    one((synth(1920, 1080, 1000 + i).astype(np.float32) / np.float32(256.0)).astype(np.float32),
+        dict(octaves=5, filter_max_extrema=10000, grid_filter_mode=1, norm_multi=9), acc)
+res["caller_profile_float_gridfilter_norm9_4_frames"] = acc
+acc = fresh()
+for (w, h, s_, fl, kw) in [(200, 150, 21, False, dict(octaves=4, upscale_factor=2.0, sift_mode=2)), (640, 480, 22, False, dict(octaves=3, upscale_factor=-2.0)),
+                           (321, 243, 23, False, dict(octaves=4, upscale_factor=0.5, sift_mode=1)), (300, 200, 24, True, dict(octaves=4, upscale_factor=1.5, sift_mode=2)),
+                           (513, 387, 25, False, dict(octaves=4, upscale_factor=-0.5))]:
+    one(synth_float(w, h, s_) if fl else synth(w, h, s_), kw, acc)                 # round 4: scale factors other than -1 / 0 / +1
+res["other_scale_factors"] = acc
+acc = fresh()
 one(np.ascontiguousarray(np.tile(synth(1920, 1080, 1000), (4, 3))[:4096, :4096]), dict(octaves=6), acc)
 res["config3_4096x4096"] = acc
+acc = fresh()
+one(synth(4096, 4096, 3001), dict(octaves=6, sift_mode=2), acc)
+res["config3_4096x4096_vlfeat_mode"] = acc
 acc = fresh()
 for name in sorted(adv.CONTENT):
     for kw in (dict(octaves=5), dict(octaves=5, sift_mode=2), dict(octaves=4, sift_mode=1, gauss_mode=3)):
