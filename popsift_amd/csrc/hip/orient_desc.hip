@@ -646,10 +646,11 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                     const v2f dxk = (v2f){dx0, dx0 + 1.0f};
                     const v2f u = pk_fma(splat(crsbp), dxk, splat(ub));
                     const v2f v = pk_fma(splat(-srsbp), dxk, splat(vb));
-                    const bool in0 = rowok && (jj >= xmin) && (jj <= xmax) &&
-                                     (u.x > -1.0f) && (u.x < 4.0f) && (v.x > -1.0f) && (v.x < 4.0f);
-                    const bool in1 = rowok && (jj + 1 <= xmax) &&
-                                     (u.y > -1.0f) && (u.y < 4.0f) && (v.y > -1.0f) && (v.y < 4.0f);
+                    // the window -1 < u, v < 4 as |u - 1.5|, |v - 1.5| < 2.5: four compares with free abs modifiers instead of
+                    // eight (a pixel within an ulp of the border has a weight of that order: it does not matter which side it falls)
+                    const v2f un = u - splat(1.5f), vn = v - splat(1.5f);
+                    const bool in0 = rowok && (jj >= xmin) && (jj <= xmax) && (fabsf(un.x) < 2.5f) && (fabsf(vn.x) < 2.5f);
+                    const bool in1 = rowok && (jj + 1 <= xmax) && (fabsf(un.y) < 2.5f) && (fabsf(vn.y) < 2.5f);
                     if (__ballot(in0 || in1) == 0ull) continue;
                     // (a software pipeline that issues the next step's loads before this step's arithmetic was
                     // measured: the compiler's conservative s_waitcnt across the loop edge undoes it, +12 %)
@@ -682,13 +683,14 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                         float r0 = r.x, r1 = r.y;
                         r0 = (ay.x > ax.x) ? 2.0f - r0 : r0;   r1 = (ay.y > ax.y) ? 2.0f - r1 : r1;
                         r0 = (gdx.x < 0.0f) ? 4.0f - r0 : r0;  r1 = (gdx.y < 0.0f) ? 4.0f - r1 : r1;
-                        r0 = (gdy.x < 0.0f) ? -r0 : r0;        r1 = (gdy.y < 0.0f) ? -r1 : r1;
+                        // r >= 0 here: "negative for gdy < 0" is the sign bit of gdy (one v_bfi); gdy == -0.0 turns angle 0 / 4 into
+                        // -0 / -4, the same bin and fraction after the wrap below
+                        r0 = __builtin_copysignf(r0, gdy.x);   r1 = __builtin_copysignf(r1, gdy.y);
                         const v2f tth = (v2f){r0, r1} - splat(ang_bins);          // in (-12, 12): not wrapped
                         const v2f ffo = (v2f){floorf(tth.x), floorf(tth.y)};
                         const v2f wgt2 = tth - ffo;
                         const v2f wgt1 = splat(1.0f) - wgt2;
 
-                        const v2f un = u - splat(1.5f), vn = v - splat(1.5f);
                         const v2f d2 = pk_fma(un, un, vn * vn) * splat(-0.125f * 1.4426950408889634f);
                         const v2f ww = (v2f){__builtin_amdgcn_exp2f(d2.x), __builtin_amdgcn_exp2f(d2.y)} * (mod * splat(DENORM ? 0x1p-135f : DFIX));
                         const v2f fu = (v2f){floorf(u.x), floorf(u.y)}, fv = (v2f){floorf(v.x), floorf(v.y)};
@@ -699,11 +701,13 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                         if constexpr (DENORM) {
                             // per pixel the pair (bin fo, bin fo + 1) = (wgt1, wgt2) x tile weight: the product's BITS are the word
                             auto bits = [](v2f p) { fix64 b; __builtin_memcpy(&b, &p, 8); return b; };
+                            // tile index (iy0 + 1) * 5 + (ix0 + 1) in float (small exact integers), one conversion per pixel
+                            const v2f tidx = pk_fma(fv, splat(5.0f), fu + splat(6.0f));
                             if (in0) {
                                 const v2f pw = (v2f){wgt1.x, wgt2.x};
                                 const unsigned fo = (unsigned)((int)ffo.x & 7);
                                 // tile (iy0, ix0) at 64-byte granules; pair view: even fo -> word fo, odd fo -> word 8 + fo - 1
-                                const unsigned tb = myacc + (unsigned)(((int)fv.x + 1) * 5 + ((int)fu.x + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                                const unsigned tb = myacc + (unsigned)(int)tidx.x * 64u + (fo + 7u * (fo & 1u)) * 4u;
                                 fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                                 lds_add(t, bits(pw * splat(w00.x)));      lds_add(t + 8, bits(pw * splat(w01.x)));       // +1 tile = 16 words = 8 u64
                                 lds_add(t + 40, bits(pw * splat(w10.x))); lds_add(t + 48, bits(pw * splat(w11.x)));      // +5 / +6 tiles
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                             if (in1) {
                                 const v2f pw = (v2f){wgt1.y, wgt2.y};
                                 const unsigned fo = (unsigned)((int)ffo.y & 7);
-                                const unsigned tb = myacc + (unsigned)(((int)fv.y + 1) * 5 + ((int)fu.y + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                                const unsigned tb = myacc + (unsigned)(int)tidx.y * 64u + (fo + 7u * (fo & 1u)) * 4u;
                                 fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                                 lds_add(t, bits(pw * splat(w00.y)));      lds_add(t + 8, bits(pw * splat(w01.y)));
                                 lds_add(t + 40, bits(pw * splat(w10.y))); lds_add(t + 48, bits(pw * splat(w11.y)));
