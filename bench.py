@@ -507,7 +507,7 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
                        "sift_mode": mode_name, "input": "u8 (ByteImages)", "grid_filter": "off",
                        "frames_per_step_per_gpu": per_rank, "frames_timed": n_frames,
                        "jobs_outstanding_per_gpu": MAX_OUT,
-                       "pipe_depth": os.environ.get("POPSIFT_PIPE_DEPTH", "clamp(usable cores / local replicas, 4, 8)"),
+                       "pipe_depth": os.environ.get("POPSIFT_PIPE_DEPTH", "8 (4 when this replica's share of the host is below two cores)"),
                        "parallelism": "replicas x%d (frame i -> GPU i mod N, no collective)%s" % (
                            world, "; --strong: %d frames per step in total (BASELINE config 4's shape)" % (per_rank * world) if args.strong else "")},
             "keypoints_per_s": round(kps_e2e / dt_e2e, 1),

@@ -89,10 +89,11 @@ int pipe_depth()
     else if( const char* e2 = getenv( "LOCAL_WORLD_SIZE" ) ) replicas = atoi( e2 );
     if( replicas < 1 ) replicas = 1;
     const int share = cores > 0 ? cores / replicas : 8;
-    // measured on MI355X (1080p bench frames, end to end): 2 workers 4356, 3: 5565, 4: 5887, 6: 5873, 8: 5951 Mpix/s --
-    // four contexts in flight already fill the GPU, fewer starve it; a worker sleeps on an event most of the time
-    // (~0.4 ms of CPU per frame), so the floor of 4 costs a small host less than an idle GPU would
-    return std::max( 4, std::min( 8, share ) );
+    // measured on MI355X (1080p bench frames, end to end): 2 workers 4356, 3: 5565, 4: 5887, 6: 5907, 8: 6105, 12: 6048,
+    // 16: 6035 Mpix/s -- four contexts in flight already fill the GPU, eight is the plateau.  Since round 4 a worker
+    // SLEEPS while its frame runs (wait_stream: ~0.03 ms of CPU per frame and worker), so eight workers fit a share of two
+    // cores; only a smaller share falls back to four.
+    return share >= 2 ? 8 : 4;
 }
 
 // pinned bytes that jobs and result objects may hold before they fall back to pageable memory (POPSIFT_PINNED_LIMIT_MB)
