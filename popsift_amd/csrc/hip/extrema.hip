@@ -212,7 +212,10 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     // two queues of packed (kind, z, y, x) codes.  A strict extremum of its own 3x3 neighbourhood cannot be
     // 8-adjacent to another one of the same kind, so a level of the 64x16 tile holds at most QCAP = 2 * 32 * 8.
     unsigned short* sQ1 = reinterpret_cast<unsigned short*>(smem + NL * THP * TWP);   // in-plane extrema, [NZ*QCAP]
-    unsigned short* sQ  = sQ1 + NZ * QCAP;                                            // 26-neighbour extrema, [NZ*QCAP]
+    // The 26-neighbour extrema reuse the space of the queue they are filtered from (round 4): pass 2 works in rounds of NT
+    // entries -- read, barrier, test, write -- and a survivor's slot is below the number of entries processed so far,
+    // i.e. never an entry that is still to be read.  26.8 instead of 29.9 KB of LDS: six workgroups per CU instead of five.
+    unsigned short* sQ  = sQ1;
     __shared__ int sCount, sCount1;
 
     const int t = threadIdx.x;
@@ -315,8 +318,11 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     __syncthreads();
     {
         const int n1 = sCount1;
-        for (int q = t; q < n1; q += NT) {
-            const int code = sQ1[q];
+        for (int base = 0; base < n1; base += NT) {
+            const int q = base + t;
+            const int code = q < n1 ? (int)sQ1[q] : -1;
+            __syncthreads();                             // the round's entries are in registers: their space may be overwritten
+            if (code < 0) continue;
             const bool is_max = (code & 0x8000) != 0;
             const int z = (code >> 10) & 31, ly = (code >> 6) & 15, cx = code & 63;
             const float v = sD[(z * THP + ly + 1) * TWP + cx + 1];
@@ -453,7 +459,7 @@ hipError_t psx_launch_extrema_batch(const PsxParams* d_params, const PsxParams& 
         if (k < n) tiles += b.tiles_x[k] * ((oc.h + ETH - 1) / ETH);
         b.tile_end[k] = tiles;
     }
-    const size_t smem = sizeof(float) * (size_t)NL * THP * TWP + 2 * sizeof(unsigned short) * (size_t)NZ * QCAP;
+    const size_t smem = sizeof(float) * (size_t)NL * THP * TWP + sizeof(unsigned short) * (size_t)NZ * QCAP;
     const dim3 grid(tiles), block(NT);
     // levels >= 7 need more than the 64 KiB of dynamic LDS a kernel gets by default (72..107 KB of the 160 KB per CU)
     if (smem > 64 * 1024) {
