@@ -283,6 +283,15 @@ static float tex2d_norm(const tex_in* t, float un, float vn)
 /* Pyramid                                                                   */
 /* ------------------------------------------------------------------------- */
 
+/* a == b << n or b == a << n for a small n: the sub-texel positions (x +- k + shift)/W * w - 0.5 are then multiples of
+ * 2^-(n+1), far from the rounding boundaries of the 1.8 fixed-point filter weight */
+static int pow2_ratio(int a, int b)
+{
+    const int big = a > b ? a : b, small = a > b ? b : a;
+    for (int n = 0; n <= 4; n++) if ((small << n) == big) return 1;
+    return 0;
+}
+
 /* s_pyramid_build_ra.cu:17-55 (normalizedSource::horiz) followed by
  * s_pyramid_build_aa.cu:52-86 (absoluteSource::vert, level 0). */
 static void octave0_level0(osift_result* r, const tex_in* t)
@@ -297,7 +306,11 @@ static void octave0_level0(osift_result* r, const tex_in* t)
         shift = 0.5f * powf(2.0f, c->upscale_factor - 0);
 
     float* intm = (float*)malloc(sizeof(float) * (size_t)W * H);
-    if (c->literal_tex) {
+    /* literal_tex 0: the cheaper upsampled-row form where it is provably the same bits (power-of-two ratio between
+     * image and octave), the literal per-tap coordinates everywhere else; 1: always literal; 2: always the
+     * upsampled-row form (tests/test_oracle_cpu.py shows where the two part) */
+    const int literal = c->literal_tex == 1 || (c->literal_tex == 0 && !(pow2_ratio(W, t->w) && pow2_ratio(H, t->h)));
+    if (literal) {
         /* per-tap texture coordinates exactly as the reference computes them */
         #pragma omp parallel for schedule(static)
         for (int y = 0; y < H; y++) {

@@ -84,8 +84,9 @@ typedef struct osift_config {
     int   filter_max_extrema; /* -1 */
     int   filter_grid_size;   /* 2 */
     int   grid_filter_mode;   /* RandomScale */
-    int   literal_tex;        /* oracle-only: 1 = per-tap texture coordinates exactly as
-                                 s_pyramid_build_ra.cu:35-50; 0 = upsampled-row form */
+    int   literal_tex;        /* oracle-only, octave 0 level 0: 1 = per-tap texture coordinates exactly as
+                                 s_pyramid_build_ra.cu:35-50; 2 = upsampled-row form; 0 = the
+                                 upsampled-row form where it is the same bits (power-of-two scale), literal otherwise */
     int   scaling_mode;       /* ScaleDefault (sift_conf.h:75-80) */
     int   desc_mode;          /* Loop (sift_conf.h:85-97) */
 } osift_config;

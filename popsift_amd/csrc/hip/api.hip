@@ -760,6 +760,7 @@ int psx_build_pyramid(psx_ctx* ctx)
         q.inc_filter = ctx->inc_filter; q.inc_ifilter = ctx->inc_ifilter; q.dd_filter = ctx->dd_filter;
         q.abs0_filter = ctx->abs0_filter; q.absN_filter = ctx->absN_filter;
         q.inc_span = ctx->inc_span; q.inc_ispan = ctx->inc_ispan; q.dd_span = ctx->dd_span; q.abs0_span = ctx->abs0_span;
+        q.up = ctx->d_up; q.up_pitch = ctx->up_pitch;
         q.intm = ctx->d_intm; q.vbuf = ctx->d_vbuf; q.vbuf_pitch = P.oct[0].pitch + 64;
         q.user = ctx;
         q.after_octave = ctx->interleave ? +[](void* u, int o) -> hipError_t {

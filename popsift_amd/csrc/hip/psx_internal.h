@@ -97,6 +97,10 @@ struct PsxLevel0Args {
 };
 
 hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s);
+// per-tap texture coordinates exactly as the reference forms them (pyramid_alt.hip): what psx_launch_level0 runs when
+// the image / octave ratio is not a power of two (psx_level0_exact)
+hipError_t psx_launch_level0_literal(const PsxLevel0Args& a, hipStream_t s);
+bool psx_level0_exact(int w, int h, int W, int H);
 hipError_t psx_launch_blur(const float* src, float* dst, int W, int H, int pitch,
                            const PsxTaps& taps, int span,
                            float* half_dst, int half_pitch, hipStream_t s,
@@ -155,6 +159,7 @@ struct PsxAltArgs {
     float upscale_factor;
     const float *inc_filter, *inc_ifilter, *dd_filter, *abs0_filter, *absN_filter;      // host tables
     const int *inc_span, *inc_ispan, *dd_span, *abs0_span;
+    float* up; int up_pitch;     // scratch of psx_launch_level0 (the resampled, padded input: PsxLevel0Args::tmp)
     float* intm;                 // scratch: one plane of octave 0 (pitch x height)
     float* vbuf; int vbuf_pitch; // scratch of the fixed-span modes: pitch + 2*7 columns
     hipError_t (*after_octave)(void* user, int octave);   // e.g. launch the octave's extrema scan

@@ -1902,8 +1902,25 @@ hipError_t psx_launch_flow(const PsxFlowJob* d_jobs, const PsxFlowItem* d_items,
     return hipGetLastError();
 }
 
+// The U(x-k) / U(x+k) form of the level-0 kernels equals the reference's per-tap coordinates (x + shift)/W -+ k/W
+// (s_pyramid_build_ra.cu:35-50) only while both forms land on the same 1/256 sub-texel.  For a power-of-two ratio
+// between image and octave the sub-texel positions are multiples of 2^-(n+1), far from the rounding boundaries at
+// (m + 0.5)/256, and the one or two ulps between the two forms cannot matter; for any other ratio (fractional
+// setDownsampling values, ScaleDirect octaves of an odd-sized image) a few coordinates per row sit on a boundary and
+// the two forms differ by one 1/256 step -- those run the literal kernels of pyramid_alt.hip.
+static bool pow2_ratio(int big, int small)
+{
+    for (int n = 0; n <= 4; n++) if ((small << n) == big) return true;
+    return false;
+}
+bool psx_level0_exact(int w, int h, int W, int H)
+{
+    return (W >= w ? pow2_ratio(W, w) : pow2_ratio(w, W)) && (H >= h ? pow2_ratio(H, h) : pow2_ratio(h, H));
+}
+
 hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s)
 {
+    if (!psx_level0_exact(a.w, a.h, a.W, a.H)) return psx_launch_level0_literal(a, s);
     const int R = (a.span_h > a.span_v ? a.span_h : a.span_v) - 1;
     if (R <= 5)  return launch_level0_r<5>(a, s);
     if (R <= 8)  return launch_level0_r<8>(a, s);

@@ -185,6 +185,19 @@ inline dim3 grid_for(int W, int H) { return dim3((W + ANT - 1) / ANT, H); }
 
 } // namespace
 
+// normalizedSource::horiz + absoluteSource::vert with the tap coordinates formed as the reference forms them,
+// (x + shift)/W -+ k/W: level 0 from the input image when the image / octave ratio is not a power of two
+// (psx_level0_exact in pyramid.hip says why the fast kernels are not bit-exact there).  a.tmp holds the horizontal pass.
+hipError_t psx_launch_level0_literal(const PsxLevel0Args& a, hipStream_t s)
+{
+    if (a.tmp_pitch < a.pitch) return hipErrorInvalidValue;
+    const AltImg img{a.img, a.w, a.h, a.is_float};
+    const dim3 g = grid_for(a.W, a.H), b(ANT);
+    hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.tmp, a.W, a.H, a.pitch, a.taps_h, a.span_h, a.shift);
+    hipLaunchKernelGGL(k_alt_v_plain, g, b, 0, s, a.tmp, a.dst, a.W, a.H, a.pitch, a.taps_v, a.span_v);
+    return hipGetLastError();
+}
+
 // Pyramid::build_pyramid for every mode combination outside the default branch; mirrors build_pyramid() of
 // oracle/sift_oracle.c statement by statement.  Returns hipErrorInvalidValue for Fixed9 / Fixed15 with levels != 3
 // (the reference: POP_FATAL "Unsupported number of levels for making all octaves at once").
@@ -213,6 +226,19 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
             hipLaunchKernelGGL(k_alt_downscale, g, b, 0, s, po.data + (size_t)(P.L - 3) * po.plane, po.w, po.h, po.pitch,
                                plane(0), W, H, pitch);
         };
+        // normalizedSource::horiz (taps th) + absoluteSource::vert (taps tv) from the input image into `dst`: exactly what
+        // level 0 of the default pyramid is, so it goes through psx_launch_level0: the default path's kernels (k_level0_x2
+        // at x2 with a radius <= 8, k_upscale + k_blur<R, true> otherwise) when the image / octave ratio is a power of two
+        // (bit-identical planes, ~10x faster on octave 0), k_alt_h_input + k_alt_v_plain when it is not
+        auto level_from_input = [&](float* dst, const PsxTaps& th, int sh, const PsxTaps& tv, int sv) -> hipError_t {
+            PsxLevel0Args l0;
+            l0.img = a.img; l0.w = a.w; l0.h = a.h; l0.is_float = a.is_float;
+            l0.dst = dst; l0.W = W; l0.H = H; l0.pitch = pitch;
+            l0.tmp = a.up; l0.tmp_pitch = a.up_pitch;
+            l0.shift = shift;
+            l0.taps_h = th; l0.span_h = sh; l0.taps_v = tv; l0.span_v = sv;
+            return psx_launch_level0(l0, s);
+        };
         auto fixed_levels = [&](int first, bool from_input) {
             const int vpitch = a.vbuf_pitch;
             const dim3 gv((W + 2 * SHIFT + ANT - 1) / ANT, H);
@@ -239,11 +265,17 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
         } else if (direct) {
             const bool interp = (gm == PSX_GAUSS_VLFEAT_RELATIVE);
             for (int level = 0; level < P.L; level++) {
+                if (!interp) {
+                    // ScaleDirect with the plain tables: level 0 of every octave straight from the input image, the other
+                    // levels absoluteSource::horiz + vert -- the default path's fused kernels
+                    const hipError_t e2 = level == 0 ? level_from_input(plane(0), taps(a.dd_filter + o * PSX_GAUSS_ALIGN), a.dd_span[o], inc(0), a.inc_span[0])
+                                                     : psx_launch_blur(plane(level - 1), plane(level), W, H, pitch, inc(level), a.inc_span[level], nullptr, 0, s);
+                    if (e2 != hipSuccess) return e2;
+                    continue;
+                }
                 if (level == 0) hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, taps(a.dd_filter + o * PSX_GAUSS_ALIGN), a.dd_span[o], shift);
-                else if (interp) hipLaunchKernelGGL(k_alt_interp<false>, g, b, 0, s, plane(level - 1), a.intm, W, H, pitch, inci(level), a.inc_ispan[level]);
-                else hipLaunchKernelGGL(k_alt_h_plain, g, b, 0, s, plane(level - 1), a.intm, W, H, pitch, inc(level), a.inc_span[level]);
-                if (interp) hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(level), W, H, pitch, inci(level), a.inc_ispan[level]);
-                else hipLaunchKernelGGL(k_alt_v_plain, g, b, 0, s, a.intm, plane(level), W, H, pitch, inc(level), a.inc_span[level]);
+                else hipLaunchKernelGGL(k_alt_interp<false>, g, b, 0, s, plane(level - 1), a.intm, W, H, pitch, inci(level), a.inc_ispan[level]);
+                hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(level), W, H, pitch, inci(level), a.inc_ispan[level]);
             }
         } else if (gm == PSX_GAUSS_VLFEAT_RELATIVE) {
             for (int level = 0; level < P.L; level++) {
@@ -259,9 +291,10 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
             }
         } else if (o == 0 && gm == PSX_GAUSS_VLFEAT_RELATIVE_ALL) {
             for (int level = 0; level < P.L; level++) {
+                // every level of octave 0 from the input image with its absolute sigma: level-0 kernels, the level's table
                 const PsxTaps f = taps(a.abs0_filter + level * PSX_GAUSS_ALIGN);
-                hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, f, a.abs0_span[level], shift);
-                hipLaunchKernelGGL(k_alt_v_plain, g, b, 0, s, a.intm, plane(level), W, H, pitch, f, a.abs0_span[level]);
+                const hipError_t e2 = level_from_input(plane(level), f, a.abs0_span[level], f, a.abs0_span[level]);
+                if (e2 != hipSuccess) return e2;
             }
         } else {
             // the default arithmetic for this octave (VLFeat_Relative_All beyond octave 0): the fused kernels of pyramid.hip

@@ -119,6 +119,20 @@ def test_other_scale_factors_match_reference(oracle, ref, up, mode, is_float):
     identical feature sets."""
     from popsift_amd.synth import synth_float
     w, h = (200, 152) if up < -1 else (72, 56)
+    _scale_factor_case(oracle, ref, w, h, up, mode, is_float)
+
+
+@pytest.mark.parametrize("w,h,up,mode", [(321, 243, 0.5, 1), (333, 251, -0.5, 0)])
+def test_fractional_scale_factors_on_the_rounding_boundaries(oracle, ref, w, h, up, mode):
+    """Sizes at which some tap coordinates of octave 0 sit on a 1/256 sub-texel boundary, so that (x + shift)/W -+ k/W
+    (the reference, s_pyramid_build_ra.cu:35-50) and (x -+ k + shift)/W give different bits
+    (tests/test_oracle_cpu.py::test_literal_texture_form_is_what_fractional_scale_factors_get): the oracle must follow
+    the reference's form."""
+    _scale_factor_case(oracle, ref, w, h, up, mode, False)
+
+
+def _scale_factor_case(oracle, ref, w, h, up, mode, is_float):
+    from popsift_amd.synth import synth_float
     img = synth_float(w, h, 11) if is_float else synth(w, h, 11)
     cfg = oracle.default_config(octaves=3 if up > -2 else 2, upscale_factor=up, sift_mode=mode)
     r, o = ref.run(cfg, img), oracle.run(cfg, img)
