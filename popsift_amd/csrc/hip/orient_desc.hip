@@ -623,7 +623,7 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
             // dx from each of the two constraints.  A step covers 8 rows x 8 pixel pairs and every row starts at ITS
             // span (the bounding box of the rotated square is up to twice its area; walking the box in common
             // columns left about half of the lanes outside the window).  The spans are conservative by a pixel,
-            // the exact predicate below decides.
+            // the exact predicate below decides (round 4: the slack was 2-3 pixels per side, 4.6 % more steps).
             const bool use_c = fabsf(crsbp) > 1e-6f, use_s = fabsf(srsbp) > 1e-6f;
             const float rcc = use_c ? 1.0f / crsbp : 0.0f, rcs = use_s ? 1.0f / srsbp : 0.0f;
             const float fxmin = (float)xmin - x, fxmax = (float)xmax - x;
@@ -638,8 +638,10 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                 float lo = fxmin, hi = fxmax;
                 if (use_c) { const float t1 = (-1.0f - ub) * rcc, t2 = (4.0f - ub) * rcc; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
                 if (use_s) { const float t1 = (vb - 4.0f) * rcs, t2 = (vb + 1.0f) * rcs; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
-                const int xa = max(xmin, (int)floorf(x + lo) - 1) & ~1;           // even: aligned pixel pairs
-                const int xb = min(xmax, (int)floorf(x + hi) + 2);
+                // first / last pixel with lo < dx < hi is floor(x + lo) + 1 / ceil(x + hi) - 1: one pixel of slack on each side
+                // covers the rounding of lo / hi (~1e-5 pixel) many times over
+                const int xa = max(xmin, (int)floorf(x + lo)) & ~1;               // even: aligned pixel pairs
+                const int xb = min(xmax, (int)floorf(x + hi) + 1);
                 const bool rowok = ii <= ymax && lo <= hi;
                 for (int jj = xa + 2 * lx; __ballot(rowok && jj <= xb) != 0ull; jj += 16) {
                     const float dx0 = jj - x;
@@ -1058,7 +1060,9 @@ hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* 
     // leave room for the other streams' kernels meanwhile (3 per CU measured +11 % on the export leg of bench.py).
     // cus = compute units of the CONTEXT's device (one PopSift per GPU may sit on unequal devices).
     if (cus <= 0) cus = 256;
-    const int grid = exporting ? 3 * cus : 10 * cus;
+    // POPSIFT_DESC_WGS=<workgroups per CU>: measurement switch for the grid (the waves loop over the descriptors)
+    static const int per_cu = [] { const char* e = getenv("POPSIFT_DESC_WGS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }();
+    const int grid = per_cu ? per_cu * cus : exporting ? 3 * cus : 10 * cus;
     // POPSIFT_DESC_DENORM=0: round 2's conversion path (v_cvt_u32_f32 of every contribution) instead of the denormal products
     static const bool denorm = [] { const char* e = getenv("POPSIFT_DESC_DENORM"); return !(e != nullptr && e[0] == '0'); }();
     if (denorm) hipLaunchKernelGGL(k_descriptors<true>, dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);

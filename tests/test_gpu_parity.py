@@ -693,6 +693,58 @@ def test_fuzz_sweep_total_budget(oracle, capi):
     assert t["kp_miss"] <= b["kp"] and t["ori_miss"] <= b["ori"] and t["desc_miss"] <= b["desc"], (t, b)
 
 
+def _wide_fuzz_cases(n, seed):
+    """The whole Config space (tools/ref_fuzz.py walks the same one through the reference's own code on the CPU):
+    fractional and x4 scale factors, every GaussMode and ScalingMode, 2-5 levels, initial blur, grid filter."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        w, h = int(rng.integers(36, 420)), int(rng.integers(36, 300))
+        gm = int(rng.choice([0, 0, 1, 2, 3, 4, 5]))
+        kw = dict(octaves=int(rng.integers(1, 5)), sift_mode=int(rng.integers(0, 3)), gauss_mode=gm,
+                  levels=3 if gm in (4, 5) else int(rng.integers(2, 6)),
+                  upscale_factor=float(rng.choice([-2.0, -1.0, -0.5, 0.0, 0.5, 1.0, 1.0, 1.5, 2.0])),
+                  scaling_mode=int(rng.choice([1, 1, 0])),
+                  norm_mode=int(rng.integers(0, 2)), norm_multi=int(rng.choice([0, 9])),
+                  sigma=float(rng.choice([1.2, 1.6, 2.0])), threshold=float(rng.choice([0.02, 0.04, 0.06])),
+                  edge_limit=float(rng.choice([8.0, 10.0, 16.0])), initial_blur=float(rng.choice([0.0, 0.5, 0.8])))
+        if kw["upscale_factor"] >= 1.5:
+            w, h = w // 2 + 20, h // 2 + 20
+        if rng.random() < 0.25:
+            kw.update(filter_max_extrema=int(rng.integers(20, 300)), filter_grid_size=int(rng.integers(1, 4)),
+                      grid_filter_mode=int(rng.integers(1, 3)))     # RandomScale depends on buffer order: left out
+        out.append((w, h, 11000 + i, bool(rng.random() < 0.3), kw))
+    return out
+
+
+@pytest.mark.parametrize("w,h,seed,is_float,kw", _wide_fuzz_cases(80, 2468))
+def test_fuzz_wide_configs(oracle, capi, w, h, seed, is_float, kw):
+    """Every pyramid branch x scale factor x mode at random odd sizes: planes bit-exact, initial extrema identical,
+    features within budget().  (Fractional scale factors and ScaleDirect octaves take the literal level-0 kernels where
+    the image / octave ratio is not a power of two -- pyramid.hip psx_level0_exact.)"""
+    img = synth_float(w, h, seed) if is_float else synth(w, h, seed)
+    ref = oracle.run(oracle.default_config(**kw), img)
+    ctx = capi.Context(capi.default_config(**kw))
+    ctx.upload(img)
+    ctx.extract()
+    assert ctx.num_octaves == ref.num_octaves and ctx.num_levels == ref.num_levels
+    for o in range(ref.num_octaves):
+        assert ctx.octave_dims(o) == ref.dims[o]
+        for l in range(ref.num_levels):
+            g = ctx.dump_plane(capi.PLANE_GAUSS, o, l)
+            assert np.array_equal(g.view(np.uint32), ref.gauss(o, l).view(np.uint32)), (o, l, float(np.abs(g - ref.gauss(o, l)).max()))
+        a, b = sort_iext(ref.iext(o)), sort_iext(ctx.dump_iext(o))
+        assert len(a) == len(b), (o, len(a), len(b))
+        for f in ("xpos", "ypos", "lpos"):
+            assert np.array_equal(a[f], b[f]), (o, f)
+    fb, db = ctx.download()
+    fa, da = ref.features(), ref.descriptors()
+    assert len(fa) == len(fb)
+    if len(fa):
+        assert_parity(match_features(fa, da, fb, db, norm_scale=float(2 ** kw["norm_multi"])), what="wide fuzz %s" % kw, **budget(len(fa)))
+    ctx.close()
+
+
 @pytest.mark.parametrize("w,h", [(3000, 9), (7, 2500), (65, 65), (63, 129), (4097, 33), (128, 1), (1, 128), (2, 2), (1920, 16)])
 def test_extreme_shapes(oracle, capi, w, h):
     """Strips thinner than a filter radius, planes smaller than a tile, one pixel wide / high, widths just over
