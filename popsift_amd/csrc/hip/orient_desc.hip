@@ -247,12 +247,17 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                     // along exact bin boundaries (gdx == gdy gives 45 deg = bin 22.5) are common in smooth images and
                     // the rule in binary / symmetric ones, where the bin hangs on the last ulp of the angle; one heavy
                     // sample in the wrong bin moves the interpolated peak by ~6e-3 rad.
-                    // The 3.3e-7 rad polynomial (2e-6 bins) decides every sample that is not within 1e-3 bins of a
-                    // boundary; only those (about 0.2 % of the samples) take the exact, ~50-instruction form.
+                    // The 3.3e-7 rad polynomial decides every sample that is not within 2e-4 bins of a boundary.  Error budget
+                    // of bfast against the exact expression, in bins (1 rad = 5.73 bins): polynomial + v_rcp 4e-7 rad and the
+                    // rounding of the exact angle 1.2e-7 rad -> 3e-6; RN(at + pi) on both sides 2 x 1.4e-6; RN(36 s) on both
+                    // sides 2 x 1.2e-6; the rounded constant 1/2pi 2e-6; the last rounding on both sides 2 x 1.9e-6: < 1.5e-5
+                    // in total, 13 times below the threshold.  About 0.04 % of the samples take the exact form (two calls
+                    // of ~130 VALU instructions, f64): with 128 samples per step that is 5 % of the steps (round 3's 1e-3
+                    // threshold put 23 % of the steps through it: a quarter of the kernel's instructions).
                     const float bfast = (float)ORI_NBINS * (at + PI_F) * (1.0f / PI2_F);
                     const float bfl = floorf(bfast);
                     int bidx = (int)bfl + ((bfast - bfl) >= 0.5f ? 1 : 0);
-                    if (fabsf((bfast - bfl) - 0.5f) < 1e-3f)
+                    if (fabsf((bfast - bfl) - 0.5f) < 2e-4f)
                         bidx = (int)roundf((float)ORI_NBINS * (atan2_1r(gy, gx) + PI_F) / PI2_F);
                     bidx = (bidx == ORI_NBINS) ? 0 : bidx;
                     atomicAdd(&myhist[bidx], (fix64)(weight * OFIX));
