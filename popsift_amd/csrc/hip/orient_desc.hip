@@ -71,16 +71,32 @@ __device__ __forceinline__ void lds_add(unsigned LDS_AS* p, unsigned v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Butterfly over the 64 lanes, partner lane ^ K for K = 32, 16, 8, 4, 2, 1 -- the order and the operand pairs of
+// "v = op(v, __shfl_xor(v, K))", hence the same bits, without the six VALU of address arithmetic that every __shfl_xor
+// (ds_bpermute) carries: v_permlane32_swap (gfx950) for the half-wave exchange, ds_swizzle's lane-swap patterns for
+// 16 / 8 / 4 (no address operand), DPP quad_perm for 2 / 1.
+template <int K>
+__device__ __forceinline__ float lane_xor(float v)
+{
+    static_assert(K == 16 || K == 8 || K == 4 || K == 2 || K == 1, "lane_xor");
+    if constexpr (K == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    else if constexpr (K == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    else return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (K << 10) | 0x1f));                      // bit-mask mode: lane ^ K
+}
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    // lanes 0..31 of the pair hold (v[i], v[i + 32]), lanes 32..63 (v[i - 32], v[i]): op of the two is op(v[i], v[i ^ 32]) everywhere
+    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = fmaxf(__int_as_float(h[0]), __int_as_float(h[1]));
+    v = fmaxf(v, lane_xor<16>(v)); v = fmaxf(v, lane_xor<8>(v)); v = fmaxf(v, lane_xor<4>(v));
+    v = fmaxf(v, lane_xor<2>(v));  v = fmaxf(v, lane_xor<1>(v));
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    const auto h = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = __int_as_float(h[0]) + __int_as_float(h[1]);
+    v += lane_xor<16>(v); v += lane_xor<8>(v); v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);
     return v;
 }
 
@@ -277,14 +293,17 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         }
         const int prev_l = isbin ? (lane == 0 ? ORI_NBINS - 1 : lane - 1) : lane;
         const int next_l = isbin ? (lane == ORI_NBINS - 1 ? 0 : lane + 1) : lane;
+        // ds_bpermute with the two byte addresses formed once (__shfl recomputes them, ~4 VALU, at each of its 14 uses)
+        auto from = [](int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); };
+        const int prev_a = prev_l * 4, next_a = next_l * 4;
 #pragma unroll
         for (int it = 0; it < 6; it++) {   // 3 x (hist->sm_hist->hist), s_orientation.cu:166-174
-            const float pv = __shfl(hval, prev_l);
-            const float nv = __shfl(hval, next_l);
+            const float pv = from(prev_a, hval);
+            const float nv = from(next_a, hval);
             hval = div3(pv + hval + nv);
         }
-        const float hp = __shfl(hval, prev_l);
-        const float hn = __shfl(hval, next_l);
+        const float hp = from(prev_a, hval);
+        const float hn = from(next_a, hval);
         bool predicate = isbin && (hval > fmaxf(hp, hn));
         const float num  = predicate ? 3.0f * hp - 4.0f * hval + 1.0f * hn : 0.0f;
         const float denB = predicate ? 2.0f * (hp - 2.0f * hval + hn) : 1.0f;
@@ -579,7 +598,9 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
         const int ext_idx = P->feat_to_ext[j];
         const psx_extremum ex = P->extrema[ext_idx];
         const int ori_num = psx_clampi(j - ex.idx_ori, 0, PSX_ORI_MAX - 1);
-        const float ang = ex.orientation[ori_num];
+        // a select chain, not ex.orientation[ori_num]: the dynamic index sent the whole record through scratch memory
+        static_assert(PSX_ORI_MAX == 4, "orientation select chain");
+        const float ang = ori_num == 0 ? ex.orientation[0] : ori_num == 1 ? ex.orientation[1] : ori_num == 2 ? ex.orientation[2] : ex.orientation[3];
         const PsxOctave oc = P->oct[ex.octave];
         const int width = oc.w, height = oc.h;
 
@@ -852,7 +873,7 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
         const int ext_idx = P->feat_to_ext[j];
         const psx_extremum ex = P->extrema[ext_idx];
         const int ori_num = psx_clampi(j - ex.idx_ori, 0, PSX_ORI_MAX - 1);
-        const float ang = ex.orientation[ori_num];
+        const float ang = ori_num == 0 ? ex.orientation[0] : ori_num == 1 ? ex.orientation[1] : ori_num == 2 ? ex.orientation[2] : ex.orientation[3];   // no scratch copy of ex
         const PsxOctave oc = P->oct[ex.octave];
         const int W = oc.w, H = oc.h, pitch = oc.pitch;
         if (ori_num == 0 && lane == 0) write_feature(P, X, ext_idx, ex, ex.idx_ori, total);
