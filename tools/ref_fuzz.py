@@ -32,7 +32,8 @@ def cases(n, seed, max_side):
                   norm_mode=int(rng.integers(0, 2)), norm_multi=int(rng.choice([0, 9])),
                   sigma=float(rng.choice([1.2, 1.6, 2.0])), threshold=float(rng.choice([0.02, 0.04, 0.06])),
                   edge_limit=float(rng.choice([8.0, 10.0, 16.0])),
-                  initial_blur=float(rng.choice([0.0, 0.5, 0.8])))
+                  initial_blur=float(rng.choice([0.0, 0.5, 0.8])),
+                  desc_mode=int(rng.choice([0, 0, 0, 1, 3, 4])))   # grid (2) is a bound, not a match: tests/test_ref_shim_cpu.py
         if kw["upscale_factor"] >= 1.5 and max(w, h) > 160:
             w, h = w // 2 + 20, h // 2 + 20                  # the emulation is slow: keep octave 0 under ~0.3 Mpix
         if rng.random() < 0.25:
