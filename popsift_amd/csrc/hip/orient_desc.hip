@@ -631,18 +631,17 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
             const float bsz   = fabsf(csbp) + fabsf(ssbp);
             const float ang_bins = ang * M_4RPI_F;
 
-            int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -0x7fffffff, ymax = -0x7fffffff;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float ox = (c & 1) ? 1.5f : -1.5f;
-                const float oy = (c & 2) ? 1.5f : -1.5f;
-                const float ptx = fmaf(csbp, ox, fmaf(-ssbp, oy, x));
-                const float pty = fmaf(csbp, oy, fmaf( ssbp, ox, y));
-                xmin = min(xmin, (int)floorf(ptx - bsz));
-                ymin = min(ymin, (int)floorf(pty - bsz));
-                xmax = max(xmax, (int)floorf(ptx + bsz));
-                ymax = max(ymax, (int)floorf(pty + bsz));
-            }
+            // bounding box of the four corners (+-1.5, +-1.5) widened by bsz (s_desc_loop.cu:46-58): floor(p - bsz) and
+            // floor(p + bsz) are monotone in p, so the minimum / maximum over the corners is taken BEFORE the floor -- the
+            // same integers as four floors each, a third of the instructions
+            const float ix0 = fmaf(-ssbp, -1.5f, x), ix1 = fmaf(-ssbp, 1.5f, x);     // corner x = csbp*ox - ssbp*oy + x
+            const float iy0 = fmaf( ssbp, -1.5f, y), iy1 = fmaf( ssbp, 1.5f, y);     // corner y = csbp*oy + ssbp*ox + y
+            const float px0 = fmaf(csbp, -1.5f, ix0), px1 = fmaf(csbp, 1.5f, ix0), px2 = fmaf(csbp, -1.5f, ix1), px3 = fmaf(csbp, 1.5f, ix1);
+            const float py0 = fmaf(csbp, -1.5f, iy0), py1 = fmaf(csbp, -1.5f, iy1), py2 = fmaf(csbp, 1.5f, iy0), py3 = fmaf(csbp, 1.5f, iy1);
+            int xmin = (int)floorf(fminf(fminf(px0, px1), fminf(px2, px3)) - bsz);
+            int xmax = (int)floorf(fmaxf(fmaxf(px0, px1), fmaxf(px2, px3)) + bsz);
+            int ymin = (int)floorf(fminf(fminf(py0, py1), fminf(py2, py3)) - bsz);
+            int ymax = (int)floorf(fmaxf(fmaxf(py0, py1), fmaxf(py2, py3)) + bsz);
             xmin = max(1, xmin); ymin = max(1, ymin);
             xmax = min(width - 2, xmax); ymax = min(height - 2, ymax);
             // Row spans.  The window is the rotated square -1 < u, v < 4; in a row (dy fixed) that is an interval of
@@ -651,7 +650,8 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
             // columns left about half of the lanes outside the window).  The spans are conservative by a pixel,
             // the exact predicate below decides (round 4: the slack was 2-3 pixels per side, 4.6 % more steps).
             const bool use_c = fabsf(crsbp) > 1e-6f, use_s = fabsf(srsbp) > 1e-6f;
-            const float rcc = use_c ? 1.0f / crsbp : 0.0f, rcs = use_s ? 1.0f / srsbp : 0.0f;
+            // v_rcp_f32 (1 ulp) instead of two IEEE divisions: these only place the conservative spans
+            const float rcc = use_c ? __builtin_amdgcn_rcpf(crsbp) : 0.0f, rcs = use_s ? __builtin_amdgcn_rcpf(srsbp) : 0.0f;
             const float fxmin = (float)xmin - x, fxmax = (float)xmax - x;
 
             for (int ty = ymin; ty <= ymax; ty += 8) {
