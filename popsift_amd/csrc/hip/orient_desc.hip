@@ -654,21 +654,37 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
             const float rcc = use_c ? __builtin_amdgcn_rcpf(crsbp) : 0.0f, rcs = use_s ? __builtin_amdgcn_rcpf(srsbp) : 0.0f;
             const float fxmin = (float)xmin - x, fxmax = (float)xmax - x;
 
-            for (int ty = ymin; ty <= ymax; ty += 8) {
+            // The spans of 64 rows at a time, one row per lane (the same expressions as before, evaluated once per row instead
+            // of once per lane and 8-row step: ~35 VALU per step-group became one ds_bpermute and ~10); a step-group fetches
+            // its rows' entries from the lanes that hold them.  Entry = first column | end column << 16, relative to the box.
+            const int xmin0 = xmin & ~1;
+            for (int cy = ymin; cy <= ymax; cy += PSX_WAVE) {
+                int sp;
+                {
+                    const int ii = cy + lane;
+                    const float dyk = ii - y;
+                    const float ub = fmaf(srsbp, dyk, 1.5f);      // u = crsbp*dx + srsbp*dy + 1.5
+                    const float vb = fmaf(crsbp, dyk, 1.5f);      // v = crsbp*dy - srsbp*dx + 1.5
+                    // -1 < u < 4  <=>  crsbp*dx in (-1 - ub, 4 - ub);   -1 < v < 4  <=>  srsbp*dx in (vb - 4, vb + 1)
+                    float lo = fxmin, hi = fxmax;
+                    if (use_c) { const float t1 = (-1.0f - ub) * rcc, t2 = (4.0f - ub) * rcc; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
+                    if (use_s) { const float t1 = (vb - 4.0f) * rcs, t2 = (vb + 1.0f) * rcs; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
+                    // first / last pixel with lo < dx < hi is floor(x + lo) + 1 / ceil(x + hi) - 1: one pixel of slack on each side
+                    // covers the rounding of lo / hi (~1e-5 pixel) many times over
+                    const int xa = max(xmin, (int)floorf(x + lo)) & ~1;               // even: aligned pixel pairs
+                    const int xb = min(xmax, (int)floorf(x + hi) + 1);
+                    sp = (ii <= ymax && lo <= hi && xa <= xb) ? ((xa - xmin0) | ((xb - xmin0) << 16)) : 1;      // 1: first column 1 > end 0
+                }
+            const int cy_end = min(cy + PSX_WAVE - 1, ymax);
+            for (int ty = cy; ty <= cy_end; ty += 8) {
                 const int ii = ty + ly;
+                const int ent = __builtin_amdgcn_ds_bpermute((ty - cy) * 4 + ly * 4, sp);
+                const int xa = xmin0 + (ent & 0xffff), xb = xmin0 + (int)((unsigned)ent >> 16);
+                const bool rowok = xa <= xb;
                 const float dyk = ii - y;
-                const float ub = fmaf(srsbp, dyk, 1.5f);      // u = crsbp*dx + srsbp*dy + 1.5
-                const float vb = fmaf(crsbp, dyk, 1.5f);      // v = crsbp*dy - srsbp*dx + 1.5
+                const float ub = fmaf(srsbp, dyk, 1.5f);
+                const float vb = fmaf(crsbp, dyk, 1.5f);
                 const unsigned rowoff = (unsigned)ii * pitch4;
-                // -1 < u < 4  <=>  crsbp*dx in (-1 - ub, 4 - ub);   -1 < v < 4  <=>  srsbp*dx in (vb - 4, vb + 1)
-                float lo = fxmin, hi = fxmax;
-                if (use_c) { const float t1 = (-1.0f - ub) * rcc, t2 = (4.0f - ub) * rcc; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
-                if (use_s) { const float t1 = (vb - 4.0f) * rcs, t2 = (vb + 1.0f) * rcs; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
-                // first / last pixel with lo < dx < hi is floor(x + lo) + 1 / ceil(x + hi) - 1: one pixel of slack on each side
-                // covers the rounding of lo / hi (~1e-5 pixel) many times over
-                const int xa = max(xmin, (int)floorf(x + lo)) & ~1;               // even: aligned pixel pairs
-                const int xb = min(xmax, (int)floorf(x + hi) + 1);
-                const bool rowok = ii <= ymax && lo <= hi;
                 for (int jj = xa + 2 * lx; __ballot(rowok && jj <= xb) != 0ull; jj += 16) {
                     const float dx0 = jj - x;
                     const v2f dxk = (v2f){dx0, dx0 + 1.0f};
@@ -773,6 +789,7 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                         }
                     }
                 }
+            }
             }
         }
         wave_fence();
