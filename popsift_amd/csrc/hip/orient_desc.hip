@@ -680,12 +680,14 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                 const int ii = ty + ly;
                 const int ent = __builtin_amdgcn_ds_bpermute((ty - cy) * 4 + ly * 4, sp);
                 const int xa = xmin0 + (ent & 0xffff), xb = xmin0 + (int)((unsigned)ent >> 16);
-                const bool rowok = xa <= xb;
+                // an empty row ends before every column: "jj <= xbe" is then the whole row test (one v_cmp feeds the loop
+                // condition and, as a mask, the window test; all window pixels of a row lie in [xa, xb])
+                const int xbe = xa <= xb ? xb : -0x7fffffff;
                 const float dyk = ii - y;
                 const float ub = fmaf(srsbp, dyk, 1.5f);
                 const float vb = fmaf(crsbp, dyk, 1.5f);
                 const unsigned rowoff = (unsigned)ii * pitch4;
-                for (int jj = xa + 2 * lx; __ballot(rowok && jj <= xb) != 0ull; jj += 16) {
+                for (int jj = xa + 2 * lx; __builtin_amdgcn_sicmp(jj, xbe, 41 /* ICMP_SLE */) != 0ull; jj += 16) {
                     const float dx0 = jj - x;
                     const v2f dxk = (v2f){dx0, dx0 + 1.0f};
                     const v2f u = pk_fma(splat(crsbp), dxk, splat(ub));
@@ -693,9 +695,9 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                     // the window -1 < u, v < 4 as |u - 1.5|, |v - 1.5| < 2.5: four compares with free abs modifiers instead of
                     // eight (a pixel within an ulp of the border has a weight of that order: it does not matter which side it falls)
                     const v2f un = u - splat(1.5f), vn = v - splat(1.5f);
-                    const bool in0 = rowok && (jj >= xmin) && (jj <= xmax) && (fabsf(un.x) < 2.5f) && (fabsf(vn.x) < 2.5f);
-                    const bool in1 = rowok && (jj + 1 <= xmax) && (fabsf(un.y) < 2.5f) && (fabsf(vn.y) < 2.5f);
-                    if (__ballot(in0 || in1) == 0ull) continue;
+                    const bool in0 = (jj <= xbe) && (jj >= xmin) && (fabsf(un.x) < 2.5f) && (fabsf(vn.x) < 2.5f);     // xbe <= xmax
+                    const bool in1 = (jj < xbe) && (fabsf(un.y) < 2.5f) && (fabsf(vn.y) < 2.5f);
+                    // (no separate "any lane?" test: the branch around the block below is taken when exec comes out empty)
                     // (a software pipeline that issues the next step's loads before this step's arithmetic was
                     // measured: the compiler's conservative s_waitcnt across the loop edge undoes it, +12 %)
                     if (in0 || in1) {
