@@ -182,7 +182,12 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         const float x = ie.xpos, y = ie.ypos;
         const int   level = psx_clampi(ie.lpos, 0, P->L - 1);
         const float sig = ie.sigma;
-        const char* plane = reinterpret_cast<const char*>(oc.data + (size_t)level * oc.plane);
+        // the keypoint record arrives through vector loads: put the (wave-uniform) plane address back into scalar registers, so
+        // that the gradient loads are "scalar base + 32-bit lane offset"
+        const unsigned long long pb = (unsigned long long)(uintptr_t)(oc.data + (size_t)level * oc.plane);
+        const unsigned pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb);
+        const unsigned pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
+        const char* plane = reinterpret_cast<const char*>((uintptr_t)(((unsigned long long)pb_hi << 32) | pb_lo));
         const unsigned pitch4 = (unsigned)oc.pitch * 4u;
 
         const float sigw = ORI_WINFACTOR * sig;
@@ -212,9 +217,9 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
             // i / pw without integer division: (i+0.5)/pw is >= 0.5/pw away from an integer
             const int q = (int)(((float)i + 0.5f) * rcp_pw);
             const int yy = q + ymin;
-            const int xx = 2 * (i - q * pw) + xs;
+            const int xx = 2 * (i - __mul24(q, pw)) + xs;
             // uniform plane base + 32-bit byte offset: global_load with scalar base
-            const unsigned off = (unsigned)yy * pitch4 + (unsigned)xx * 4u;
+            const unsigned off = __umul24((unsigned)yy, pitch4) + (unsigned)xx * 4u;   // rows and pitch bytes < 2^24: v_mul_u32_u24 (v_mul_lo_u32 is quarter rate)
             const v2f  ctr = *(gv2f_p)(plane + off);                  // p[xx], p[xx+1]
             const float lft = *(gfloat_p)(plane + off - 4u);          // p[xx-1]
             const float rgt = *(gfloat_p)(plane + off + 8u);          // p[xx+2]
@@ -276,7 +281,10 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                     if (fabsf((bfast - bfl) - 0.5f) < 2e-4f)
                         bidx = (int)roundf((float)ORI_NBINS * (atan2_1r(gy, gx) + PI_F) / PI2_F);
                     bidx = (bidx == ORI_NBINS) ? 0 : bidx;
-                    atomicAdd(&myhist[bidx], (fix64)(weight * OFIX));
+                    // weight <= |gradient| <= 255 sqrt 2 for pixel values in 0..255 (float images: 0..1 scaled by 255 at level
+                    // 0), so weight * 2^23 < 2^32: one v_cvt_u32_f32 (truncating like the 64-bit conversion, saturating beyond
+                    // the range) instead of the seven instructions of float -> u64
+                    atomicAdd(&myhist[bidx], (fix64)(unsigned)(weight * OFIX));
                 }
             }
         }
