@@ -227,6 +227,14 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     // ---- stage DoG tile: every thread owns <= NE elements; all their loads are issued before the
     // first use so that one HBM round trip covers the whole tile ----
     constexpr int NE = (THP * TWP + NT - 1) / NT;
+    // addresses as "uniform level base (scalar registers) + 32-bit byte offset of the pixel within its plane": the generic
+    // form (64-bit pointer arithmetic per load through v_mad_u64_u32 / v_mul_lo_u32, flat loads) was a third of the
+    // kernel's vector instructions
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef const __attribute__((address_space(1))) float* gfloat_p;
+    const gchar_p gbase = (gchar_p)oc.data;
+    const size_t plane_b = (size_t)oc.plane * sizeof(float);
+    const unsigned pitch_b = (unsigned)oc.pitch * 4u;                 // rows and pitch bytes < 2^24: v_mul_u32_u24
     if (L == 6) {
         float g[NE][6];
 #pragma unroll
@@ -236,9 +244,9 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
             const int ry = ec / TWP, rx = ec - ry * TWP;
             const int gx = psx_clampi(tx0 - 1 + rx, 0, oc.w - 1);
             const int gy = psx_clampi(ty0 - 1 + ry, 0, oc.h - 1);
-            const float* p = oc.data + (size_t)gy * oc.pitch + gx;
+            const unsigned off = __umul24((unsigned)gy, pitch_b) + (unsigned)gx * 4u;
 #pragma unroll
-            for (int l = 0; l < 6; l++) g[k][l] = p[(size_t)l * oc.plane];
+            for (int l = 0; l < 6; l++) g[k][l] = *(gfloat_p)(gbase + l * plane_b + off);
         }
 #pragma unroll
         for (int k = 0; k < NE; k++) {
@@ -254,10 +262,10 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
             const int ry = e / TWP, rx = e - ry * TWP;
             const int gx = psx_clampi(tx0 - 1 + rx, 0, oc.w - 1);
             const int gy = psx_clampi(ty0 - 1 + ry, 0, oc.h - 1);
-            const float* p = oc.data + (size_t)gy * oc.pitch + gx;
-            float prev = p[0];
+            const unsigned off = __umul24((unsigned)gy, pitch_b) + (unsigned)gx * 4u;
+            float prev = *(gfloat_p)(gbase + off);
             for (int l = 0; l < NL; l++) {
-                const float cur = p[(size_t)(l + 1) * oc.plane];
+                const float cur = *(gfloat_p)(gbase + (size_t)(l + 1) * plane_b + off);
                 sD[(l * THP + ry) * TWP + rx] = cur - prev;
                 prev = cur;
             }
