@@ -577,6 +577,13 @@ __device__ __forceinline__ void normalize_store(const PsxParams* P, const PsxExp
 // (134 -> ~118 VALU per step).  f32 denormals are not flushed on gfx950 (HIP default) and run at the normal rate; the
 // intermediate weights are denormal too, i.e. rounded to the same grid before the last product: <= 2 units of 2^-14 per
 // contribution instead of 1/2, against descriptor sums of 10^2..10^3.
+// byte offset of the u64 that holds bins (fo, fo + 1) in a tile's two views: even fo -> word fo, odd fo -> word 8 + fo - 1
+__device__ __forceinline__ unsigned bin_slot(unsigned fo)
+{
+    const unsigned h = fo & 7u;
+    return ((((h << 3) | h) >> 1) & 7u) << 3;            // v_and, v_lshl_or, v_bfe; the shift rides on the add
+}
+
 template <bool DENORM>
 __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
 {
@@ -625,7 +632,9 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
         const unsigned pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb);
         const unsigned pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb >> 32));
         const char* plane = reinterpret_cast<const char*>((uintptr_t)(((unsigned long long)pb_hi << 32) | pb_lo));
-        const unsigned pitch4 = (unsigned)oc.pitch * 4u;
+        const unsigned pitch4 = __builtin_amdgcn_readfirstlane((unsigned)oc.pitch * 4u);     // the octave record came through vector loads
+        const char* plane_dn = plane + pitch4;
+        const char* plane_up = plane - pitch4;
 
         if (SBP != 0.0f) {
             // the reference takes __sincosf here (s_desc_loop.cu:38); v_sin_f32 / v_cos_f32 work in revolutions
@@ -695,8 +704,9 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                 const float ub = fmaf(srsbp, dyk, 1.5f);
                 const float vb = fmaf(crsbp, dyk, 1.5f);
                 const unsigned rowoff = (unsigned)ii * pitch4;
-                for (int jj = xa + 2 * lx; __builtin_amdgcn_sicmp(jj, xbe, 41 /* ICMP_SLE */) != 0ull; jj += 16) {
-                    const float dx0 = jj - x;
+                float fj = (float)(xa + 2 * lx);          // the column as a float beside the integer: + 16 is exact, no conversion per step
+                for (int jj = xa + 2 * lx; __builtin_amdgcn_sicmp(jj, xbe, 41 /* ICMP_SLE */) != 0ull; jj += 16, fj += 16.0f) {
+                    const float dx0 = fj - x;
                     const v2f dxk = (v2f){dx0, dx0 + 1.0f};
                     const v2f u = pk_fma(splat(crsbp), dxk, splat(ub));
                     const v2f v = pk_fma(splat(-srsbp), dxk, splat(vb));
@@ -713,8 +723,9 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                         const v2f  ctr = *(gv2f_p)(plane + off);                  // p[jj], p[jj+1]
                         const float lft = *(gfloat_p)(plane + off - 4u);          // p[jj-1]
                         const float rgt = *(gfloat_p)(plane + off + 8u);          // p[jj+2]
-                        const v2f  dwn = *(gv2f_p)(plane + (off + pitch4));
-                        const v2f  upp = *(gv2f_p)(plane + (off - pitch4));
+                        // the rows above and below through their own (uniform) bases: one lane offset serves all three loads
+                        const v2f  dwn = *(gv2f_p)(plane_dn + off);
+                        const v2f  upp = *(gv2f_p)(plane_up + off);
                         const v2f gdx = (v2f){ctr.y - lft, rgt - ctr.x};
                         const v2f gdy = dwn - upp;
                         const v2f m2 = pk_fma(gdx, gdx, gdy * gdy);
@@ -759,17 +770,16 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                             const v2f tidx = pk_fma(fv, splat(5.0f), fu + splat(6.0f));
                             if (in0) {
                                 const v2f pw = (v2f){wgt1.x, wgt2.x};
-                                const unsigned fo = (unsigned)((int)ffo.x & 7);
-                                // tile (iy0, ix0) at 64-byte granules; pair view: even fo -> word fo, odd fo -> word 8 + fo - 1
-                                const unsigned tb = myacc + (unsigned)(int)tidx.x * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                                // tile (iy0, ix0) at 64-byte granules; pair view: even fo -> word fo, odd fo -> word 8 + fo - 1, i.e. the
+                                // u64 slot (b0 b2 b1) for fo = (b2 b1 b0): the three bits rotated right by one
+                                const unsigned tb = bin_slot((unsigned)(int)ffo.x) + (((unsigned)(int)tidx.x << 6) + myacc);
                                 fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                                 lds_add(t, bits(pw * splat(w00.x)));      lds_add(t + 8, bits(pw * splat(w01.x)));       // +1 tile = 16 words = 8 u64
                                 lds_add(t + 40, bits(pw * splat(w10.x))); lds_add(t + 48, bits(pw * splat(w11.x)));      // +5 / +6 tiles
                             }
                             if (in1) {
                                 const v2f pw = (v2f){wgt1.y, wgt2.y};
-                                const unsigned fo = (unsigned)((int)ffo.y & 7);
-                                const unsigned tb = myacc + (unsigned)(int)tidx.y * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                                const unsigned tb = bin_slot((unsigned)(int)ffo.y) + (((unsigned)(int)tidx.y << 6) + myacc);
                                 fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                                 lds_add(t, bits(pw * splat(w00.y)));      lds_add(t + 8, bits(pw * splat(w01.y)));
                                 lds_add(t + 40, bits(pw * splat(w10.y))); lds_add(t + 48, bits(pw * splat(w11.y)));
