@@ -769,7 +769,7 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                             // tile index (iy0 + 1) * 5 + (ix0 + 1) in float (small exact integers), one conversion per pixel
                             const v2f tidx = pk_fma(fv, splat(5.0f), fu + splat(6.0f));
                             if (in0) {
-                                const v2f pw = (v2f){wgt1.x, wgt2.x};
+                                const v2f pw = pk_fma(splat(wgt2.x), (v2f){-1.0f, 1.0f}, (v2f){1.0f, 0.0f});     // (1 - w, w) = (wgt1.x, wgt2.x) without moving components
                                 // tile (iy0, ix0) at 64-byte granules; pair view: even fo -> word fo, odd fo -> word 8 + fo - 1, i.e. the
                                 // u64 slot (b0 b2 b1) for fo = (b2 b1 b0): the three bits rotated right by one
                                 const unsigned tb = bin_slot((unsigned)(int)ffo.x) + (((unsigned)(int)tidx.x << 6) + myacc);
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                                 lds_add(t + 40, bits(pw * splat(w10.x))); lds_add(t + 48, bits(pw * splat(w11.x)));      // +5 / +6 tiles
                             }
                             if (in1) {
-                                const v2f pw = (v2f){wgt1.y, wgt2.y};
+                                const v2f pw = pk_fma(splat(wgt2.y), (v2f){-1.0f, 1.0f}, (v2f){1.0f, 0.0f});
                                 const unsigned tb = bin_slot((unsigned)(int)ffo.y) + (((unsigned)(int)tidx.y << 6) + myacc);
                                 fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                                 lds_add(t, bits(pw * splat(w00.y)));      lds_add(t + 8, bits(pw * splat(w01.y)));
