@@ -18,7 +18,7 @@ from popsift_amd import capi
 from popsift_amd.synth import synth, synth_float
 from tests import adversarial as adv
 from tests.parity import match_features, sort_iext
-from tests.test_gpu_parity import _fuzz_cases
+from tests.test_gpu_parity import _fuzz_cases, _wide_fuzz_cases
 
 n_fuzz = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 out = sys.argv[2] if len(sys.argv) > 2 else None
@@ -58,6 +58,10 @@ acc = fresh()
 for (w, h, s, is_float, kw) in _fuzz_cases(n_fuzz, 424242):
     one(synth_float(w, h, s) if is_float else synth(w, h, s), kw, acc)
 res["fuzz_small_configs"] = acc
+acc = fresh()
+for (w, h, s, is_float, kw) in _wide_fuzz_cases(max(50, n_fuzz // 2), 171717):     # round 4: the whole Config space (modes, scale factors, grid filter)
+    one(synth_float(w, h, s) if is_float else synth(w, h, s), kw, acc)
+res["fuzz_wide_configs"] = acc
 acc = fresh()
 for i in range(8):
     one(synth(1920, 1080, 1000 + i), dict(octaves=5), acc)
