@@ -236,6 +236,15 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     const size_t plane_b = (size_t)oc.plane * sizeof(float);
     const unsigned pitch_b = (unsigned)oc.pitch * 4u;                 // rows and pitch bytes < 2^24: v_mul_u32_u24
     if (L == 6) {
+        // one scalar base per level (readfirstlane keeps "base + level * plane" from being re-associated into per-lane 64-bit
+        // additions): every load is "scalar base + the pixel's 32-bit offset"
+        gchar_p lb[6];
+#pragma unroll
+        for (int l = 0; l < 6; l++) {
+            const unsigned long long a = (unsigned long long)(uintptr_t)(gbase + l * plane_b);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+            lb[l] = (gchar_p)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+        }
         float g[NE][6];
 #pragma unroll
         for (int k = 0; k < NE; k++) {
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
             const int gy = psx_clampi(ty0 - 1 + ry, 0, oc.h - 1);
             const unsigned off = __umul24((unsigned)gy, pitch_b) + (unsigned)gx * 4u;
 #pragma unroll
-            for (int l = 0; l < 6; l++) g[k][l] = *(gfloat_p)(gbase + l * plane_b + off);
+            for (int l = 0; l < 6; l++) g[k][l] = *(gfloat_p)(lb[l] + off);
         }
 #pragma unroll
         for (int k = 0; k < NE; k++) {
