@@ -300,6 +300,28 @@ __device__ __forceinline__ void blur_body(const BlurArgs& a, const int lid, floa
 #ifdef PSX_PHASE_TIMING
             if (a.dbg & 4) drow = reinterpret_cast<GLOBAL_AS char*>(gdst + (ptrdiff_t)(64 + (blockIdx.x & 7) * 40) * a.pitch);   // stores stay in L2
 #endif
+            // Fast path (workgroup uniform): every row of step kk lies inside the chunk and the strip is a full one with both
+            // columns of every pair inside the plane -- all but the first flush of a chunk and the plane's last strip.  No
+            // per-row range test, no exec juggling around the stores: 4 x (base of the row in scalar registers + the thread's
+            // 32-bit offset).
+            if constexpr (FLOW == 0) {
+                if (kk * BR >= 2 * R && Y0 + (kk + 1) * BR - 2 * R <= Y1 && x0 + TW <= a.W) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        GLOBAL_AS char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
+                        unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
+                        __hip_atomic_store(reinterpret_cast<GLOBAL_AS unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    if (a.half_dst != nullptr) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int r_out = r_out0 + i;
+                            if ((r_out & 1) == 0) ghalf[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
+                        }
+                    }
+                    return;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int r_out = r_out0 + i;
