@@ -1087,6 +1087,16 @@ __device__ __forceinline__ void level0_body(const L0Args& a, const int lid)
     auto flush = [&](const int kk) {
         const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
         char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
+        // workgroup uniform fast path, as in blur_body: all 32 rows of the step inside the chunk, a full strip
+        if (kk * BR >= 2 * R && Y0 + (kk + 1) * BR - 2 * R <= Y1 && x0 + TW <= a.W) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
+                unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r_out = r_out0 + i;
@@ -1275,6 +1285,16 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
     auto flush = [&](const int kk) {
         const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
         char* drow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
+        // workgroup uniform fast path, as in blur_body: all 32 rows of the step inside the chunk, a full strip
+        if (kk * BR >= 2 * R && Y0 + (kk + 1) * BR - 2 * R <= Y1 && x0 + TW <= a.W) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
+                unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r_out = r_out0 + i;
