@@ -282,9 +282,12 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                         bidx = (int)roundf((float)ORI_NBINS * (atan2_1r(gy, gx) + PI_F) / PI2_F);
                     bidx = (bidx == ORI_NBINS) ? 0 : bidx;
                     // weight <= |gradient| <= 255 sqrt 2 for pixel values in 0..255 (float images: 0..1 scaled by 255 at level
-                    // 0), so weight * 2^23 < 2^32: one v_cvt_u32_f32 (truncating like the 64-bit conversion, saturating beyond
-                    // the range) instead of the seven instructions of float -> u64
-                    atomicAdd(&myhist[bidx], (fix64)(unsigned)(weight * OFIX));
+                    // 0), so weight * 2^23 < 2^32: one v_cvt_u32_f32 (truncating like the 64-bit conversion) instead of the seven
+                    // instructions of float -> u64; a float image outside [0, 1] can exceed it and takes the long form
+                    const float wf = weight * OFIX;
+                    fix64 wq = (fix64)(unsigned)fminf(wf, 4294967040.0f);
+                    if (wf >= 4294967296.0f) wq = (fix64)wf;
+                    atomicAdd(&myhist[bidx], wq);
                 }
             }
         }
