@@ -100,6 +100,9 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// float -> 64-bit fixed point for k_orientation's out-of-range case (a function so that it stays out of the common path)
+__device__ __noinline__ fix64 wide_fix(float v) { return (fix64)v; }
+
 // atan2 on the gradient: degree-13 odd minimax polynomial for atan (max error 3.3e-7 rad), v_rcp_f32
 // atan2 evaluated in double and rounded once (what oracle/sift_oracle.c::atan2f_1r does): only on the rare exact path
 __device__ __noinline__ float atan2_1r(float y, float x) { return (float)atan2((double)y, (double)x); }
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                     // instructions of float -> u64; a float image outside [0, 1] can exceed it and takes the long form
                     const float wf = weight * OFIX;
                     fix64 wq = (fix64)(unsigned)fminf(wf, 4294967040.0f);
-                    if (wf >= 4294967296.0f) wq = (fix64)wf;
+                    if (__builtin_amdgcn_ballot_w64(wf >= 4294967296.0f) != 0ull) wq = wide_fix(wf);   // a call: not speculated into the common path
                     atomicAdd(&myhist[bidx], wq);
                 }
             }

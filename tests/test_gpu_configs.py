@@ -230,3 +230,29 @@ def test_descriptor_bins_do_not_overflow_at_large_sigma(oracle, capi):
     assert len(fb) > 5
     _features_within_budget(ref, fb, db, "large sigma")
     ctx.close()
+
+
+def test_float_image_outside_unit_range_keeps_orientations(oracle, capi):
+    """Float images are specified as [0, 1) (popsift.h:68,243); a caller that passes a larger range still gets the
+    reference's pyramid, extrema and orientation histogram (float accumulators there).  Here the orientation histogram is
+    41.23 fixed point fed by one v_cvt_u32_f32 per sample, which only holds weights below 2^9: beyond that the kernel takes
+    the 64-bit conversion (orient_desc.hip wide_fix).  Planes bit-exact, same extrema, same orientations.  (The descriptor
+    bins are 18.14 fixed point sized for the specified range: not compared.)"""
+    from popsift_amd.synth import synth_float
+    img = (synth_float(320, 240, 5) * np.float32(40.0)).astype(np.float32)
+    kw = dict(octaves=3)
+    ref = oracle.run(oracle.default_config(**kw), img)
+    ctx = capi.Context(capi.default_config(**kw))
+    ctx.upload(img)
+    ctx.extract()
+    for o in range(ref.num_octaves):
+        for l in range(ref.num_levels):
+            assert np.array_equal(ctx.dump_plane(capi.PLANE_GAUSS, o, l), ref.gauss(o, l)), (o, l)
+    ea, eb = ref.extrema(), ctx.dump_extrema()
+    assert len(ea) == len(eb) > 500
+    ka = np.lexsort((ea["ypos"], ea["xpos"], ea["octave"])); kb = np.lexsort((eb["ypos"], eb["xpos"], eb["octave"]))
+    ea, eb = ea[ka], eb[kb]
+    assert np.array_equal(ea["xpos"], eb["xpos"]) and np.array_equal(ea["ypos"], eb["ypos"])
+    assert np.array_equal(ea["num_ori"], eb["num_ori"])
+    assert np.abs(ea["orientation"] - eb["orientation"]).max() < 1e-4
+    ctx.close()
