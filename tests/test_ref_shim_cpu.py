@@ -122,19 +122,19 @@ def test_other_scale_factors_match_reference(oracle, ref, up, mode, is_float):
     _scale_factor_case(oracle, ref, w, h, up, mode, is_float)
 
 
-@pytest.mark.parametrize("w,h,up,mode", [(321, 243, 0.5, 1), (333, 251, -0.5, 0)])
+@pytest.mark.parametrize("w,h,up,mode", [(163, 122, 0.5, 1), (201, 151, -0.5, 0)])
 def test_fractional_scale_factors_on_the_rounding_boundaries(oracle, ref, w, h, up, mode):
     """Sizes at which some tap coordinates of octave 0 sit on a 1/256 sub-texel boundary, so that (x + shift)/W -+ k/W
     (the reference, s_pyramid_build_ra.cu:35-50) and (x -+ k + shift)/W give different bits
-    (tests/test_oracle_cpu.py::test_literal_texture_form_is_what_fractional_scale_factors_get): the oracle must follow
-    the reference's form."""
-    _scale_factor_case(oracle, ref, w, h, up, mode, False)
+    (tests/test_oracle_cpu.py::test_literal_texture_form_is_what_fractional_scale_factors_get; these two sizes: 858 and 658
+    pixels of level 0 differ between the forms, by up to 0.015): the oracle must follow the reference's form."""
+    _scale_factor_case(oracle, ref, w, h, up, mode, False, octaves=2)
 
 
-def _scale_factor_case(oracle, ref, w, h, up, mode, is_float):
+def _scale_factor_case(oracle, ref, w, h, up, mode, is_float, octaves=None):
     from popsift_amd.synth import synth_float
     img = synth_float(w, h, 11) if is_float else synth(w, h, 11)
-    cfg = oracle.default_config(octaves=3 if up > -2 else 2, upscale_factor=up, sift_mode=mode)
+    cfg = oracle.default_config(octaves=octaves or (3 if up > -2 else 2), upscale_factor=up, sift_mode=mode)
     r, o = ref.run(cfg, img), oracle.run(cfg, img)
     assert r.dims == o.dims and r.num_levels == o.num_levels
     for oc in range(r.num_octaves):
