@@ -7,11 +7,16 @@
 //
 // These modes exist for API completeness of setGaussMode / setScalingMode; each gives a different numerical
 // result and has its own branch in the CPU restatement (oracle/sift_oracle.c build_pyramid), pinned against the
-// reference's own kernels.  They are written for exactness, not for the roofline: one thread per output pixel,
-// separate horizontal / vertical launches through an intermediate plane, the reference's operation order with
-// explicit fmaf (this file is compiled with -ffp-contract=off).  The texture unit the reference relies on
+// reference's own kernels.  The kernels of this file are written for exactness, not for the roofline: one thread per
+// output pixel, separate horizontal / vertical launches through an intermediate plane, the reference's operation order
+// with explicit fmaf (this file is compiled with -ffp-contract=off).  The texture unit the reference relies on
 // (normalised / unnormalised coordinates, clamp addressing, linear filtering with 1.8 fixed-point weights) is
 // software here, as in pyramid.hip.
+// Round 4: where a branch is the arithmetic of the default pyramid with other tables -- every level of
+// VLFeat_Relative_All's octave 0, level 0 of every ScaleDirect octave, the levels >= 1 of both -- it runs on
+// pyramid.hip's kernels (psx_launch_level0 / psx_launch_blur); k_alt_h_input + k_alt_v_plain remain what
+// psx_launch_level0 itself falls back to when the image / octave ratio is not a power of two
+// (psx_launch_level0_literal below: the per-tap texture coordinates as the reference forms them).
 #include "psx_internal.h"
 
 namespace {
