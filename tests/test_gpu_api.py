@@ -228,3 +228,37 @@ def test_cross_stream_hand_over_of_plain_stores_under_pcie_load(capi):
         stop.set()
         for t in ts:
             t.join()
+
+
+_SWITCH_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import pyoracle as oracle
+from popsift_amd import capi
+from popsift_amd.synth import synth
+from tests.parity import assert_parity, budget, match_features
+for (w, h, seed, kw) in [(640, 480, 3, dict(octaves=4)), (333, 251, 5, dict(octaves=3, sift_mode=1)), (1920, 1080, 1000, dict(octaves=5, sift_mode=2))]:
+    img = synth(w, h, seed)
+    ref = oracle.run(oracle.default_config(**kw), img)
+    ctx = capi.Context(capi.default_config(**kw)); ctx.upload(img); ctx.extract()
+    for o in range(ref.num_octaves):
+        for l in range(ref.num_levels):
+            assert np.array_equal(ctx.dump_plane(capi.PLANE_GAUSS, o, l), ref.gauss(o, l)), (o, l)
+    fb, db = ctx.download()
+    assert len(fb) == ref.ext_total
+    assert_parity(match_features(ref.features(), ref.descriptors(), fb, db), what="switch", **budget(len(fb)))
+    ctx.close()
+print("SWITCH-OK")
+"""
+
+
+@pytest.mark.parametrize("env", [dict(POPSIFT_DESC_DENORM="0"), dict(POPSIFT_LEVEL0_X2="0"), dict(POPSIFT_LEVEL0_FUSED="0"),
+                                 dict(POPSIFT_BLUR_DEFER="0"), dict(POPSIFT_DESC_WGS="3")])
+def test_documented_fallback_switches_keep_parity(env):
+    """The kernel-variant switches of INTEGRATION.md (read once per process, hence a subprocess each): the older variants
+    they select stay bit-exact on the planes and within the feature budget on three frames."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT % root], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SWITCH-OK" in r.stdout, (env, r.stdout[-400:], r.stderr[-1500:])
