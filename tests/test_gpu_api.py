@@ -253,7 +253,8 @@ print("SWITCH-OK")
 
 
 @pytest.mark.parametrize("env", [dict(POPSIFT_DESC_DENORM="0"), dict(POPSIFT_LEVEL0_X2="0"), dict(POPSIFT_LEVEL0_FUSED="0"),
-                                 dict(POPSIFT_BLUR_DEFER="0"), dict(POPSIFT_DESC_WGS="3")])
+                                 dict(POPSIFT_BLUR_DEFER="0"), dict(POPSIFT_DESC_WGS="3"), dict(POPSIFT_BLUR_DMA="2"), dict(POPSIFT_BLUR_DMA="3"),
+                                 dict(POPSIFT_BLUR_STEPS="3")])
 def test_documented_fallback_switches_keep_parity(env):
     """The kernel-variant switches of INTEGRATION.md (read once per process, hence a subprocess each): the older variants
     they select stay bit-exact on the planes and within the feature budget on three frames."""
