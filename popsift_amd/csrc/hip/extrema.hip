@@ -311,13 +311,18 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     for (int z = 1; z <= NZ; z++) {
         bool pre[4];
         bool anyp = false;
+        // the four centre values in one go (pinned: otherwise each read is sunk behind its row's validity branch and
+        // waited for on its own -- four LDS round trips in a row per level)
+        float cv[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) cv[r] = sD[(z * THP + ly0 + r + 1) * TWP + lx + 1];
+        asm volatile("" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]));
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int y = ty0 + ly0 + r;
             bool valid = (x >= 1 && y >= 1 && x <= oc.w - 2 && y <= oc.h - 2);
             if (MODE == PSX_MODE_OPENCV) valid = valid && (x >= 5 && y >= 5 && x < oc.w - 5 && y < oc.h - 5);
-            const float v = sD[(z * THP + ly0 + r + 1) * TWP + lx + 1];
-            pre[r] = valid && fabsf(v) >= thr1;
+            pre[r] = valid && fabsf(cv[r]) >= thr1;
             anyp = anyp || pre[r];
         }
         if (__ballot(anyp) == 0ull) continue;

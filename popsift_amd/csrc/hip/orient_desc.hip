@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         const int xs = xmin & ~1;
         const int pw = (wx > 0) ? ((xmax - xs) >> 1) + 1 : 0;              // pairs per row
         const int loops2 = (pw > 0 && hy > 0) ? pw * hy : 0;
-        const float rcp_pw = 1.0f / (float)max(pw, 1);
+        const float rcp_pw = __builtin_amdgcn_rcpf((float)max(pw, 1));       // 1 ulp: (i + 0.5) * rcp_pw stays >= 0.5 / pw - 4e-6 away from an integer
         for (int i = lane; i < loops2; i += PSX_WAVE) {
             // i / pw without integer division: (i+0.5)/pw is >= 0.5/pw away from an integer
             const int q = (int)(((float)i + 0.5f) * rcp_pw);
@@ -248,21 +248,25 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                 const v2f rc = (v2f){__builtin_amdgcn_rcpf(fmaxf(mx.x, 1e-30f)), __builtin_amdgcn_rcpf(fmaxf(mx.y, 1e-30f))};
                 const v2f a = mn * rc;
                 const v2f s2 = a * a;
-                v2f r = splat(0.006811792496591806f);
-                r = pk_fma(r, s2, splat(-0.0336042195558548f));
-                r = pk_fma(r, s2, splat(0.07962366938591003f));
-                r = pk_fma(r, s2, splat(-0.1323334127664566f));
-                r = pk_fma(r, s2, splat(0.19807815551757812f));
-                r = pk_fma(r, s2, splat(-0.3331736922264099f));
-                r = pk_fma(r, s2, splat(0.9999961256980896f));
+                // the polynomial in BIN units (36 bins per turn: coefficients x 18 / pi), so that the octant fix-ups work on
+                // 9 / 18 bins and "+ 18" gives the bin value directly (the fast value only has to be within 1e-5 bins of the
+                // exact expression, see below)
+                constexpr float KB = 5.729577951308232f;
+                v2f r = splat(0.006811792496591806f * KB);
+                r = pk_fma(r, s2, splat(-0.0336042195558548f * KB));
+                r = pk_fma(r, s2, splat(0.07962366938591003f * KB));
+                r = pk_fma(r, s2, splat(-0.1323334127664566f * KB));
+                r = pk_fma(r, s2, splat(0.19807815551757812f * KB));
+                r = pk_fma(r, s2, splat(-0.3331736922264099f * KB));
+                r = pk_fma(r, s2, splat(0.9999961256980896f * KB));
                 r = r * a;
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     if (!(e == 0 ? on0 : on1)) continue;
                     const float gx = e == 0 ? gdx.x : gdx.y, gy = e == 0 ? gdy.x : gdy.y;
                     float at = e == 0 ? r.x : r.y;
-                    if ((e == 0 ? ay.x : ay.y) > (e == 0 ? ax.x : ax.y)) at = 1.57079632679489662f - at;
-                    if (gx < 0.0f) at = PI_F - at;
+                    if ((e == 0 ? ay.x : ay.y) > (e == 0 ? ax.x : ax.y)) at = 9.0f - at;
+                    if (gx < 0.0f) at = 18.0f - at;
                     at = (gy < 0.0f) ? -at : at;
                     const float grad = __builtin_amdgcn_sqrtf(e == 0 ? m2.x : m2.y);
                     const float weight = grad * __builtin_amdgcn_exp2f((float)(e == 0 ? sq0 : sq1) * factor2);
@@ -273,12 +277,13 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                     // sample in the wrong bin moves the interpolated peak by ~6e-3 rad.
                     // The 3.3e-7 rad polynomial decides every sample that is not within 2e-4 bins of a boundary.  Error budget
                     // of bfast against the exact expression, in bins (1 rad = 5.73 bins): polynomial + v_rcp 4e-7 rad and the
-                    // rounding of the exact angle 1.2e-7 rad -> 3e-6; RN(at + pi) on both sides 2 x 1.4e-6; RN(36 s) on both
-                    // sides 2 x 1.2e-6; the rounded constant 1/2pi 2e-6; the last rounding on both sides 2 x 1.9e-6: < 1.5e-5
-                    // in total, 13 times below the threshold.  About 0.04 % of the samples take the exact form (two calls
+                    // rounding of the exact angle 1.2e-7 rad -> 3e-6; the fix-ups 9 - r, 18 - r and + 18 on this side < 4e-6;
+                    // RN(at + pi), RN(36 s) and the division on the exact side 1.4e-6 + 1.2e-6 + 1.9e-6: < 1.2e-5
+                    // in total, 16 times below the threshold.  About 0.04 % of the samples take the exact form (two calls
                     // of ~130 VALU instructions, f64): with 128 samples per step that is 5 % of the steps (round 3's 1e-3
                     // threshold put 23 % of the steps through it: a quarter of the kernel's instructions).
-                    const float bfast = (float)ORI_NBINS * (at + PI_F) * (1.0f / PI2_F);
+                    static_assert(ORI_NBINS == 36, "bin units of the fast angle");
+                    const float bfast = at + 18.0f;
                     const float bfl = floorf(bfast);
                     int bidx = (int)bfl + ((bfast - bfl) >= 0.5f ? 1 : 0);
                     if (fabsf((bfast - bfl) - 0.5f) < 2e-4f)
