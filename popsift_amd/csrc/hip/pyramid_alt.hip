@@ -31,7 +31,14 @@ __device__ __forceinline__ float a_texel(const AltImg& t, int i, int j)
     i = psx_clampi(i, 0, t.w - 1);
     j = psx_clampi(j, 0, t.h - 1);
     if (t.is_float) return static_cast<const float*>(t.px)[(size_t)j * t.w + i];
-    return (float)static_cast<const uint8_t*>(t.px)[(size_t)j * t.w + i] / 255.0f;
+    // q / 255 correctly rounded without the IEEE division sequence (~10 instructions, four times per bilinear fetch, 9-15
+    // fetches per output in the fixed-span modes): q * RN(1/255) plus one Newton correction is fl(q / 255) for all 256
+    // inputs -- the same three instructions as l0_unorm8 in pyramid.hip (tests/test_gpu_parity.py::test_u8_normalisation_exact
+    // walks all values through that one; the mode tests hold this one to the oracle's planes bit for bit)
+    const float f = (float)static_cast<const uint8_t*>(t.px)[(size_t)j * t.w + i];
+    const float c = 1.0f / 255.0f;
+    const float r = f * c;
+    return fmaf(fmaf(-255.0f, r, f), c, r);
 }
 __device__ __forceinline__ void a_axis(float cn, int size, int& i0, float& a)
 {
