@@ -237,7 +237,10 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
     const unsigned pitch_b = (unsigned)oc.pitch * 4u;                 // rows and pitch bytes < 2^24: v_mul_u32_u24
     if (L == 6) {
         // one scalar base per level (readfirstlane keeps "base + level * plane" from being re-associated into per-lane 64-bit
-        // additions): every load is "scalar base + the pixel's 32-bit offset"
+        // additions): every load is "scalar base + the pixel's 32-bit offset".  (A staging map in which a wave takes whole
+        // rows -- scalar row clamp and offset, the two halo columns in a spare slot -- cut another 2 M vector instructions per
+        // frame and measured 1.3 % SLOWER end to end, 3 % on sparse frames: not kept; the kernel is not bound by its
+        // instruction count.)
         gchar_p lb[6];
 #pragma unroll
         for (int l = 0; l < 6; l++) {
@@ -245,36 +248,25 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
             lb[l] = (gchar_p)(uintptr_t)(((unsigned long long)hi << 32) | lo);
         }
-        // Element map: wave w takes the rows w, w + 4, ... of the padded tile, a lane one of the first 64 columns -- the row
-        // (its clamp, its byte offset) is wave uniform, i.e. scalar, and the column is clamped once per thread; the two
-        // remaining columns of all 18 rows (36 elements) ride in wave 2's spare fifth slot.  (e = t + k * NT with a division
-        // by 66 per element was ~60 vector instructions per thread.)
-        static_assert(NT == 256 && THP == 18 && TWP == 66 && NE == 5, "staging map of k_extrema");
-        const int w = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;
-        const unsigned coloff = (unsigned)psx_clampi(tx0 - 1 + ln, 0, oc.w - 1) * 4u;
-        int s_ry[NE], s_rx[NE];
-        bool s_on[NE];
         float g[NE][6];
 #pragma unroll
         for (int k = 0; k < NE; k++) {
-            unsigned off;
-            if (k < 4 || w < 2) {
-                const int ry = w + 4 * k;                                              // scalar
-                off = (unsigned)psx_clampi(ty0 - 1 + ry, 0, oc.h - 1) * pitch_b + coloff;
-                s_ry[k] = ry; s_rx[k] = ln; s_on[k] = true;
-            } else {
-                const int ry = min(ln >> 1, THP - 1), rx = ETW + (ln & 1);
-                off = __umul24((unsigned)psx_clampi(ty0 - 1 + ry, 0, oc.h - 1), pitch_b) + (unsigned)psx_clampi(tx0 - 1 + rx, 0, oc.w - 1) * 4u;
-                s_ry[k] = ry; s_rx[k] = rx; s_on[k] = (w == 2) && ln < 2 * THP;
-            }
+            const int e = t + k * NT;
+            const int ec = min(e, THP * TWP - 1);
+            const int ry = ec / TWP, rx = ec - ry * TWP;
+            const int gx = psx_clampi(tx0 - 1 + rx, 0, oc.w - 1);
+            const int gy = psx_clampi(ty0 - 1 + ry, 0, oc.h - 1);
+            const unsigned off = __umul24((unsigned)gy, pitch_b) + (unsigned)gx * 4u;
 #pragma unroll
             for (int l = 0; l < 6; l++) g[k][l] = *(gfloat_p)(lb[l] + off);
         }
 #pragma unroll
         for (int k = 0; k < NE; k++) {
-            if (s_on[k]) {
+            const int e = t + k * NT;
+            if (e < THP * TWP) {
+                const int ry = e / TWP, rx = e - ry * TWP;
 #pragma unroll
-                for (int l = 0; l < 5; l++) sD[(l * THP + s_ry[k]) * TWP + s_rx[k]] = g[k][l + 1] - g[k][l];
+                for (int l = 0; l < 5; l++) sD[(l * THP + ry) * TWP + rx] = g[k][l + 1] - g[k][l];
             }
         }
     } else {
