@@ -1,0 +1,133 @@
+"""The arithmetic identities the kernels rely on where they replace an IEEE operation of the reference by something
+cheaper, checked on the CPU (numpy float32; an fma is emulated in float64 wherever the exact product fits 53 bits, which
+it does for every case below).  Each test names the kernel code it backs; the kernels themselves are held to the oracle
+bit for bit by the GPU tests.
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+def _fma(a, b, c):
+    """fl32(a * b + c) with one rounding (operands float32; exact in float64 for the magnitudes used here)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+
+
+def test_u8_over_255_without_a_division():
+    """pyramid.hip l0_unorm8 / pyramid_alt.hip a_texel: q * RN(1/255) and one Newton correction is fl(q / 255) for all
+    256 byte values (cudaReadModeNormalizedFloat, s_image.cu:147)."""
+    q = np.arange(256, dtype=f32)
+    c = f32(1.0) / f32(255.0)
+    r = (q * c).astype(f32)
+    e = _fma(np.full(256, -255.0, f32), r, q)
+    got = _fma(e, np.full(256, c, f32), r)
+    assert np.array_equal(got, (q / f32(255.0)).astype(f32))
+
+
+def test_tap_offset_over_width_by_reciprocal_and_one_newton_step():
+    """pyramid_alt.hip k_alt_h_input: float(offset) / W (s_pyramid_build_ra.cu:44) as k * RN(1/W) corrected once equals
+    the IEEE quotient for every tap index up to 32 and every width below 2^17 (the kernel divides beyond that)."""
+    W = np.arange(1, 1 << 17, dtype=np.float64)
+    Wf = W.astype(f32)
+    y = (f32(1.0) / Wf).astype(f32)
+    for k in range(1, 33):
+        kf = np.full(W.shape, k, f32)
+        q0 = (kf * y).astype(f32)
+        r = _fma(-Wf, q0, kf)
+        q = _fma(r, y, q0)
+        assert np.array_equal(q, (kf / Wf).astype(f32)), k
+
+
+def test_division_by_three_in_three_instructions():
+    """orient_desc.hip div3 (the six smoothing passes of the orientation histogram, s_orientation.cu:166-174): x * RN(1/3),
+    the exact remainder in an fma, one correction -- the IEEE quotient on random floats over nine decades and on the
+    integers a histogram can hold exactly."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([(rng.random(2_000_000) * 10.0 ** rng.integers(-4, 5, 2_000_000)).astype(f32),
+                        np.arange(0, 1 << 20, dtype=f32)])
+    y = f32(0.3333333432674407958984375)
+    q = (x * y).astype(f32)
+    r = _fma(np.full(x.shape, -3.0, f32), q, x)
+    got = _fma(r, np.full(x.shape, y, f32), q)
+    assert np.array_equal(got, (x / f32(3.0)).astype(f32))
+
+
+def test_bin_pair_slot_is_a_three_bit_rotation():
+    """orient_desc.hip bin_slot: the u64 that holds bins (fo, fo + 1) of a descriptor tile lives at word fo for even fo and
+    at word 8 + fo - 1 for odd fo (two views of the 8 bins); as a byte offset that is the bin index rotated right by one
+    bit, times 8 -- for any integer fo, negative ones included (two's complement & 7)."""
+    for fo in range(-16, 17):
+        h = fo & 7
+        word = h if h % 2 == 0 else 8 + h - 1
+        rot = ((((h << 3) | h) >> 1) & 7) << 3
+        assert rot == word * 4, fo
+
+
+def test_bounding_box_floor_of_the_extreme_corner():
+    """orient_desc.hip k_descriptors: min over the corners of floor(p - b) == floor(min(p) - b) (and max / + likewise),
+    because x -> floor(fl(x - b)) is monotone; the reference takes the floor per corner (s_desc_loop.cu:46-58)."""
+    rng = np.random.default_rng(9)
+    p = (rng.random((200_000, 4)) * 4000.0 - 100.0).astype(f32)
+    p[: 50_000] = np.rint(p[: 50_000])                      # corners on integers and ties
+    b = (rng.random(200_000) * 60.0).astype(f32)
+    lo_each = np.floor((p - b[:, None]).astype(f32)).min(axis=1)
+    lo_once = np.floor((p.min(axis=1) - b).astype(f32))
+    hi_each = np.floor((p + b[:, None]).astype(f32)).max(axis=1)
+    hi_once = np.floor((p.max(axis=1) + b).astype(f32))
+    assert np.array_equal(lo_each, lo_once) and np.array_equal(hi_each, hi_once)
+
+
+def test_one_minus_w_and_w_from_one_fma():
+    """orient_desc.hip: the pair (1 - w, w) as fma(w, (-1, 1), (1, 0)) -- fl(1 - w) and w themselves, for every
+    representable fraction the kernel can see (w = t - floor(t), t in (-12, 12))."""
+    rng = np.random.default_rng(2)
+    t = ((rng.random(1_000_000) * 24.0 - 12.0)).astype(f32)
+    w = (t - np.floor(t)).astype(f32)
+    lo = _fma(w, np.full(w.shape, -1.0, f32), np.full(w.shape, 1.0, f32))
+    hi = _fma(w, np.full(w.shape, 1.0, f32), np.full(w.shape, 0.0, f32))
+    assert np.array_equal(lo, (f32(1.0) - w).astype(f32)) and np.array_equal(hi, w)
+
+
+def test_denormal_product_is_the_fixed_point_integer():
+    """orient_desc.hip k_descriptors<DENORM>: with the scale 2^14 * 2^-149 folded into a weight, every product further down
+    is a denormal float, i.e. a multiple of 2^-149 whose BIT PATTERN is that multiple -- the 18.14 fixed-point integer that
+    ds_add_u64 adds, with no conversion.  Each multiplication rounds to that grid (nearest even): a product of a
+    grid-rounded weight and a factor <= 1 is within one unit of the exact value (the kernel chains four: <= 2 units of
+    2^-14 against sums of 10^2..10^3), and sums of such words are exact integer sums."""
+    rng = np.random.default_rng(4)
+    a = (rng.random(500_000) * 360.0).astype(f32)                      # magnitude x Gaussian weight
+    b = rng.random(500_000).astype(f32)                                 # bin weight x tile weight, <= 1
+    scaled = (a * f32(2.0) ** f32(-135)).astype(f32)                   # a on the 2^-14 grid (denormal: a < 512)
+    prod = (scaled * b).astype(f32)                                     # rounds to a multiple of 2^-149 again
+    bits = prod.view(np.uint32).astype(np.int64)
+    assert (bits < (1 << 23)).all()                                     # still denormal: the exponent field is zero
+    exact = a.astype(np.float64) * b.astype(np.float64) * 16384.0
+    assert np.abs(bits - exact).max() <= 1.0
+    # the word IS the value: bits * 2^-149 == prod, and adding the words adds the values
+    assert np.array_equal(bits.astype(np.float64) * 2.0 ** -149, prod.astype(np.float64))
+    s = (prod[:1000].astype(np.float64)).sum()
+    assert bits[:1000].sum() * 2.0 ** -149 == s
+
+
+def test_level0_row_form_needs_a_power_of_two_ratio():
+    """pyramid.hip psx_level0_exact: (x + s)/W -+ k/W and (x -+ k + s)/W land on the same 1/256 sub-texel for every column
+    and tap when the image / octave ratio is a power of two, and not in general (a fractional scale factor: some columns
+    differ by one 1/256 step) -- the reason the kernels of the default path are gated on that ratio."""
+    def positions(c, size):
+        t = (c * f32(size)).astype(f32) - f32(0.5)
+        fl = np.floor(t)
+        return fl.astype(np.int64) * 256 + np.rint(((t - fl).astype(f32) * f32(256.0)).astype(f32)).astype(np.int64)
+
+    def mismatches(w, W, shift, taps=8):
+        x = np.arange(W, dtype=f32)
+        bad = 0
+        for k in range(1, taps + 1):
+            for sg in (-1.0, 1.0):
+                lit = (((x + f32(shift)) / f32(W)).astype(f32) + f32(sg) * (f32(k) / f32(W))).astype(f32)
+                row = (((x + f32(sg * k)) + f32(shift)) / f32(W)).astype(f32)
+                bad += int((positions(lit, w) != positions(row, w)).sum())
+        return bad
+
+    for w, W, s in [(333, 666, 1.0), (333, 666, 0.5), (1920, 3840, 1.0), (1920, 960, 0.5), (1920, 240, 0.5), (333, 333, 0.5), (251, 1004, 2.0)]:
+        assert mismatches(w, W, s) == 0, (w, W, s)
+    assert mismatches(333, 471, 0.5 * 2 ** 0.5) > 0 and mismatches(640, 906, 0.5 * 2 ** 0.5) > 0
