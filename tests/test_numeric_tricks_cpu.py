@@ -131,3 +131,61 @@ def test_level0_row_form_needs_a_power_of_two_ratio():
     for w, W, s in [(333, 666, 1.0), (333, 666, 0.5), (1920, 3840, 1.0), (1920, 960, 0.5), (1920, 240, 0.5), (333, 333, 0.5), (251, 1004, 2.0)]:
         assert mismatches(w, W, s) == 0, (w, W, s)
     assert mismatches(333, 471, 0.5 * 2 ** 0.5) > 0 and mismatches(640, 906, 0.5 * 2 ** 0.5) > 0
+
+
+def test_orientation_fast_bin_equals_exact_bin_outside_the_guard_band():
+    """orient_desc.hip k_orientation: the histogram bin of a sample is roundf(36 (atan2f + pi) / 2 pi) with the angle rounded
+    once from double (oracle/sift_oracle.c atan2f_1r).  The kernel evaluates that only within 2e-4 bins of a bin boundary and
+    otherwise takes a degree-13 polynomial in bin units with v_rcp_f32 (1 ulp); this replays both in float32 on a million
+    gradients (random, near-diagonal, near-axis, tiny, integer-valued like the ones of smooth 8-bit images) and checks that
+    the fast bin is the exact bin wherever the guard does not send the sample to the exact path -- for a correctly rounded
+    reciprocal and for one that is an ulp off either way."""
+    rng = np.random.default_rng(11)
+    n = 250_000
+    g = rng.standard_normal((n, 2)) * 10.0 ** rng.integers(-3, 3, (n, 1))
+    diag = rng.standard_normal((n, 1)) * 20.0
+    near_diag = np.hstack([diag, diag * rng.choice([-1.0, 1.0], (n, 1))]) * (1.0 + rng.standard_normal((n, 2)) * 1e-6)
+    near_axis = np.hstack([rng.standard_normal((n, 1)) * 30.0, rng.standard_normal((n, 1)) * 1e-4])
+    ints = rng.integers(-40, 41, (n, 2)).astype(np.float64) * rng.choice([1.0, 0.5, 0.25], (n, 1))
+    g = np.vstack([g, near_diag, near_axis, near_axis[:, ::-1], ints]).astype(f32)
+    gx, gy = g[:, 0], g[:, 1]
+    keep = (gx != 0) | (gy != 0)
+    gx, gy = gx[keep], gy[keep]
+
+    PI_F, PI2_F = f32(3.14159265358979323846), f32(6.28318530717958647692)
+    exact_at = np.arctan2(gy.astype(np.float64), gx.astype(np.float64)).astype(f32)
+    be = ((f32(36.0) * (exact_at + PI_F).astype(f32)).astype(f32) / PI2_F).astype(f32)
+    exact_bin = (np.trunc(be) + (np.abs(be - np.trunc(be)) >= 0.5) * np.sign(be)).astype(np.int64)     # roundf: half away from zero
+    exact_bin[exact_bin == 36] = 0
+
+    KB = f32(5.729577951308232)
+    coef = [(f32(c) * KB).astype(f32) for c in (0.006811792496591806, -0.0336042195558548, 0.07962366938591003,
+                                                -0.1323334127664566, 0.19807815551757812, -0.3331736922264099, 0.9999961256980896)]
+    ax, ay = np.abs(gx), np.abs(gy)
+    mx, mn = np.maximum(ax, ay), np.minimum(ax, ay)
+    den = np.maximum(mx, f32(1e-30))
+    rc0 = (f32(1.0) / den).astype(f32)
+    for ulp in (0, 1, -1):
+        rc = rc0 if ulp == 0 else np.nextafter(rc0, np.where(ulp > 0, f32(np.inf), f32(0.0)).astype(f32)).astype(f32)
+        a = (mn * rc).astype(f32)
+        s2 = (a * a).astype(f32)
+        r = np.full(a.shape, coef[0], f32)
+        for c in coef[1:]:
+            r = _fma(r, s2, np.full(a.shape, c, f32))
+        r = (r * a).astype(f32)
+        at = np.where(ay > ax, (f32(9.0) - r).astype(f32), r)
+        at = np.where(gx < 0, (f32(18.0) - at).astype(f32), at)
+        at = np.where(gy < 0, -at, at)
+        bfast = (at + f32(18.0)).astype(f32)
+        bfl = np.floor(bfast)
+        frac = (bfast - bfl).astype(f32)
+        fast_bin = bfl.astype(np.int64) + (frac >= 0.5)
+        fast_bin[fast_bin == 36] = 0
+        guard = np.abs((frac - f32(0.5)).astype(f32)) < f32(2e-4)
+        wrong = (fast_bin != exact_bin) & ~guard
+        assert not wrong.any(), (ulp, int(wrong.sum()), gx[wrong][:4], gy[wrong][:4])
+        assert guard.mean() < 0.35                 # (the near-diagonal / integer families sit on boundaries by construction)
+        # distance of the fast value from the exact expression: the kernel's comment budgets < 1.2e-5 bins
+        d = np.abs(bfast.astype(np.float64) - be.astype(np.float64))
+        d = np.minimum(d, 36.0 - d)
+        assert d.max() < 1.5e-5, d.max()
