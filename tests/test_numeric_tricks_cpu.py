@@ -189,3 +189,18 @@ def test_orientation_fast_bin_equals_exact_bin_outside_the_guard_band():
         d = np.abs(bfast.astype(np.float64) - be.astype(np.float64))
         d = np.minimum(d, 36.0 - d)
         assert d.max() < 1.5e-5, d.max()
+
+
+def test_atan_polynomial_error_bound():
+    """orient_desc.hip fast_atan2 / the packed atan of k_descriptors and k_orientation: the degree-13 odd polynomial on
+    [0, 1], evaluated in float32 with fmas as the kernels do, stays within 3.5e-7 rad of atan (the comments say 3.3e-7)."""
+    a = np.linspace(0.0, 1.0, 2_000_001).astype(f32)
+    s = (a * a).astype(f32)
+    coef = [f32(c) for c in (0.006811792496591806, -0.0336042195558548, 0.07962366938591003, -0.1323334127664566,
+                             0.19807815551757812, -0.3331736922264099, 0.9999961256980896)]
+    r = np.full(a.shape, coef[0], f32)
+    for c in coef[1:]:
+        r = _fma(r, s, np.full(a.shape, c, f32))
+    r = (r * a).astype(f32)
+    err = np.abs(r.astype(np.float64) - np.arctan(a.astype(np.float64)))
+    assert err.max() < 3.5e-7, err.max()
