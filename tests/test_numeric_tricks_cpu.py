@@ -204,3 +204,35 @@ def test_atan_polynomial_error_bound():
     r = (r * a).astype(f32)
     err = np.abs(r.astype(np.float64) - np.arctan(a.astype(np.float64)))
     assert err.max() < 3.5e-7, err.max()
+
+
+def test_row_split_of_the_orientation_window_by_reciprocal():
+    """orient_desc.hip k_orientation: i / pw as (int)((i + 0.5) * rcp(pw)) with v_rcp_f32 (1 ulp): exact for every pair count
+    a window can have (radius <= 3 * 1.5 * sigma_max ~ 40) and every index in it, reciprocal an ulp off either way included."""
+    for pw in range(1, 48):
+        i = np.arange(0, pw * 100, dtype=np.int64)
+        base = f32(f32(1.0) / f32(pw))
+        for r in (base, np.nextafter(f32(base), f32(np.inf)), np.nextafter(f32(base), f32(0.0))):
+            q = ((i.astype(f32) + f32(0.5)) * f32(r)).astype(f32).astype(np.int64)
+            assert np.array_equal(q, i // pw), (pw, float(r))
+
+
+def test_x2_upsampling_has_constant_filter_weights():
+    """pyramid.hip k_level0_x2: with W = 2 w the 1.8 fixed-point weight of output column X is 0 / 1/2 by parity for the
+    sampling shift 1.0 (PopSift, VLFeat) and 3/4 / 1/4 for 0.5 (OpenCV), and the left texel is X/2 - (parity ? 0 : 1) resp.
+    (X - 1) >> 1 -- for every width the kernel accepts; what the kernel's constants and its gate rest on."""
+    for w in (4, 5, 7, 64, 333, 1920, 4096, 5000):
+        W = 2 * w
+        X = np.arange(-16, W + 16, dtype=f32)
+        for shift in (1.0, 0.5):
+            cn = ((X + f32(shift)) / f32(W)).astype(f32)
+            tb = ((cn * f32(w)).astype(f32) - f32(0.5)).astype(f32)
+            fl = np.floor(tb)
+            al = (np.rint(((tb - fl).astype(f32) * f32(256.0)).astype(f32)) * f32(1.0 / 256.0)).astype(f32)
+            i0 = fl.astype(np.int64)
+            Xi = X.astype(np.int64)
+            # a weight of 1 on the left neighbour's right texel is the same sample as a weight of 0 one texel further: compare
+            # the sampled position i0 + al
+            pos = i0 + al.astype(np.float64)
+            want = Xi / 2.0 if shift == 1.0 else Xi / 2.0 - 0.25
+            assert np.array_equal(pos, want), (w, shift)
