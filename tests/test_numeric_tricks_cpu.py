@@ -236,3 +236,60 @@ def test_x2_upsampling_has_constant_filter_weights():
             pos = i0 + al.astype(np.float64)
             want = Xi / 2.0 if shift == 1.0 else Xi / 2.0 - 0.25
             assert np.array_equal(pos, want), (w, shift)
+
+
+def test_descriptor_row_spans_contain_every_window_pixel():
+    """orient_desc.hip k_descriptors: a row of the rotated 5 x 5-SBP window is walked from xa to xb, computed from the two
+    linear constraints with one pixel of slack (round 4; 2-3 before) and reciprocals from v_rcp_f32; the exact predicate
+    |u - 1.5| < 2.5, |v - 1.5| < 2.5 decides inside.  Float32 replay for random keypoints: every pixel that passes the
+    predicate lies inside its row's span (reciprocals exact and an ulp off either way) -- the spans only ever skip pixels
+    that are outside the window, which is why tightening them left the descriptors bit-identical."""
+    rng = np.random.default_rng(21)
+    checked = 0
+    for _ in range(1200):
+        x = f32(rng.uniform(30, 400)); y = f32(rng.uniform(30, 300))
+        ang = f32(rng.uniform(-np.pi, np.pi)) if rng.random() > 0.15 else f32(rng.choice([0.0, np.pi / 2, -np.pi / 2, np.pi / 4, np.pi]))
+        SBP = f32(3.0 * rng.uniform(1.2, 6.7))
+        W, H = 460, 360
+        cos_t, sin_t = f32(np.cos(np.float64(ang))), f32(np.sin(np.float64(ang)))
+        csbp, ssbp = f32(cos_t * SBP), f32(sin_t * SBP)
+        crsbp, srsbp = f32(cos_t / SBP), f32(sin_t / SBP)
+        bsz = f32(abs(csbp) + abs(ssbp))
+        px = [f32(f32(csbp * ox) + f32(f32(-ssbp * oy) + x)) for ox in (-1.5, 1.5) for oy in (-1.5, 1.5)]
+        py = [f32(f32(csbp * oy) + f32(f32(ssbp * ox) + y)) for ox in (-1.5, 1.5) for oy in (-1.5, 1.5)]
+        xmin = max(1, int(np.floor(f32(min(px) - bsz)))); xmax = min(W - 2, int(np.floor(f32(max(px) + bsz))))
+        ymin = max(1, int(np.floor(f32(min(py) - bsz)))); ymax = min(H - 2, int(np.floor(f32(max(py) + bsz))))
+        if xmin > xmax or ymin > ymax:
+            continue
+        use_c, use_s = abs(crsbp) > 1e-6, abs(srsbp) > 1e-6
+        jj = np.arange(xmin, xmax + 1, dtype=np.int64)
+        dx = (jj.astype(f32) - x).astype(f32)
+        for ulp in (0, 1, -1):
+            def rcp(v):
+                r = f32(f32(1.0) / v)
+                return r if ulp == 0 else np.nextafter(r, f32(np.inf) if ulp > 0 else f32(-np.inf))
+            rcc = rcp(crsbp) if use_c else f32(0.0)
+            rcs = rcp(srsbp) if use_s else f32(0.0)
+            for ii in range(ymin, ymax + 1):
+                dyk = f32(f32(ii) - y)
+                ub = f32(np.float64(srsbp) * np.float64(dyk) + 1.5)          # fmaf
+                vb = f32(np.float64(crsbp) * np.float64(dyk) + 1.5)
+                lo, hi = f32(xmin) - x, f32(xmax) - x
+                if use_c:
+                    t1, t2 = f32(f32(-1.0 - ub) * rcc), f32(f32(4.0 - ub) * rcc)
+                    lo, hi = max(lo, min(t1, t2)), min(hi, max(t1, t2))
+                if use_s:
+                    t1, t2 = f32(f32(vb - 4.0) * rcs), f32(f32(vb + 1.0) * rcs)
+                    lo, hi = max(lo, min(t1, t2)), min(hi, max(t1, t2))
+                u = (np.float64(crsbp) * dx.astype(np.float64) + np.float64(ub)).astype(f32)      # pk_fma
+                v = (np.float64(-srsbp) * dx.astype(np.float64) + np.float64(vb)).astype(f32)
+                inside = (np.abs((u - f32(1.5)).astype(f32)) < 2.5) & (np.abs((v - f32(1.5)).astype(f32)) < 2.5)
+                if not inside.any():
+                    continue
+                assert lo <= hi, (x, y, ang, SBP, ii)
+                xa = max(xmin, int(np.floor(f32(x + lo)))) & ~1
+                xb = min(xmax, int(np.floor(f32(x + hi))) + 1)
+                first, last = int(jj[inside][0]), int(jj[inside][-1])
+                assert xa <= first and last <= xb, (x, y, ang, SBP, ii, xa, xb, first, last)
+                checked += 1
+    assert checked > 100_000
