@@ -146,21 +146,42 @@ __global__ __launch_bounds__(ANT) void k_alt_interp(const float* src, float* dst
     dst[(size_t)y * pitch + x] = out;
 }
 
-// fixedSpan::relativeTexAddress::octave_fixed_vert (s_pyramid_fixed.cu:123-140): column cx - SHIFT of the vbuf
-__global__ __launch_bounds__(ANT) void k_fixed_v_input(AltImg t, float* vbuf, int W, int H, int vpitch, PsxTaps f, int SHIFT, float tshift)
+// fixedSpan::relativeTexAddress::octave_fixed_vert (s_pyramid_fixed.cu:123-140): column cx - SHIFT of the vbuf.
+// The 2 SHIFT + 1 fetches of an output share their column (texel columns i0 / i0 + 1 and weight a: formed once) and walk up
+// the texel rows: they are taken in ascending order, the x-lerp of a texel row is kept while consecutive fetches need it
+// (at x2 upsampling a fetch advances half a texel row: 6 row lerps instead of 18 for 9 taps), and the weighted sum then runs
+// over the stored values in the reference's order (centre, then the pairs -i / +i) -- the same values, the same sum.
+template <int SHIFT>
+__global__ __launch_bounds__(ANT) void k_fixed_v_input(AltImg t, float* vbuf, int W, int H, int vpitch, PsxTaps f, float tshift)
 {
     const int cx = blockIdx.x * ANT + threadIdx.x - SHIFT, y = blockIdx.y;
     if (cx >= W + SHIFT) return;
     const float mul_w = 1.0f / (float)W, mul_h = 1.0f / (float)H;        // __frcp_rn
     const float xpos = ((float)cx + tshift) * mul_w;
     const float ypos = ((float)y + tshift) * mul_h;
-    float val = tex2d_norm(t, xpos, ypos);
-    float fval = val * f.g[0];
-    for (int i = 1; i <= SHIFT; i++) {
-        val  = tex2d_norm(t, xpos, ypos - i * mul_h);
-        val += tex2d_norm(t, xpos, ypos + i * mul_h);
-        fval = fmaf(val, f.g[i], fval);
+    int i0; float a;
+    a_axis(xpos, t.w, i0, a);
+    const int ia = psx_clampi(i0, 0, t.w - 1), ib = psx_clampi(i0 + 1, 0, t.w - 1);
+    auto row = [&](int j) { return a_lerp(a_texel(t, ia, j), a_texel(t, ib, j), a); };      // j already clamped
+    float val[2 * SHIFT + 1];
+    int cj0 = -1, cj1 = -1;                                                 // texel rows whose x-lerp is held in r0 / r1
+    float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+    for (int k = -SHIFT; k <= SHIFT; k++) {
+        const float vn = k < 0 ? ypos - (-k) * mul_h : (k > 0 ? ypos + k * mul_h : ypos);
+        int j0; float b;
+        a_axis(vn, t.h, j0, b);
+        // every lane of the block has the same y: scalar row indices, scalar branches
+        const int ja = __builtin_amdgcn_readfirstlane(psx_clampi(j0, 0, t.h - 1));
+        const int jb = __builtin_amdgcn_readfirstlane(psx_clampi(j0 + 1, 0, t.h - 1));
+        const float ra = ja == cj0 ? r0 : (ja == cj1 ? r1 : row(ja));
+        const float rb = jb == ja ? ra : (jb == cj1 ? r1 : (jb == cj0 ? r0 : row(jb)));
+        cj0 = ja; cj1 = jb; r0 = ra; r1 = rb;
+        val[k + SHIFT] = a_lerp(ra, rb, b);
     }
+    float fval = val[SHIFT] * f.g[0];
+#pragma unroll
+    for (int i = 1; i <= SHIFT; i++) fval = fmaf(val[SHIFT - i] + val[SHIFT + i], f.g[i], fval);
     vbuf[(size_t)y * vpitch + cx + SHIFT] = fval;
 }
 
@@ -263,7 +284,8 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
                 const PsxTaps f = taps((from_input ? a.abs0_filter : a.absN_filter) + level * PSX_GAUSS_ALIGN);
                 if (from_input) {
                     const float tshift = 0.5f * powf(2.0f, a.upscale_factor);
-                    hipLaunchKernelGGL(k_fixed_v_input, gv, b, 0, s, img, a.vbuf, W, H, vpitch, f, SHIFT, tshift);
+                    if (SHIFT == 4) hipLaunchKernelGGL(k_fixed_v_input<4>, gv, b, 0, s, img, a.vbuf, W, H, vpitch, f, tshift);
+                    else            hipLaunchKernelGGL(k_fixed_v_input<7>, gv, b, 0, s, img, a.vbuf, W, H, vpitch, f, tshift);
                 } else {
                     hipLaunchKernelGGL(k_fixed_v_plane, gv, b, 0, s, plane(0), pitch, a.vbuf, W, H, vpitch, f, SHIFT);
                 }
