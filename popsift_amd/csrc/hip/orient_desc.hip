@@ -323,7 +323,13 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         }
         const float hp = from(prev_a, hval);
         const float hn = from(next_a, hval);
-        bool predicate = isbin && (hval > fmaxf(hp, hn));
+        // A peak is a bin above both neighbours (s_orientation.cu:199).  The right-hand test is >= here: the histogram is an
+        // exact integer sum, so a gradient field that is mirror symmetric about a bin boundary (blobs, corners) gives two
+        // EQUAL top bins, which the strict test would drop altogether -- the keypoint would get the orientation of some
+        // minor peak.  In the reference's float accumulation (and the oracle's) rounding noise breaks such ties, one of the
+        // two bins wins and the parabola puts the angle at their common boundary; the left bin of the pair with hn == hval
+        // gives exactly that (newbin = 1.5).  Bins that differ are treated as before.
+        bool predicate = isbin && hval > hp && hval >= hn;
         const float num  = predicate ? 3.0f * hp - 4.0f * hval + 1.0f * hn : 0.0f;
         const float denB = predicate ? 2.0f * (hp - 2.0f * hval + hn) : 1.0f;
         const float newbin = num / denB;

@@ -58,22 +58,8 @@ __device__ __forceinline__ float tex2d_norm(const AltImg& t, float un, float vn)
     return a_lerp(r0, r1, b);
 }
 
-// ---- a Gaussian plane as an unnormalised, clamped, linearly filtered texture; (x, y) are the arguments of
-// readTex (assist.h:68-77), which adds 0.5 ----
-__device__ __forceinline__ float plane_linear(const float* p, int W, int H, int pitch, float x, float y)
-{
-    const float xs = x + 0.5f, ys = y + 0.5f;
-    const float xb = xs - 0.5f, yb = ys - 0.5f;
-    const float fx = floorf(xb), fy = floorf(yb);
-    const float a = rintf((xb - fx) * 256.0f) * (1.0f / 256.0f);
-    const float b = rintf((yb - fy) * 256.0f) * (1.0f / 256.0f);
-    const int i = (int)fx, j = (int)fy;
-    const int i0 = psx_clampi(i, 0, W - 1), i1 = psx_clampi(i + 1, 0, W - 1);
-    const int j0 = psx_clampi(j, 0, H - 1), j1 = psx_clampi(j + 1, 0, H - 1);
-    const float r0 = a_lerp(p[(size_t)j0 * pitch + i0], p[(size_t)j0 * pitch + i1], a);
-    const float r1 = a_lerp(p[(size_t)j1 * pitch + i0], p[(size_t)j1 * pitch + i1], a);
-    return a_lerp(r0, r1, b);
-}
+// ---- a Gaussian plane as an unnormalised, clamped, linearly filtered texture (readTex, assist.h:68-77): plane_linear_1d
+// below; the interpolating descriptor modes have their own 2-D form in orient_desc.hip ----
 
 // normalizedSource::horiz / horiz_level / horiz_all (s_pyramid_build_ra.cu:17-132)
 __global__ __launch_bounds__(ANT) void k_alt_h_input(AltImg t, float* intm, int W, int H, int pitch, PsxTaps f, int span, float shift)
@@ -127,6 +113,25 @@ __global__ __launch_bounds__(ANT) void k_alt_h_plain(const float* src, float* in
     intm[(size_t)y * pitch + x] = out;
 }
 
+// plane_linear with one of the two coordinates an integer pixel index (xi, yi inside the plane) and the other one, t,
+// fractional.  On the integer axis the 1.8 weight is exactly 0 and lerp(p, q, 0) = p + 0 * q = p for the finite,
+// non-negative values of a Gaussian plane (a zero keeps its sign only if q's sign agrees: planes of images in [0, 1] never
+// hold a negative zero), so the neighbour on that axis is neither loaded nor multiplied: half the loads, a third of the lerps.
+template <bool VERTICAL>
+__device__ __forceinline__ float plane_linear_1d(const float* p, int W, int H, int pitch, int xi, int yi, float t)
+{
+    const float ts = t + 0.5f, tb = ts - 0.5f;                 // readTex adds 0.5, the texture unit takes it off again
+    const float ft = floorf(tb);
+    const float w = rintf((tb - ft) * 256.0f) * (1.0f / 256.0f);
+    const int k = (int)ft;
+    if (VERTICAL) {
+        const int j0 = psx_clampi(k, 0, H - 1), j1 = psx_clampi(k + 1, 0, H - 1);
+        return a_lerp(p[(size_t)j0 * pitch + xi], p[(size_t)j1 * pitch + xi], w);
+    }
+    const int i0 = psx_clampi(k, 0, W - 1), i1 = psx_clampi(k + 1, 0, W - 1);
+    return a_lerp(p[(size_t)yi * pitch + i0], p[(size_t)yi * pitch + i1], w);
+}
+
 // absoluteSourceInterpolated::horiz / vert (s_pyramid_build_ai.cu:17-69)
 template <bool VERTICAL>
 __global__ __launch_bounds__(ANT) void k_alt_interp(const float* src, float* dst, int W, int H, int pitch, PsxTaps fi, int ispan)
@@ -134,15 +139,14 @@ __global__ __launch_bounds__(ANT) void k_alt_interp(const float* src, float* dst
     const int x = blockIdx.x * ANT + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
     float out = 0.0f;
+    const float c = VERTICAL ? (float)y : (float)x;             // the coordinate the taps move along
     for (int offset = 1; offset <= ispan; offset += 2) {
         const float u = fi.g[offset];
         const float off = offset + (1.0f - u);
-        float val;
-        if (VERTICAL) val = plane_linear(src, W, H, pitch, (float)x, (float)y - off) + plane_linear(src, W, H, pitch, (float)x, (float)y + off);
-        else          val = plane_linear(src, W, H, pitch, (float)x - off, (float)y) + plane_linear(src, W, H, pitch, (float)x + off, (float)y);
+        const float val = plane_linear_1d<VERTICAL>(src, W, H, pitch, x, y, c - off) + plane_linear_1d<VERTICAL>(src, W, H, pitch, x, y, c + off);
         out = fmaf(val, fi.g[offset + 1], out);
     }
-    out = fmaf(plane_linear(src, W, H, pitch, (float)x, (float)y), fi.g[0], out);
+    out = fmaf(src[(size_t)y * pitch + x], fi.g[0], out);       // both coordinates integer: the pixel itself
     dst[(size_t)y * pitch + x] = out;
 }
 
