@@ -713,7 +713,11 @@ def _wide_fuzz_cases(n, seed):
         if rng.random() < 0.25:
             kw.update(filter_max_extrema=int(rng.integers(20, 300)), filter_grid_size=int(rng.integers(1, 4)),
                       grid_filter_mode=int(rng.integers(1, 3)))     # RandomScale depends on buffer order: left out
-        out.append((w, h, 11000 + i, bool(rng.random() < 0.3), kw))
+        is_float = bool(rng.random() < 0.3)
+        # the interpolating descriptor samplers (iloop, igrid, notile) in a quarter of the cases; grid (2) is a bound, not a
+        # match (tests/test_gpu_modes.py).  Drawn last: the cases above are those of the round-4 sweeps
+        kw["desc_mode"] = int(rng.choice([0, 0, 0, 1, 3, 4]))
+        out.append((w, h, 11000 + i, is_float, kw))
     return out
 
 
