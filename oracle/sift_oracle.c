@@ -567,8 +567,12 @@ static void fixed_octave0(osift_result* r, const tex_in* t, int SHIFT)
                 float val = tex2d_norm(t, xpos, ypos);
                 float fval = val * f[0];
                 for (int i = 1; i <= SHIFT; i++) {
-                    val  = tex2d_norm(t, xpos, ypos - i * mul_h);
-                    val += tex2d_norm(t, xpos, ypos + i * mul_h);
+                    /* "ypos - i * mul_h" in device code: nvcc contracts it into one fma (-fmad=true), and so does the
+                     * reference built for the CPU (oracle/Makefile REF_CXX); two roundings instead of one move a tap across
+                     * a 1/256 sub-texel boundary once in a while when H is not a power-of-two multiple of the image
+                     * height (found by tools/ref_fuzz.py: one row of a 193 x 191 plane at upscale 0.5) */
+                    val  = tex2d_norm(t, xpos, fmaf(-(float)i, mul_h, ypos));
+                    val += tex2d_norm(t, xpos, fmaf((float)i, mul_h, ypos));
                     fval = fmaf(val, f[i], fval);
                 }
                 vbuf[(size_t)y * VW + cx + SHIFT] = fval;

@@ -172,7 +172,8 @@ __global__ __launch_bounds__(ANT) void k_fixed_v_input(AltImg t, float* vbuf, in
     float r0 = 0.0f, r1 = 0.0f;
 #pragma unroll
     for (int k = -SHIFT; k <= SHIFT; k++) {
-        const float vn = k < 0 ? ypos - (-k) * mul_h : (k > 0 ? ypos + k * mul_h : ypos);
+        // ypos -+ i * mul_h is ONE fma in the reference's device code (nvcc contracts it; this file is built -ffp-contract=off)
+        const float vn = k == 0 ? ypos : fmaf((float)k, mul_h, ypos);
         int j0; float b;
         a_axis(vn, t.h, j0, b);
         // every lane of the block has the same y: scalar row indices, scalar branches

@@ -233,3 +233,17 @@ def test_grid_descriptor_mode_matches_reference(oracle, ref):
     m = match_features(rf, rd, o.features(), o.descriptors())
     assert m["kp_miss"] == 0 and m["ori_miss"] == 0
     assert m["desc_miss"] <= 0.1 * m["desc_compared"] and m["max_desc_dist"] < 0.05, m
+
+
+def test_fixed_span_tap_rows_are_one_fma(oracle, ref):
+    """fixedSpan::relativeTexAddress::octave_fixed_vert reads its taps at "ypos -+ i * mul_h" (s_pyramid_fixed.cu:140-141),
+    which nvcc contracts into one fma; with a multiply rounded on its own a tap of row 161 of this 193 x 191 plane (Fixed15,
+    scale factor 0.5) lands on the other side of a 1/256 sub-texel boundary and the whole row differs by 6e-4 (found by
+    tools/ref_fuzz.py, round 4).  Oracle = reference, every plane."""
+    img = synth(136, 135, 9080)
+    cfg = oracle.default_config(octaves=1, sift_mode=1, gauss_mode=5, levels=3, upscale_factor=0.5, initial_blur=0.8, threshold=0.02)
+    r, o = ref.run(cfg, img), oracle.run(cfg, img)
+    assert r.dims == o.dims == [(193, 191)]
+    for l in range(r.num_levels):
+        assert np.array_equal(r.gauss(0, l), o.gauss(0, l)), l
+    assert r.ext_total == o.ext_total
