@@ -64,6 +64,12 @@ CASES = {
     "down2_200x152": (200, 152, 302, False, dict(octaves=2, upscale_factor=-2.0)),
     "up_half_opencv_120x90": (120, 90, 303, False, dict(octaves=3, upscale_factor=0.5, sift_mode=po.MODE_OPENCV)),
     "up_1p5_float_96x72": (96, 72, 304, True, dict(octaves=3, upscale_factor=1.5, sift_mode=po.MODE_VLFEAT)),
+    # sizes at which a tap coordinate sits on a 1/256 sub-texel boundary (round 4, found by tools/ref_fuzz.py): level 0 of
+    # a fractional scale factor -- (x + shift)/W -+ k/W is not (x -+ k + shift)/W there -- and the fixed-span taps
+    # ypos -+ i * mul_h, one fma in the reference's device code
+    "up_half_boundary_163x122": (163, 122, 11, False, dict(octaves=2, upscale_factor=0.5, sift_mode=po.MODE_OPENCV)),
+    "fixed15_up_half_136x135": (136, 135, 9080, False, dict(octaves=1, sift_mode=po.MODE_OPENCV, gauss_mode=po.GAUSS_FIXED15,
+                                                            upscale_factor=0.5, initial_blur=0.8, threshold=0.02)),
 }
 
 # BASELINE config 2 at full size in the mode the north_star quotes parity on: the bench frame (seed 1000), VLFeat
