@@ -293,3 +293,33 @@ def test_descriptor_row_spans_contain_every_window_pixel():
                 assert xa <= first and last <= xb, (x, y, ang, SBP, ii, xa, xb, first, last)
                 checked += 1
     assert checked > 100_000
+
+
+def test_two_bin_plateau_peaks_on_the_common_boundary():
+    """orient_desc.hip k_orientation: with the peak test hval > hp && hval >= hn a two-bin plateau (an exact tie that only
+    the integer histogram can produce; the reference's float sums break it by rounding noise) is a peak at its LEFT bin,
+    and the parabola through (hp, h, h) puts the refined position 1.5 bins right of the previous bin, i.e. on the boundary
+    between the two equal bins -- where the reference's answer lies up to its noise.  Exactly one peak per plateau, none on
+    a flat histogram, unchanged where neighbours differ."""
+    def peaks(h):
+        out = []
+        n = len(h)
+        for b in range(n):
+            hp, hv, hn = h[(b - 1) % n], h[b], h[(b + 1) % n]
+            if hv > hp and hv >= hn:
+                num = 3.0 * hp - 4.0 * hv + hn
+                den = 2.0 * (hp - 2.0 * hv + hn)
+                nb = num / den
+                if 0.0 <= nb <= 2.0:
+                    out.append(((b - 1) % n) + nb)
+        return out
+
+    h = np.array([0.1, 0.4, 1.0, 1.0, 0.5, 0.2] + [0.05] * 30)
+    assert len(peaks(h)) == 1 and abs(peaks(h)[0] - 2.5) < 1e-9   # the boundary between bins 2 and 3
+    assert peaks(np.zeros(36)) == []
+    h2 = np.array([0.1, 0.4, 1.0, 0.9, 0.5, 0.2] + [0.05] * 30)
+    strict = [b for b in range(36) if h2[b] > max(h2[b - 1], h2[(b + 1) % 36])]
+    assert strict == [2] and len(peaks(h2)) == 1 and 1.5 < peaks(h2)[0] < 2.5
+    h3 = np.array([0.05] * 34 + [1.0, 1.0])                    # a plateau across the wrap-around neighbour
+    pw = peaks(np.roll(h3, 1))
+    assert len(pw) == 1 and abs(pw[0] - 35.5) < 1e-9
