@@ -12,6 +12,7 @@
 // with no host synchronisation inside the chain (the reference has four blocking counter
 // round-trips and four device-wide syncs per image).
 #include "psx_internal.h"
+#include "blur_tile_core.h"
 
 #include <cmath>
 #include <cstdio>
@@ -21,6 +22,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -175,6 +177,17 @@ struct psx_ctx {
     PsxFlowJob*  d_flow_jobs = nullptr;  size_t flow_jobs_cap = 0;
     PsxFlowItem* d_flow_items = nullptr; size_t flow_items_cap = 0;
     long long*   d_flow_trace = nullptr;     // psx_flow_trace only
+    // k_blur_tile (pyramid_tile.hip): the octaves that cannot fill the chip run several levels per launch on LDS-resident
+    // tiles -- levels 1..L-3 (+ the decimation) of octave o together with levels L-2..L-1 of octave o-1 in ONE launch.
+    // POPSIFT_TILE=0: one launch per level (the diagonal schedule); POPSIFT_TILE_MAXPX: largest plane (pixels) that takes
+    // the tile kernel; POPSIFT_TILE_TY / POPSIFT_TILE_NT: tile rows (32 / 64) and threads per workgroup (512 / 1024)
+    int  tile_mode = 1, tile_ty = 64, tile_nt = 512;
+    long long tile_maxpx = 3ll << 20;
+    bool tile_on = false;              // a tile schedule exists for the current size
+    int  tile_first = 0;               // first octave on the tile kernel; the octaves in front keep one launch per level
+    struct TileLaunch { int job0, njobs, grid; size_t lds; };
+    std::vector<TileLaunch> tile_launches;
+    PsxTileJob* d_tile_jobs = nullptr; size_t tile_jobs_cap = 0;
     int  resident_blocks = 1024;       // 4 x compute units
     bool batch_octaves = true;         // diagonal schedule: two octaves' levels in one launch (POPSIFT_BATCH_OCTAVES=0: one plane per launch)
 };
@@ -303,6 +316,166 @@ int grow(psx_ctx* ctx, T** ptr, size_t* cap, size_t need)
 
 } // namespace
 
+// ---- k_blur_tile: the schedule of a frame size (psx_resize) --------------------------------------------------------------
+// The blur levels 1..L-1 of every octave from tile_first on are cut into groups of consecutive levels, each one job of the
+// tile kernel: a group ends at level L-3 (the level that feeds the next octave: the next octave must not wait for more) and
+// wherever the plan of blur_tile_core.h says "does not fit" (LDS, Q's width).  A job runs in the launch slot behind its
+// producer -- the previous group of its octave, or the group of the octave above that ends at level L-3 -- and all jobs of
+// a slot share one launch, the deepest octave (the head of the dependency chain) first.  Default configuration: slot s =
+// {levels 1..3 of octave first + s, levels 4..5 of octave first + s - 1}.
+struct TileSched { std::vector<PsxTileJob> jobs; std::vector<psx_ctx::TileLaunch> launches; std::vector<int> octave, l0, slot; int first = 0; };
+// false: nothing to run on the tile kernel (no octave small enough, or a level it is not built for)
+static bool tile_schedule(const PsxParams& P, const int* inc_span, const float* inc_filter, int tile_ty, int tile_nt,
+                          long long maxpx, TileSched& out)
+{
+    const int L = P.L, D = L - 3;
+    int first = 0;
+    while (first < P.num_octaves && (long long)P.oct[first].w * P.oct[first].h > maxpx) first++;
+    if (first >= P.num_octaves || D < 1) return false;
+    struct Group { int octave, l0, nlev, slot; PsxTileJob job; size_t lds; };
+    std::vector<Group> groups;
+    int feeder_slot = -1;                              // slot of the group that writes level 0 of the octave being planned
+    const int rows_cap = (tile_nt >= 1024 ? 8 : 16);
+    for (int o = first; o < P.num_octaves; o++) {
+        const PsxOctave& oc = P.oct[o];
+        int l = 1, prev_slot = feeder_slot, next_feeder = -1;
+        while (l < L) {
+            const int lmax = l <= D ? D : L - 1;       // a group does not cross level L-3
+            int n = lmax - l + 1;
+            if (n > PSX_TILE_MAXLEV) n = PSX_TILE_MAXLEV;
+            Group g{};
+            for (; n >= 1; n--) {
+                int radii[PSX_TILE_MAXLEV];
+                for (int k = 0; k < n; k++) radii[k] = inc_span[l + k] - 1;
+                memset(&g.job, 0, sizeof(g.job));
+                g.lds = psx_tile_plan_job(g.job, oc.w, oc.h, oc.pitch, n, radii, 64, tile_ty);
+                if (g.lds != 0 && g.job.h.NR <= rows_cap * (tile_nt >> g.job.h.lpr_shift)) break;
+            }
+            if (n < 1) return false;                   // a level the tile kernel is not built for: keep the launches
+            g.octave = o; g.l0 = l; g.nlev = n; g.slot = prev_slot + 1;
+            PsxTileHdr& h = g.job.h;
+            h.src = oc.data + (size_t)(l - 1) * oc.plane;
+            h.half_dst = nullptr; h.half_pitch = 0; h.half_lev = -1;
+            for (int k = 0; k < n; k++) {
+                g.job.dst[k] = oc.data + (size_t)(l + k) * oc.plane;
+                for (int q = 0; q < PSX_GAUSS_ALIGN; q++) g.job.taps[k].g[q] = inc_filter[(l + k) * PSX_GAUSS_ALIGN + q];
+            }
+            if (l <= D && l + n - 1 == D) {
+                next_feeder = g.slot;
+                if (o + 1 < P.num_octaves) { h.half_dst = P.oct[o + 1].data; h.half_pitch = P.oct[o + 1].pitch; h.half_lev = D - l; }
+            }
+            prev_slot = g.slot;
+            groups.push_back(g);
+            l += n;
+        }
+        feeder_slot = next_feeder;
+    }
+    int nslots = 0;
+    for (const Group& g : groups) if (g.slot + 1 > nslots) nslots = g.slot + 1;
+    for (int s = 0; s < nslots; s++) {
+        psx_ctx::TileLaunch ln{(int)out.jobs.size(), 0, 0, 0};
+        for (int o = P.num_octaves - 1; o >= first; o--)
+            for (const Group& g : groups)
+                if (g.slot == s && g.octave == o) {
+                    PsxTileJob j = g.job;
+                    j.h.block0 = ln.grid;
+                    ln.grid += j.h.tiles_x * j.h.tiles_y;
+                    if (g.lds > ln.lds) ln.lds = g.lds;
+                    ln.njobs++;
+                    out.jobs.push_back(j);
+                    out.octave.push_back(g.octave); out.l0.push_back(g.l0); out.slot.push_back(s);
+                }
+        if (ln.njobs > 0) out.launches.push_back(ln);
+    }
+    out.first = first;
+    return !out.jobs.empty();
+}
+
+static int plan_tiles(psx_ctx* ctx)
+{
+    ctx->tile_on = false;
+    ctx->tile_launches.clear();
+    if (ctx->tile_mode == 0 || ctx->alt_pyramid || ctx->flow_on) return PSX_OK;
+    TileSched sc;
+    if (!tile_schedule(ctx->hp, ctx->inc_span, ctx->inc_filter, ctx->tile_ty, ctx->tile_nt, ctx->tile_maxpx, sc)) return PSX_OK;
+    int rc = grow(ctx, &ctx->d_tile_jobs, &ctx->tile_jobs_cap, sc.jobs.size());
+    if (rc != PSX_OK) return rc;
+    PSX_HIP(hipMemcpy(ctx->d_tile_jobs, sc.jobs.data(), sizeof(PsxTileJob) * sc.jobs.size(), hipMemcpyHostToDevice));
+    ctx->tile_launches = sc.launches;
+    ctx->tile_on = true;
+    ctx->tile_first = sc.first;
+    return PSX_OK;
+}
+
+// Host-only self check of a tile schedule (no device needed; tests/test_capi_cpu.py): every level 1..L-1 of every octave
+// from the first tiled one on is produced by exactly one job, a job sits in a later launch than the job that writes its
+// source plane, the decimated plane of an octave is written by the job that ends at level L-3, workgroup ranges of a
+// launch are contiguous.  Returns the number of jobs (0: the kernel would not be used), or a negative code naming the
+// violated invariant.  stats (optional, 4 ints): first tiled octave, launches, largest LDS need, largest grid.
+extern "C" int psx_tile_selfcheck(int w0, int h0, int num_octaves, int levels, const int* spans, int tile_ty, int tile_nt,
+                                  long long maxpx, int* stats)
+{
+    PsxParams P;
+    memset(&P, 0, sizeof(P));
+    P.num_octaves = num_octaves; P.levels = levels; P.L = levels + 3;
+    if (num_octaves < 1 || num_octaves > PSX_MAX_OCTAVES || P.L > PSX_GAUSS_LEVELS) return -1;
+    size_t off = 4096;
+    int w = w0, h = h0;
+    for (int o = 0; o < num_octaves; o++) {
+        PsxOctave& oc = P.oct[o];
+        oc.w = w; oc.h = h; oc.pitch = (w + 63) & ~63; oc.plane = (size_t)oc.pitch * h;
+        oc.data = reinterpret_cast<float*>(off * 4);
+        off += oc.plane * P.L;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    std::vector<float> filt((size_t)PSX_GAUSS_LEVELS * PSX_GAUSS_ALIGN, 0.0f);
+    TileSched sc;
+    if (!tile_schedule(P, spans, filt.data(), tile_ty, tile_nt, maxpx, sc)) return 0;
+    const int L = P.L, D = L - 3;
+    std::vector<int> writer((size_t)num_octaves * L, -1), wslot((size_t)num_octaves * L, -1);
+    for (size_t q = 0; q < sc.jobs.size(); q++) {
+        const PsxTileJob& j = sc.jobs[q];
+        const int o = sc.octave[q], l0 = sc.l0[q];
+        if (o < sc.first || o >= num_octaves || l0 < 1 || l0 + j.h.nlev > L) return -2;
+        if (j.h.src != P.oct[o].data + (size_t)(l0 - 1) * P.oct[o].plane || j.h.W != P.oct[o].w || j.h.H != P.oct[o].h) return -3;
+        for (int k = 0; k < j.h.nlev; k++) {
+            if (j.dst[k] != P.oct[o].data + (size_t)(l0 + k) * P.oct[o].plane) return -3;
+            if (spans[l0 + k] - 1 > psx_tile_radius(j.lev[k].rsel)) return -4;
+            int& wr = writer[(size_t)o * L + l0 + k];
+            if (wr != -1) return -5;
+            wr = (int)q; wslot[(size_t)o * L + l0 + k] = sc.slot[q];
+        }
+        const bool feeds = l0 <= D && l0 + j.h.nlev - 1 == D && o + 1 < num_octaves;
+        if (feeds != (j.h.half_dst != nullptr)) return -6;
+        if (feeds) {
+            if (j.h.half_dst != P.oct[o + 1].data || j.h.half_lev != D - l0 || j.h.half_pitch != P.oct[o + 1].pitch) return -6;
+            writer[(size_t)(o + 1) * L] = (int)q; wslot[(size_t)(o + 1) * L] = sc.slot[q];
+        }
+    }
+    for (int o = sc.first; o < num_octaves; o++)
+        for (int l = 1; l < L; l++) if (writer[(size_t)o * L + l] < 0) return -7;
+    for (size_t q = 0; q < sc.jobs.size(); q++) {
+        const int o = sc.octave[q], l0 = sc.l0[q];
+        const int src_slot = (o == sc.first && l0 == 1) ? -1 : wslot[(size_t)o * L + l0 - 1];
+        if (!(o == sc.first && l0 == 1) && (src_slot < 0 || src_slot >= sc.slot[q])) return -8;   // the producer is not in an earlier launch
+    }
+    size_t maxlds = 0; int maxgrid = 0;
+    for (const psx_ctx::TileLaunch& ln : sc.launches) {
+        int at = 0;
+        for (int q = 0; q < ln.njobs; q++) {
+            const PsxTileJob& j = sc.jobs[(size_t)ln.job0 + q];
+            if (j.h.block0 != at) return -9;
+            at += j.h.tiles_x * j.h.tiles_y;
+            if (sc.slot[(size_t)ln.job0 + q] != sc.slot[(size_t)ln.job0]) return -9;
+        }
+        if (at != ln.grid || ln.lds == 0 || ln.lds > PSX_TILE_LDS_MAX) return -9;
+        if (ln.lds > maxlds) maxlds = ln.lds;
+        if (ln.grid > maxgrid) maxgrid = ln.grid;
+    }
+    if (stats) { stats[0] = sc.first; stats[1] = (int)sc.launches.size(); stats[2] = (int)maxlds; stats[3] = maxgrid; }
+    return (int)sc.jobs.size();
+}
+
 extern "C" {
 
 const char* psx_version(void) { return "popsift-mi355x 0.1 (gfx950, HIP)"; }
@@ -428,6 +601,10 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     // (single frame 0.63 vs 0.63 ms, throughput equal): kernel-to-kernel dependencies cost the same either way
     { const char* g = getenv("POPSIFT_HIP_GRAPH"); n->graph_off = !(g != nullptr && g[0] == '1'); }
     { const char* g = getenv("POPSIFT_BATCH_OCTAVES"); n->batch_octaves = !(g != nullptr && g[0] == '0'); }
+    { const char* g = getenv("POPSIFT_TILE"); if (g != nullptr && (g[0] == '0' || g[0] == '1')) n->tile_mode = g[0] - '0'; }
+    { const char* g = getenv("POPSIFT_TILE_TY"); if (g != nullptr) { const int v = atoi(g); if (v >= 8 && v <= 128 && (v & 3) == 0) n->tile_ty = v; } }
+    { const char* g = getenv("POPSIFT_TILE_NT"); if (g != nullptr) { const int v = atoi(g); if (v == 512 || v == 1024) n->tile_nt = v; } }
+    { const char* g = getenv("POPSIFT_TILE_MAXPX"); if (g != nullptr) { const long long v = atoll(g); if (v >= 0) n->tile_maxpx = v; } }
     std::string why;
     int rc = compute_tables(&n->cfg, n->inc_filter, n->inc_span, n->inc_sigma, n->dd_filter, n->dd_span,
                             n->dd_sigma, &why);
@@ -484,6 +661,7 @@ int psx_destroy(psx_ctx* ctx)
     (void)hipFree(ctx->d_input_own); (void)hipFree(ctx->d_pyr); (void)hipFree(ctx->d_up);
     (void)hipFree(ctx->d_intm); (void)hipFree(ctx->d_vbuf);
     (void)hipFree(ctx->d_flow_jobs); (void)hipFree(ctx->d_flow_items);
+    (void)hipFree(ctx->d_tile_jobs);
     (void)hipFree(ctx->d_gf_keys); (void)hipFree(ctx->d_gf_vals); (void)hipFree(ctx->d_gf_temp);
     (void)hipFree(ctx->d_gf_scratch);
     (void)hipFree(ctx->d_iext); (void)hipFree(ctx->d_iext_off); (void)hipFree(ctx->d_cand);
@@ -609,6 +787,7 @@ int psx_resize(psx_ctx* ctx, int w, int h)
             if (!ok) return fail(ctx, PSX_ERR_HIP, "psx_resize: could not upload the pyramid work list");
         }
     }
+    { const int trc = plan_tiles(ctx); if (trc != PSX_OK) return trc; }
     ctx->d_cand_ct = reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->d_cnt) + CNT_BLOCK + ctx->flow_bytes);
     P.cand_capacity = (4 * c.max_extrema + PSX_CAND_SUB - 1) / PSX_CAND_SUB;
     if ((rc = grow(ctx, &ctx->d_cand, &ctx->cand_cap, (size_t)P.num_octaves * PSX_CAND_SUB * P.cand_capacity)) != PSX_OK) return rc;
@@ -809,6 +988,42 @@ int psx_build_pyramid(psx_ctx* ctx)
             if (pf) { ctx->blur_probe_n = 1; ctx->blur_probe_bytes = ctx->flow_algo_bytes; }
             else    { ctx->blur_probe_n = P.L - 1; ctx->blur_probe_bytes = 8.0 * (double)P.oct[0].w * P.oct[0].h; }
         }
+        if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        return PSX_OK;
+    }
+    if (ctx->tile_on && !(probe && ctx->tile_first == 0)) {
+        // octaves in front of tile_first: one launch per level, the octave's extrema scan right behind its last level;
+        // then the tile launches (several levels of up to two octaves each); then the scans of the small octaves
+        double probe_bytes = 0.0;
+        int deferred[PSX_MAX_OCTAVES], ndef = 0;
+        auto scan_after = [&](int o) -> int {
+            if (!ctx->interleave) return PSX_OK;
+            if (psx_extrema_tiles(P, o) >= ctx->resident_blocks) {
+                const bool px = probe && o == 0;
+                if (px) PSX_HIP(hipEventRecord(ctx->ev_x[2], ctx->stream));
+                PSX_HIP(psx_launch_extrema(ctx->d_params, ctx->hp, ctx->d_cnt, o, ctx->stream));
+                if (px) { PSX_HIP(hipEventRecord(ctx->ev_x[3], ctx->stream)); ctx->probe_ext0 = true; }
+            } else
+                deferred[ndef++] = o;
+            return PSX_OK;
+        };
+        for (int o = 0; o < ctx->tile_first; o++) {
+            for (int level = 1; level < P.L; level++) {
+                const bool pl = probe && o == 0;
+                hipEvent_t e0 = pl ? ctx->ev_blur[2 * (level - 1)] : nullptr, e1 = pl ? ctx->ev_blur[2 * (level - 1) + 1] : nullptr;
+                const int rc = launch_blur_level(ctx, o, level, e0, e1);
+                if (rc != PSX_OK) return rc;
+                if (pl) probe_bytes += 8.0 * (double)P.oct[o].w * P.oct[o].h;
+            }
+            const int rc = scan_after(o);
+            if (rc != PSX_OK) return rc;
+        }
+        for (const psx_ctx::TileLaunch& ln : ctx->tile_launches)
+            PSX_HIP(psx_launch_blur_tile(ctx->d_tile_jobs + ln.job0, ln.njobs, ln.grid, ln.lds, ctx->tile_nt, ctx->stream));
+        for (int o = ctx->tile_first; o < P.num_octaves; o++) { const int rc = scan_after(o); if (rc != PSX_OK) return rc; }
+        if (ndef > 0) { const int rc = launch_extrema_set(ctx, deferred, ndef); if (rc != PSX_OK) return rc; }
+        if (probe) { ctx->blur_probe_n = P.L - 1; ctx->blur_probe_bytes = probe_bytes / (P.L - 1); }
+        ctx->ext_launched = ctx->interleave;
         if (ctx->timers) PSX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
         return PSX_OK;
     }

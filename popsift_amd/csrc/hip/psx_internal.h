@@ -190,5 +190,20 @@ hipError_t psx_launch_feature_ptrs(const psx_feature* in, psx_feature_dev* out, 
 hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, const PsxExport& x, int cus, hipStream_t s);
 hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, const PsxExport& x, int cus, hipStream_t s);
 
+// ---- multi-level tile kernel (pyramid_tile.hip, blur_tile_core.h): several consecutive levels of an octave per launch ----
+struct PsxTileJob;
+// nt: 512 or 1024 threads per workgroup; lds_bytes: the largest LDS need among the jobs (<= 80 KB: two workgroups per CU at nt = 512)
+hipError_t psx_launch_blur_tile(const PsxTileJob* d_jobs, int njobs, int grid, size_t lds_bytes, int nt, hipStream_t s,
+                                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+
 // ---- small device helpers --------------------------------------------------------------------
 __device__ __forceinline__ int psx_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// Blocks with equal (blockIdx % 8) run on the same XCD and share its L2 (MI355X_MICROARCH.md, "Workgroup dispatch"); give
+// them contiguous logical ids so that neighbouring strips / tiles, which share halo pixels, hit the same L2.  Bijective
+// for any grid size.  Speed only.
+__device__ __forceinline__ int psx_xcd_remap(int b, int n)
+{
+    const int q = n >> 3, r = n & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}

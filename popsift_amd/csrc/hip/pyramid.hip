@@ -22,6 +22,7 @@
 //   V (s_pyramid_build_aa.cu:52-86): k=span-1..1: acc+=T[y-k]*g; acc+=T[y+k]*g; then centre
 //   level 0 H (s_pyramid_build_ra.cu:17-55): pairs outermost-in, then centre, then *255
 #include "psx_internal.h"
+#include "blur_arith.h"
 
 #include <hip/hip_ext.h>
 
@@ -39,15 +40,7 @@ constexpr int TW = 64;    // strip width (columns per workgroup)
 constexpr int BR = 32;    // rows per marching step
 constexpr int NT = 256;   // threads per workgroup
 
-// Blocks with equal (blockIdx % 8) run on the same XCD and share its L2 (MI355X_MICROARCH.md,
-// "Workgroup dispatch"); give them contiguous logical ids so that neighbouring strips, which
-// share halo columns, hit the same L2.  Bijective for any grid size.  Speed only.
-__device__ __forceinline__ int xcd_remap(int b, int n)
-{
-    const int q = n >> 3, r = n & 7;
-    const int xcd = b & 7, k = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
+__device__ __forceinline__ int xcd_remap(int b, int n) { return psx_xcd_remap(b, n); }
 
 struct BlurArgs {
     const float* src;
@@ -64,16 +57,8 @@ struct BlurArgs {
 #endif
 };
 
-// the same chain on two adjacent columns at once (v_pk_fma_f32): v[j] = (T[.][c], T[.][c+1])
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
 #define LDS_AS __attribute__((address_space(3)))
 #define GLOBAL_AS __attribute__((address_space(1)))
-__device__ __forceinline__ v2f pk_fma(v2f a, float g, v2f c)
-{
-    return __builtin_elementwise_fma(a, (v2f){g, g}, c);
-}
 #ifdef PSX_PHASE_TIMING
 __device__ long long* g_blur_dbg = nullptr;
 extern "C" void psx_debug_set_blur_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blur_dbg), &d, sizeof(d)); }
@@ -107,40 +92,7 @@ struct Geom2 {
     static constexpr int RS   = TW + 4;                 // ring row stride (floats): 16-byte aligned rows, == 4 (mod 8)
 };
 
-// k-major forms of the two filters: the per-output chains are the reference's, but the independent
-// chains advance together so that dependent v_pk_fma_f32 never issue back to back
-//   levels >= 1 (s_pyramid_build_aa.cu:17-50): centre, then pairs (x-k)+(x+k) from k=span-1 down to 1
-//   level 0 of octave 0 (s_pyramid_build_ra.cu:17-55): pairs outermost-in, then centre, then *255
-template <int R, int HALO, bool LEVEL0>
-__device__ __forceinline__ void hfilter8_km(const float* win, const PsxTaps& tp, float* out)
-{
-#pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = LEVEL0 ? 0.0f : fmaf(win[HALO + i], tp.g[0], 0.0f);
-#pragma unroll
-    for (int k = R; k >= 1; k--) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) out[i] = fmaf(win[HALO + i - k] + win[HALO + i + k], tp.g[k], out[i]);
-    }
-    if (LEVEL0) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) { out[i] = fmaf(win[HALO + i], tp.g[0], out[i]); out[i] = out[i] * 255.0f; }
-    }
-}
-template <int R>
-__device__ __forceinline__ void vfilter2x4_km(const v2f* v, const PsxTaps& tp, v2f* o)
-{
-#pragma unroll
-    for (int i = 0; i < 4; i++) o[i] = (v2f){0.0f, 0.0f};
-#pragma unroll
-    for (int k = R; k >= 1; k--) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i - k], tp.g[k], o[i]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i + k], tp.g[k], o[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) o[i] = pk_fma(v[R + i], tp.g[0], o[i]);
-}
+// hfilter8_km / vfilter2x4_km: blur_arith.h (shared with the tile kernel and its host emulation)
 
 // FLOW (k_pyramid_flow, the whole-pyramid kernel with device-side dependencies): 0 = an ordinary launch; 1 = every store is a
 // system-scope (write-through) store, so that a dependent workgroup of the SAME launch may read the rows once this

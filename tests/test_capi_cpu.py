@@ -248,3 +248,43 @@ def test_pyramid_flow_plan_refuses_large_radii():
     assert L.psx_flow_selfcheck(640, 480, 3, 3, spans, 0, 1024, 0, None) == -2
     spans[5] = 14
     assert L.psx_flow_selfcheck(640, 480, 3, 3, spans, 0, 1024, 0, None) > 0
+
+
+@pytest.mark.parametrize("w0,h0,octaves,levels", [(3840, 2160, 5, 3), (8192, 8192, 6, 3), (1280, 960, 5, 3), (640, 480, 4, 3),
+                                                  (150, 122, 3, 3), (64, 64, 2, 3), (4097, 33, 3, 3), (9, 3000, 4, 3), (2, 2, 1, 3),
+                                                  (1, 128, 2, 3), (667, 503, 4, 2), (667, 503, 4, 4), (1280, 960, 5, 5)])
+@pytest.mark.parametrize("ty,nt", [(64, 512), (32, 512), (64, 1024)])
+def test_tile_schedule_covers_every_level_once(w0, h0, octaves, levels, ty, nt):
+    """k_blur_tile's host-side schedule (api.hip tile_schedule), checked without a device: every blur level of every octave
+    from the first tiled one on is written by exactly one job, producers sit in earlier launches than their consumers, the
+    decimated plane comes from the job that ends at level L-3, workgroup ranges of a launch are contiguous, LDS fits."""
+    import ctypes as C
+    from popsift_amd import capi
+    L = capi.lib()
+    L.psx_tile_selfcheck.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] + [C.c_int] * 2 + [C.c_longlong, C.POINTER(C.c_int)]
+    t = capi.gauss_tables(capi.default_config(levels=levels))
+    spans = (C.c_int * capi.GAUSS_LEVELS)(*[int(v) for v in t["inc_span"]])
+    stats = (C.c_int * 4)()
+    maxpx = 3 << 20
+    n = L.psx_tile_selfcheck(w0, h0, octaves, levels, spans, ty, nt, maxpx, stats)
+    assert n >= 0, "psx_tile_selfcheck code %d" % n
+    first, launches, lds, grid = list(stats)
+    small = [o for o in range(octaves) if ((w0 + (1 << o) - 1) >> o) * ((h0 + (1 << o) - 1) >> o) <= maxpx]
+    if n == 0:
+        assert not small or max(int(v) for v in spans[:levels + 3]) - 1 > 13
+    else:
+        assert first == small[0] and lds <= 160 * 1024
+        if levels == 3:
+            # default configuration: levels 1..3 and 4..5 of every tiled octave, octave o's second job beside octave o+1's first
+            assert n == 2 * (octaves - first) and launches == octaves - first + 1
+
+
+def test_tile_schedule_refuses_large_radii():
+    import ctypes as C
+    from popsift_amd import capi
+    L = capi.lib()
+    L.psx_tile_selfcheck.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] + [C.c_int] * 2 + [C.c_longlong, C.POINTER(C.c_int)]
+    spans = (C.c_int * capi.GAUSS_LEVELS)(*([6, 6, 8, 9, 11, 17] + [0] * (capi.GAUSS_LEVELS - 6)))
+    assert L.psx_tile_selfcheck(640, 480, 3, 3, spans, 64, 512, 3 << 20, None) == 0
+    spans[5] = 14
+    assert L.psx_tile_selfcheck(640, 480, 3, 3, spans, 64, 512, 3 << 20, None) == 6

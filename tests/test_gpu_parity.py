@@ -804,6 +804,42 @@ def test_pyramid_flow_kernel_bit_exact(oracle, capi, monkeypatch, flow, ld, step
             ctx.close()
 
 
+# ---- k_blur_tile: several blur levels of the small octaves per launch on LDS-resident tiles (default; POPSIFT_TILE=0: off) ----
+@pytest.mark.parametrize("tile,ty,nt,maxpx", [("1", "64", "512", "3145728"), ("1", "32", "512", "1000000000"),
+                                              ("1", "64", "1024", "1000000000"), ("1", "32", "1024", "300000"), ("0", "64", "512", "0")])
+def test_tile_kernel_bit_exact(oracle, capi, monkeypatch, tile, ty, nt, maxpx):
+    """The multi-level tile kernel (pyramid_tile.hip k_blur_tile; the switches are read at psx_create): levels 1..L-3 (+ the
+    decimation) and levels L-2..L-1 of an octave are one launch each, out of LDS.  Same arithmetic as the marching kernel
+    (blur_arith.h): every plane bit-identical to the oracle -- with every octave on the tile kernel (maxpx huge), only the
+    small ones, both tile heights and workgroup sizes, other level counts (other groupings of levels into jobs), planes
+    smaller than a tile's halo, several contexts in flight.  tests/test_tile_emu_cpu.py checks the same phases on the CPU."""
+    monkeypatch.setenv("POPSIFT_TILE", tile)
+    monkeypatch.setenv("POPSIFT_TILE_TY", ty)
+    monkeypatch.setenv("POPSIFT_TILE_NT", nt)
+    monkeypatch.setenv("POPSIFT_TILE_MAXPX", maxpx)
+    cases = [(1920, 1080, 1000, dict(octaves=5, sift_mode=2)), (640, 480, 1001, dict(octaves=5, sift_mode=1, gauss_mode=3)),
+             (333, 251, 7, dict(octaves=4)), (257, 190, 3, dict(octaves=3, upscale_factor=0.0)), (65, 65, 9, dict(octaves=3)),
+             (4097, 33, 5, dict(octaves=3)), (200, 150, 21, dict(octaves=4, upscale_factor=2.0)),
+             (320, 240, 11, dict(octaves=3, levels=2)), (320, 240, 12, dict(octaves=3, levels=4)), (31, 17, 13, dict(octaves=2))]
+    for w, h, seed, kw in cases:
+        imgs = [synth(w, h, seed), synth(w, h, seed + 100)]
+        refs = [oracle.run_pyramid(oracle.default_config(**kw), im) for im in imgs]
+        ctxs = [capi.Context(capi.default_config(**kw)) for _ in range(3)]
+        for rep in range(2):
+            for k, ctx in enumerate(ctxs):                     # three contexts in flight, frames alternating
+                ctx.upload(imgs[(rep + k) % 2])
+                ctx.extract()
+            for k, ctx in enumerate(ctxs):
+                ref = refs[(rep + k) % 2]
+                ctx.counts()
+                for o in range(ref.num_octaves):
+                    for l in range(ref.num_levels):
+                        g = ctx.dump_plane(capi.PLANE_GAUSS, o, l)
+                        assert np.array_equal(g.view(np.uint32), ref.gauss(o, l).view(np.uint32)), (w, h, rep, k, o, l)
+        for ctx in ctxs:
+            ctx.close()
+
+
 def test_orientation_of_a_mirror_symmetric_gradient_field(oracle, capi):
     """A keypoint whose gradient field is mirror symmetric about a histogram bin boundary has two equal top bins.  With the
     reference's (and the oracle's) float accumulation rounding noise breaks the tie, one of the two wins and the parabola
