@@ -242,6 +242,9 @@ int psx_device_results(psx_ctx* ctx, const psx_feature** d_features, const float
 /* pinned, GPU-mapped host memory (hipHostMalloc): cheap targets for psx_attach_export and sources for
  * psx_upload_*.  Allocation is slow (pool the buffers). */
 int psx_host_alloc(size_t bytes, void** out);
+/* the same with `device` made current on the calling thread first (device < 0: as psx_host_alloc): the HIP runtime
+ * places pinned pages near the calling thread's current device or CPUs; a pool that serves device d allocates here. */
+int psx_host_alloc_near(int device, size_t bytes, void** out);
 int psx_host_free(void* ptr);
 int psx_dev_alloc(int device, size_t bytes, void** out);
 int psx_dev_free(int device, void* ptr);

@@ -60,7 +60,7 @@ SYMBOLS = [
     "psx_find_extrema", "psx_orientation", "psx_descriptors", "psx_extract", "psx_sync", "psx_counts",
     "psx_download", "psx_attach_export", "psx_device_results", "psx_dump_plane", "psx_dump_iext", "psx_dump_extrema",
     "psx_set_wait_mode", "psx_enable_timers", "psx_stage_times", "psx_time_blur", "psx_stream",
-    "psx_host_alloc", "psx_host_free", "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_dev_write", "psx_clone_results", "psx_match", "psx_match_release", "psx_device_count", "psx_device_info", "psx_device_pci",
+    "psx_host_alloc", "psx_host_alloc_near", "psx_host_free", "psx_dev_alloc", "psx_dev_free", "psx_dev_read", "psx_dev_write", "psx_clone_results", "psx_match", "psx_match_release", "psx_device_count", "psx_device_info", "psx_device_pci",
     "psx_enable_blur_probe", "psx_blur_probe_times", "psx_copy_bench", "psx_upload_pinned", "psx_attach_export_mapped",
     "psx_print_gauss_tables", "psx_flow_trace", "psx_debug_cross_stream", "psx_probe_extra_times",
 ]

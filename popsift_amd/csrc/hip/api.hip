@@ -179,9 +179,13 @@ struct psx_ctx {
     long long*   d_flow_trace = nullptr;     // psx_flow_trace only
     // k_blur_tile (pyramid_tile.hip): the octaves that cannot fill the chip run several levels per launch on LDS-resident
     // tiles -- levels 1..L-3 (+ the decimation) of octave o together with levels L-2..L-1 of octave o-1 in ONE launch.
-    // POPSIFT_TILE=0: one launch per level (the diagonal schedule); POPSIFT_TILE_MAXPX: largest plane (pixels) that takes
-    // the tile kernel; POPSIFT_TILE_TY / POPSIFT_TILE_NT: tile rows (32 / 64) and threads per workgroup (512 / 1024)
-    int  tile_mode = 1, tile_ty = 64, tile_nt = 512;
+    // OPT-IN (POPSIFT_TILE=1; default: one launch per level, the diagonal schedule): bit-exact, five pyramid launches
+    // for octaves 1-4 instead of thirteen, but measured slower on MI355X (profiles/r05_tile_schedule_ab.txt: single frame
+    // 0.467 vs 0.436 ms, 8-context throughput -11 %): a tile is a serial chain of passes whose instruction overhead per
+    // 8 x 8 block (addresses, predicates, stores) is ~2x its filter arithmetic, and the halo work is 1.65x.
+    // POPSIFT_TILE_MAXPX: largest plane (pixels) that takes the tile kernel; POPSIFT_TILE_TY / POPSIFT_TILE_NT: tile rows
+    // (32 / 64) and threads per workgroup (512 / 1024); POPSIFT_TILE_SMALL=0: no 32 x 32 tiles for the tiny octaves
+    int  tile_mode = 0, tile_ty = 64, tile_nt = 1024;
     long long tile_maxpx = 3ll << 20;
     bool tile_on = false;              // a tile schedule exists for the current size
     int  tile_first = 0;               // first octave on the tile kernel; the octaves in front keep one launch per level
@@ -328,6 +332,7 @@ struct TileSched { std::vector<PsxTileJob> jobs; std::vector<psx_ctx::TileLaunch
 static bool tile_schedule(const PsxParams& P, const int* inc_span, const float* inc_filter, int tile_ty, int tile_nt,
                           long long maxpx, TileSched& out)
 {
+    static const bool small_tiles = [] { const char* e = getenv("POPSIFT_TILE_SMALL"); return !(e != nullptr && e[0] == '0'); }();
     const int L = P.L, D = L - 3;
     int first = 0;
     while (first < P.num_octaves && (long long)P.oct[first].w * P.oct[first].h > maxpx) first++;
@@ -338,6 +343,10 @@ static bool tile_schedule(const PsxParams& P, const int* inc_span, const float* 
     const int rows_cap = (tile_nt >= 1024 ? 8 : 16);
     for (int o = first; o < P.num_octaves; o++) {
         const PsxOctave& oc = P.oct[o];
+        // an octave that cannot give every CU a 64-column tile takes 32 x 32 tiles: a tile is a serial chain of passes,
+        // what counts for such an octave is the length of that chain, not the halo work it repeats
+        int tx = 64, ty = tile_ty;
+        if (small_tiles && ((oc.w + 63) / 64) * ((oc.h + ty - 1) / ty) < 200) { tx = 32; ty = 32; }
         int l = 1, prev_slot = feeder_slot, next_feeder = -1;
         while (l < L) {
             const int lmax = l <= D ? D : L - 1;       // a group does not cross level L-3
@@ -348,7 +357,7 @@ static bool tile_schedule(const PsxParams& P, const int* inc_span, const float* 
                 int radii[PSX_TILE_MAXLEV];
                 for (int k = 0; k < n; k++) radii[k] = inc_span[l + k] - 1;
                 memset(&g.job, 0, sizeof(g.job));
-                g.lds = psx_tile_plan_job(g.job, oc.w, oc.h, oc.pitch, n, radii, 64, tile_ty);
+                g.lds = psx_tile_plan_job(g.job, oc.w, oc.h, oc.pitch, n, radii, tx, ty);
                 if (g.lds != 0 && g.job.h.NR <= rows_cap * (tile_nt >> g.job.h.lpr_shift)) break;
             }
             if (n < 1) return false;                   // a level the tile kernel is not built for: keep the launches
@@ -1463,6 +1472,13 @@ int psx_host_alloc(size_t bytes, void** out)
         return fail(nullptr, PSX_ERR_HIP, "psx_host_alloc: mapped host memory has a different device address on this system");
     }
     return PSX_OK;
+}
+
+int psx_host_alloc_near(int device, size_t bytes, void** out)
+{
+    psx_ctx* ctx = nullptr;
+    if (device >= 0) PSX_HIP(hipSetDevice(device));
+    return psx_host_alloc(bytes, out);
 }
 
 int psx_host_free(void* ptr)

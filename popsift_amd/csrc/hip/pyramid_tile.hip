@@ -12,9 +12,31 @@
 
 namespace {
 
+// Barrier between two phases that hand data over through LDS only: wait for this wave's LDS operations, not for its
+// global stores (__syncthreads() waits for vmcnt(0) as well, i.e. for the write-through plane stores of the vertical
+// pass to reach memory -- microseconds per level that nobody needs: the planes are read by LATER launches).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef PSX_PHASE_TIMING
+// measurement build (tools/build_phase_lib.sh, tools/tile_phase.py): clock64 at the phase boundaries of every workgroup
+__device__ long long* g_tile_dbg = nullptr;
+// record slot = an atomic ticket (word 0 of the buffer), so that every workgroup of every launch of a frame keeps its stamps
+#define TSTAMP(i) do { if (threadIdx.x == 0 && g_tile_dbg) g_tile_dbg[16 + (size_t)tslot * 16 + (i)] = clock64(); } while (0)
+#else
+#define TSTAMP(i)
+#endif
+
 template <int NT>
 __device__ __forceinline__ void tile_run(const PsxTileJob* __restrict__ jobs, const int njobs, float* const s_tile)
 {
+#ifdef PSX_PHASE_TIMING
+    int tslot = 0;
+    if (threadIdx.x == 0 && g_tile_dbg) tslot = (int)atomicAdd((unsigned long long*)g_tile_dbg, 1ull) & 4095;
+#endif
+    TSTAMP(0);
     const int tid = threadIdx.x;
     const int lid = psx_xcd_remap(blockIdx.x, gridDim.x);
     int ji = 0;
@@ -27,10 +49,16 @@ __device__ __forceinline__ void tile_run(const PsxTileJob* __restrict__ jobs, co
     float* const P = s_tile;
     float* const Q = s_tile + h.NR * h.SP;
 
+    TSTAMP(1);
+#ifdef PSX_PHASE_TIMING
+    if (threadIdx.x == 0 && g_tile_dbg) g_tile_dbg[16 + (size_t)tslot * 16 + 15] = (long long)h.nlev | ((long long)gridDim.x << 8) | ((long long)h.TX << 32) | ((long long)h.TY << 40);
+#endif
     tile_load<NT>(h, X0, Y0, P, tid);
+    TSTAMP(2);
     // any cell of P outside the plane: the levels' regions must be re-clamped between levels
     const bool edge = X0 - h.OX < 0 || X0 + h.TX + h.OX > h.W || Y0 - h.OY < 0 || Y0 + h.TY + h.OY > h.H;
-    __syncthreads();
+    lds_barrier();
+    TSTAMP(3);
     for (int l = 0; l < h.nlev; l++) {
         const PsxTileLevel lv = jb->lev[l];
         PsxTaps tp;
@@ -50,7 +78,9 @@ __device__ __forceinline__ void tile_run(const PsxTileJob* __restrict__ jobs, co
             case 3:  tile_hpass<psx_tile_radius(3), NT>(h, lv, tp, P, Q, th); break;
             default: tile_hpass<psx_tile_radius(4), NT>(h, lv, tp, P, Q, th); break;
         }
-        __syncthreads();
+        TSTAMP(4 + 3 * l);
+        lds_barrier();
+        TSTAMP(5 + 3 * l);
         asm volatile("" : "+v"(tv));
         switch (lv.rsel) {
             case 0:  tile_vpass<psx_tile_radius(0), NT>(h, lv, tp, Q, P, gdst, ghalf, X0, Y0, keep, tv); break;
@@ -59,11 +89,12 @@ __device__ __forceinline__ void tile_run(const PsxTileJob* __restrict__ jobs, co
             case 3:  tile_vpass<psx_tile_radius(3), NT>(h, lv, tp, Q, P, gdst, ghalf, X0, Y0, keep, tv); break;
             default: tile_vpass<psx_tile_radius(4), NT>(h, lv, tp, Q, P, gdst, ghalf, X0, Y0, keep, tv); break;
         }
+        TSTAMP(6 + 3 * l);
         if (keep) {
-            __syncthreads();
+            lds_barrier();
             if (edge) {
                 tile_fixup<NT>(h, lv, P, X0, Y0, tid);
-                __syncthreads();
+                lds_barrier();
             }
         }
     }
@@ -88,6 +119,10 @@ hipError_t launch(const PsxTileJob* d_jobs, int njobs, int grid, hipStream_t s, 
 }
 
 } // namespace
+
+#ifdef PSX_PHASE_TIMING
+extern "C" void psx_debug_set_tile_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_dbg), &d, sizeof(d)); }
+#endif
 
 hipError_t psx_launch_blur_tile(const PsxTileJob* d_jobs, int njobs, int grid, size_t lds_bytes, int nt, hipStream_t s,
                                 hipEvent_t ev0, hipEvent_t ev1)

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -60,68 +61,84 @@ const int MAX_POOLS = 33;                       // devices 0..31, and one pool f
 // drain / refill burst
 size_t free_limit()
 {
-    static const size_t lim = []{ const char* e = getenv( "POPSIFT_POOL_FREE_MB" ); return (size_t)( e ? atol( e ) : 2048 ) << 20; }();
+    static const size_t lim = []{ const char* e = getenv( "POPSIFT_POOL_FREE_MB" ); const long v = e ? atol( e ) : 2048; return (size_t)( v < 0 ? 0 : v ) << 20; }();
     return lim;
 }
 
-// CPUs local to the device's PCIe root, "" when unknown or when the host has a single NUMA node
-std::string local_cpulist( int device )
+// "0-3,8,10-11\n" -> the listed CPUs that the process may run on.  No strtok: several workers, the pool's helper threads
+// and the caller of enqueue() parse at the same moment during warm-up, and strtok keeps process-global state.
+int parse_cpulist( const char* s, const cpu_set_t& allowed, cpu_set_t* want )
 {
-    if( device < 0 || access( "/sys/devices/system/node/node1", F_OK ) != 0 ) return "";
-    const char* e = getenv( "POPSIFT_NUMA_PIN" );
-    if( e != nullptr && e[0] == '0' ) return "";
-    char bus[64];
-    if( psx_device_pci( device, bus, sizeof(bus) ) != PSX_OK || bus[0] == 0 ) return "";
-    for( char* c = bus; *c; c++ ) *c = (char)tolower( *c );
-    FILE* f = fopen( ( std::string( "/sys/bus/pci/devices/" ) + bus + "/local_cpulist" ).c_str(), "r" );
-    if( f == nullptr ) return "";
-    char line[4096] = { 0 };
-    const bool got = fgets( line, sizeof(line), f ) != nullptr;
-    fclose( f );
-    return got ? std::string( line ) : std::string();
+    CPU_ZERO( want );
+    int n = 0;
+    while( *s != 0 ) {
+        while( *s == ',' || *s == '\n' || *s == ' ' ) s++;
+        if( *s == 0 ) break;
+        char* end = nullptr;
+        long a = strtol( s, &end, 10 );
+        if( end == s ) { while( *s != 0 && *s != ',' ) s++; continue; }     // not a number: skip the token
+        long b = a;
+        s = end;
+        if( *s == '-' ) { b = strtol( s + 1, &end, 10 ); if( end == s + 1 ) b = a; s = end; }
+        while( *s != 0 && *s != ',' ) s++;
+        for( long c = a < 0 ? 0 : a; c <= b && c < CPU_SETSIZE; c++ )
+            if( CPU_ISSET( (int)c, &allowed ) ) { CPU_SET( (int)c, want ); n++; }
+    }
+    return n;
 }
 
-bool pin_to_cpulist( const std::string& list )
+// CPUs local to each device's PCIe root, read and parsed ONCE per device (sysfs does not change under us)
+struct DeviceCpus { std::once_flag once; bool valid = false; cpu_set_t set; };
+DeviceCpus& device_cpus( int device )
 {
-    cpu_set_t allowed, want;
-    if( list.empty() || sched_getaffinity( 0, sizeof(allowed), &allowed ) != 0 ) return false;
-    CPU_ZERO( &want );
-    int n = 0;
-    std::vector<char> buf( list.begin(), list.end() ); buf.push_back( 0 );
-    for( char* tok = strtok( buf.data(), ",\n" ); tok != nullptr; tok = strtok( nullptr, ",\n" ) ) {
-        int a = 0, b = 0;
-        const int k = sscanf( tok, "%d-%d", &a, &b );
-        if( k < 1 ) continue;
-        if( k == 1 ) b = a;
-        for( int c = a; c <= b && c < CPU_SETSIZE; c++ )
-            if( CPU_ISSET( c, &allowed ) ) { CPU_SET( c, &want ); n++; }
-    }
-    return n > 0 && sched_setaffinity( 0, sizeof(want), &want ) == 0;
+    static DeviceCpus* tab = new DeviceCpus[MAX_POOLS];
+    DeviceCpus& d = tab[ ( device >= 0 && device < MAX_POOLS - 1 ) ? device : MAX_POOLS - 1 ];
+    if( device < 0 || device >= MAX_POOLS - 1 ) return d;           // never valid
+    std::call_once( d.once, [&d, device]{
+        const char* e = getenv( "POPSIFT_NUMA_PIN" );
+        if( e != nullptr && e[0] == '0' ) return;
+        char bus[64];
+        if( psx_device_pci( device, bus, sizeof(bus) ) != PSX_OK || bus[0] == 0 ) return;
+        for( char* c = bus; *c; c++ ) *c = (char)tolower( *c );
+        FILE* f = fopen( ( std::string( "/sys/bus/pci/devices/" ) + bus + "/local_cpulist" ).c_str(), "r" );
+        if( f == nullptr ) return;
+        char line[4096] = { 0 };
+        const bool got = fgets( line, sizeof(line), f ) != nullptr;
+        fclose( f );
+        cpu_set_t allowed;
+        if( !got || sched_getaffinity( 0, sizeof(allowed), &allowed ) != 0 ) return;
+        d.valid = parse_cpulist( line, allowed, &d.set ) > 0;
+    } );
+    return d;
 }
+bool multi_node_host() { static const bool m = access( "/sys/devices/system/node/node1", F_OK ) == 0; return m; }
+
+void forget_pinned( void* p );      // drops the buffer from the pointer -> device registry (it is about to be freed)
 
 struct Pool
 {
     std::mutex                            m;
-    std::vector<std::pair<void*, size_t>> free_list;
+    std::multimap<size_t, void*>          free_list;        // by capacity: the smallest adequate buffer in O(log n)
     const bool                            pinned;
     const int                             device;          // -1: none
     size_t                                in_use = 0;      // bytes handed out
     size_t                                free_bytes = 0;  // bytes on the free list
     Stats                                 st;
-    std::string                           cpus;            // CPUs of the device's NUMA node ("" = do not care)
-    std::once_flag                        cpus_once;
     Pool( bool p, int d ) : pinned( p ), device( d ) { }
 
-    // hipHostMalloc places the pages on the NUMA node of the CALLING thread.  The caller of enqueue() runs anywhere,
-    // so on a multi-socket host a pool miss allocates from a short-lived helper thread bound to the CPUs of the
-    // device's PCIe root: socket-1 GPUs then DMA to socket-1 memory.  Only pool misses pay for it (warm-up).
+    // Where the pages of a pinned buffer land: on the NUMA node the HIP runtime picks for the calling thread -- by its CPU
+    // affinity or by its current device, depending on the runtime.  The caller of enqueue() runs anywhere, so on a
+    // multi-socket host a pool miss allocates from a short-lived helper thread that is bound to the CPUs of the device's
+    // PCIe root AND has made the device current (psx_host_alloc_near): socket-1 GPUs then DMA to socket-1 memory under
+    // either rule.  Only pool misses pay for it (warm-up).
     void* alloc_pinned( size_t c )
     {
-        std::call_once( cpus_once, [this]{ cpus = local_cpulist( device ); } );
         void* p = nullptr;
-        if( cpus.empty() ) { if( psx_host_alloc( c, &p ) != PSX_OK ) return nullptr; return p; }
-        const std::string list = cpus;
-        std::thread t( [&p, c, &list]{ pin_to_cpulist( list ); if( psx_host_alloc( c, &p ) != PSX_OK ) p = nullptr; } );
+        DeviceCpus& dc = device_cpus( device );
+        if( !multi_node_host() || !dc.valid ) { if( psx_host_alloc_near( device, c, &p ) != PSX_OK ) return nullptr; return p; }
+        const int dev = device;
+        const cpu_set_t* set = &dc.set;
+        std::thread t( [&p, c, dev, set]{ (void)sched_setaffinity( 0, sizeof(cpu_set_t), set ); if( psx_host_alloc_near( dev, c, &p ) != PSX_OK ) p = nullptr; } );
         t.join();
         return p;
     }
@@ -131,13 +148,10 @@ struct Pool
         if( bytes == 0 ) bytes = 1;
         {
             std::lock_guard<std::mutex> g( m );
-            int best = -1;
-            for( size_t i = 0; i < free_list.size(); i++ )
-                if( free_list[i].second >= bytes && free_list[i].second <= 4 * bytes + ( 4u << 20 ) &&
-                    ( best < 0 || free_list[i].second < free_list[best].second ) ) best = (int)i;
-            if( best >= 0 ) {
-                void* p = free_list[best].first; *cap = free_list[best].second;
-                free_list[best] = free_list.back(); free_list.pop_back();
+            auto it = free_list.lower_bound( bytes );
+            if( it != free_list.end() && it->first <= 4 * bytes + ( 4u << 20 ) ) {
+                void* p = it->second; *cap = it->first;
+                free_list.erase( it );
                 in_use += *cap; free_bytes -= *cap; st.hits++;
                 return p;
             }
@@ -157,10 +171,10 @@ struct Pool
         {
             std::lock_guard<std::mutex> g( m );
             in_use -= std::min( in_use, cap );
-            if( free_bytes + cap <= free_limit() ) { free_list.emplace_back( p, cap ); free_bytes += cap; return; }
+            if( free_bytes + cap <= free_limit() ) { free_list.emplace( cap, p ); free_bytes += cap; return; }
             st.frees++;
         }
-        if( pinned ) psx_host_free( p ); else free( p );      // only beyond the byte bound: never in a steady stream
+        if( pinned ) { forget_pinned( p ); psx_host_free( p ); } else free( p );      // only beyond the byte bound: never in a steady stream
     }
     Stats stats()
     {
@@ -188,11 +202,18 @@ struct Registry
     static int shard( void* p ) { return (int)( ( (uintptr_t)p >> 12 ) & 15 ); }
     void set( void* p, int dev ) { const int s = shard( p ); std::lock_guard<std::mutex> g( m[s] ); map[s][p] = dev; }
     int  get( void* p )          { const int s = shard( p ); std::lock_guard<std::mutex> g( m[s] ); auto it = map[s].find( p ); return it == map[s].end() ? -1 : it->second; }
+    void erase( void* p )        { const int s = shard( p ); std::lock_guard<std::mutex> g( m[s] ); map[s].erase( p ); }
 };
 Registry& registry() { static Registry* r = new Registry; return *r; }
+void forget_pinned( void* p ) { registry().erase( p ); }
 thread_local int t_device = -1;
 } // namespace
 
+bool  pin_thread_to_device_cpus( int device )
+{
+    DeviceCpus& dc = device_cpus( device );
+    return dc.valid && sched_setaffinity( 0, sizeof(cpu_set_t), &dc.set ) == 0;
+}
 void  set_thread_device( int device )         { t_device = device; }
 int   thread_device( )                        { return t_device; }
 void* get_plain( size_t bytes, size_t* cap )  { return plain().get( bytes, cap ); }

@@ -20,6 +20,9 @@ void  put_plain( void* p, size_t cap );
 /// PCIe root): get_pinned serves the calling thread's device (set_thread_device; -1 = the pool of no device),
 /// put_pinned returns a buffer to the pool it came from, whichever thread calls it.  A free list is bounded by bytes
 /// (POPSIFT_POOL_FREE_MB), so a steady stream never reaches hipHostFree / hipHostMalloc.
+/// Best effort: bind the calling thread to the CPUs local to the device's PCIe root (sysfs local_cpulist, read and
+/// parsed once per device; POPSIFT_NUMA_PIN=0 disables it).  false = affinity untouched.
+bool  pin_thread_to_device_cpus( int device );
 void  set_thread_device( int device );
 int   thread_device( );
 void* get_pinned( size_t bytes, size_t* cap );

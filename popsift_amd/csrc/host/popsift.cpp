@@ -457,31 +457,7 @@ namespace {
 // POPSIFT_NUMA_PIN=0 disables it.  Linux sysfs only; any failure leaves the affinity untouched.
 void pin_to_device_numa_node( int device )
 {
-    const char* e = getenv( "POPSIFT_NUMA_PIN" );
-    if( e != nullptr && e[0] == '0' ) return;
-    char bus[64];
-    if( psx_device_pci( device, bus, sizeof(bus) ) != PSX_OK || bus[0] == 0 ) return;
-    for( char* c = bus; *c; c++ ) *c = (char)tolower( *c );
-    const std::string path = std::string( "/sys/bus/pci/devices/" ) + bus + "/local_cpulist";
-    FILE* f = fopen( path.c_str(), "r" );
-    if( f == nullptr ) return;
-    char line[4096] = { 0 };
-    const bool got = fgets( line, sizeof(line), f ) != nullptr;
-    fclose( f );
-    if( !got ) return;
-    cpu_set_t allowed, want;
-    if( sched_getaffinity( 0, sizeof(allowed), &allowed ) != 0 ) return;
-    CPU_ZERO( &want );
-    int n = 0;
-    for( char* tok = strtok( line, ",\n" ); tok != nullptr; tok = strtok( nullptr, ",\n" ) ) {
-        int a = 0, b = 0;
-        const int k = sscanf( tok, "%d-%d", &a, &b );
-        if( k < 1 ) continue;
-        if( k == 1 ) b = a;
-        for( int c = a; c <= b && c < CPU_SETSIZE; c++ )
-            if( CPU_ISSET( c, &allowed ) ) { CPU_SET( c, &want ); n++; }
-    }
-    if( n > 0 ) sched_setaffinity( 0, sizeof(want), &want );
+    (void)popsift::pool::pin_thread_to_device_cpus( device );      // one reentrant parser, one sysfs read per device (host_pool.h)
 }
 } // namespace
 

@@ -79,16 +79,18 @@ def run_job(emu, ref, tabs, o, l0, nlev, tx, ty, nt, with_half):
 
 
 CASES = [
-    # (w, h, octaves, sift mode, tile rows, threads)
-    (200, 150, 3, po.MODE_POPSIFT, 64, 512),      # x2: octave 0 is 400 x 300 -> tiles 7 x 5, octaves of 200x150, 100x75
-    (163, 122, 3, po.MODE_VLFEAT, 32, 512),       # odd sizes: last tiles partly outside the plane, one-pixel columns
-    (96, 64, 2, po.MODE_OPENCV, 64, 1024),        # OpenCV spans (radius 6 runs on the radius-7 body)
-    (33, 21, 2, po.MODE_POPSIFT, 32, 1024),       # planes smaller than one tile's halo
+    # (w, h, octaves, sift mode, tile columns, tile rows, threads)
+    (200, 150, 3, po.MODE_POPSIFT, 64, 64, 512),      # x2: octave 0 is 400 x 300 -> tiles 7 x 5, octaves of 200x150, 100x75
+    (163, 122, 3, po.MODE_VLFEAT, 64, 32, 512),       # odd sizes: last tiles partly outside the plane, one-pixel columns
+    (96, 64, 2, po.MODE_OPENCV, 64, 64, 1024),        # OpenCV spans (radius 6 runs on the radius-7 body)
+    (33, 21, 2, po.MODE_POPSIFT, 64, 32, 1024),       # planes smaller than one tile's halo
+    (163, 122, 3, po.MODE_POPSIFT, 32, 32, 1024),     # the 32 x 32 tiles of the octaves that cannot fill the chip
+    (120, 90, 2, po.MODE_OPENCV, 32, 32, 512),
 ]
 
 
-@pytest.mark.parametrize("w,h,octaves,mode,ty,nt", CASES)
-def test_tile_phases_reproduce_the_oracle_planes(emu, w, h, octaves, mode, ty, nt):
+@pytest.mark.parametrize("w,h,octaves,mode,tx,ty,nt", CASES)
+def test_tile_phases_reproduce_the_oracle_planes(emu, w, h, octaves, mode, tx, ty, nt):
     cfg = po.default_config(octaves=octaves, sift_mode=mode)
     if mode == po.MODE_OPENCV:
         cfg.gauss_mode = po.GAUSS_OPENCV_COMPUTE
@@ -101,7 +103,7 @@ def test_tile_phases_reproduce_the_oracle_planes(emu, w, h, octaves, mode, ty, n
     for o in range(ref.num_octaves):
         # the two jobs of the default schedule: levels 1..L-3 (+ decimation), levels L-2..L-1
         for l0, n, half in ((1, D, True), (D + 1, L - 1 - D, False)):
-            bad, info = run_job(emu, ref, tabs, o, l0, n, 64, ty, nt, half)
+            bad, info = run_job(emu, ref, tabs, o, l0, n, tx, ty, nt, half)
             assert bad is not None, "plan rejected a default-config job: %s" % info
             assert bad == 0, "octave %d levels %d..%d: %d pixels differ (plan %s)" % (o, l0, l0 + n - 1, bad, info)
             ran += 1
