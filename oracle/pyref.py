@@ -12,7 +12,8 @@ import numpy as np
 from . import pyoracle as po
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(_HERE, "_ref", "libpopsift_ref.so")
+# OSIFT_REF_LIB: a variant build (make -C oracle ref_nofma / ref_model)
+SO = os.environ.get("OSIFT_REF_LIB") or os.path.join(_HERE, "_ref", "libpopsift_ref.so")
 _LIB = None
 
 

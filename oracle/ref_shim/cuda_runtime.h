@@ -236,24 +236,36 @@ template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; 
 static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 
+// -DOSIFT_CUDA_MODEL (make -C oracle ref_model; device translation units only): every stand-in below moves its correctly
+// rounded result by an error inside the bound the CUDA Programming Guide documents for the function it stands for
+// (oracle/cuda_model.h, selected at run time by the environment variable OSIFT_CUDA_MODEL); without the define the CM_* macros are
+// the plain operations
+#include "../cuda_model.h"
 // glibc's <math.h> declares __expf / __sincosf as its own internal entry points: rename ours
-static inline float shim_expf_(float x) { return expf(x); }
+static inline float shim_expf_(float x) { return CM_FAST_EXPF(x); }
 // evaluated in double and rounded once: the grid descriptor's pixel snapping (s_desc_grid.cu:72-78) flips on the last
 // bit of sin / cos, so the stand-in must not depend on libm's float sinf / cosf rounding (oracle/sift_oracle.c does the same)
-static inline void shim_sincosf_(float a, float* s, float* c) { *s = (float)sin((double)a); *c = (float)cos((double)a); }
+static inline void shim_sincosf_(float a, float* s, float* c) { *s = CM_FAST_SIN((float)sin((double)a)); *c = CM_FAST_COS((float)cos((double)a)); }
 #define __expf shim_expf_
 #define __sincosf shim_sincosf_
 // CUDA's atan2f (<= 2 ulp, unspecified beyond that) picks the orientation-histogram bin through
 // roundf(36 (theta + pi) / 2 pi) (s_orientation.cu:148-151): on exactly diagonal gradients (binary images, symmetric
 // patterns) the bin hangs on theta's last ulp.  The stand-in is the correctly rounded value -- atan2 in double,
 // rounded once -- which the oracle and the HIP kernel use too, so that all three sides take the same bin.
-static inline float shim_atan2f_(float y, float x) { return (float)atan2((double)y, (double)x); }
+static inline float shim_atan2f_(float y, float x) { return CM_ATAN2F((float)atan2((double)y, (double)x)); }
 #define atan2f shim_atan2f_
-static inline float __fdividef(float a, float b) { return a / b; }
+#ifdef OSIFT_CUDA_MODEL
+// device expf / hypotf (libdevice: 2 / 3 ulp); the standard build leaves them to libm
+static inline float shim_model_expf_(float x) { return CM_EXPF(x); }
+static inline float shim_model_hypotf_(float a, float b) { return CM_HYPOTF(a, b); }
+#define expf shim_model_expf_
+#define hypotf shim_model_hypotf_
+#endif
+static inline float __fdividef(float a, float b) { return CM_FDIVIDEF(a, b); }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float __fsqrt_rn(float a) { return sqrtf(a); }
 static inline float __fsqrt_rz(float a) { return sqrtf(a); }
-static inline float __frsqrt_rn(float a) { return 1.0f / sqrtf(a); }
+static inline float __frsqrt_rn(float a) { return CM_FRSQRT_RN(a); }
 static __attribute__((noinline)) float __fmul_ru(float a, float b)
 {
     volatile float va = a, vb = b;

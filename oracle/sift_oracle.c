@@ -22,6 +22,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <xmmintrin.h>
+#include "cuda_model.h"     /* -DOSIFT_CUDA_MODEL: sensitivity builds; otherwise every CM_* macro is the plain operation */
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -1078,7 +1079,7 @@ static inline float rdata(const float* plane, int W, int H, int x, int y)
  * value in the last ulp for some arguments -- how many orientation bins hang on that ulp is measured, not defined away */
 static inline float atan2f_1r(float y, float x) { return atan2f(y, x); }
 #else
-static inline float atan2f_1r(float y, float x) { return (float)atan2((double)y, (double)x); }
+static inline float atan2f_1r(float y, float x) { return CM_ATAN2F((float)atan2((double)y, (double)x)); }
 #endif
 
 /* s_gradiant.h:56-69 (texture variant) */
@@ -1086,7 +1087,7 @@ static inline void get_gradiant(float* grad, float* theta, int x, int y, const f
 {
     float dx = rdata(plane, W, H, x + 1, y) - rdata(plane, W, H, x - 1, y);
     float dy = rdata(plane, W, H, x, y + 1) - rdata(plane, W, H, x, y - 1);
-    *grad  = hypotf(dx, dy);
+    *grad  = CM_HYPOTF(dx, dy);
     *theta = atan2f_1r(dy, dx);
 }
 
@@ -1135,7 +1136,7 @@ static void orientation_one(const osift_result* r, int o, const osift_iext* iext
 
     const float sigw = ORI_WINFACTOR * sig;
     const int   rad  = (int)roundf((3.0f * sigw));
-    const float factor = -0.5f / (sigw * sigw);          /* __fdividef */
+    const float factor = CM_FDIVIDEF(-0.5f, (sigw * sigw));   /* __fdividef */
     const int   sq_thres = rad * rad;
 
     int xmin = imax(1,     (int)roundf(x) - rad);
@@ -1156,8 +1157,8 @@ static void orientation_one(const osift_result* r, int o, const osift_iext* iext
         float dy = yy - y;
         int sq_dist = (int)(dx * dx + dy * dy);
         if (sq_dist <= sq_thres) {
-            float weight = grad * expf(sq_dist * factor);
-            int bidx = (int)roundf((float)ORI_NBINS * (theta + PI_F) / PI2_F);
+            float weight = grad * CM_EXPF(sq_dist * factor);
+            int bidx = (int)roundf(CM_FDIVIDEF((float)ORI_NBINS * (theta + PI_F), PI2_F));   /* __fdividef, s_orientation.cu:148 */
             bidx = (bidx == ORI_NBINS) ? 0 : bidx;
             hist[bidx] += weight;   /* reference: shared-memory float atomicAdd, order unspecified */
         }
@@ -1191,7 +1192,7 @@ static void orientation_one(const osift_result* r, int o, const osift_iext* iext
                 denB = 2.0f * (sm_hist[prev] - 2.0f * sm_hist[bin] + sm_hist[next]);
             }
         }
-        const float newbin = num / denB;                 /* __fdividef */
+        const float newbin = CM_FDIVIDEF(num, denB);         /* __fdividef */
         predicate = (predicate && newbin >= 0.0f && newbin <= 2.0f);
         refined_angle[bin] = predicate ? prev + newbin : -1;
         yval[bin] = predicate ? -(num * num) / (4.0f * denB) + sm_hist[prev] : -INFINITY;
@@ -1274,8 +1275,8 @@ static void descriptor_one(const osift_result* r, const osift_ext* ext, float an
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (SBP == 0) return;
 
-    const float cos_t = cosf(ang);      /* __sincosf */
-    const float sin_t = sinf(ang);
+    const float cos_t = CM_FAST_COS(cosf(ang));      /* __sincosf */
+    const float sin_t = CM_FAST_SIN(sinf(ang));
     const float csbp  = cos_t * SBP;
     const float ssbp  = sin_t * SBP;
     const float crsbp = cos_t / SBP;
@@ -1312,7 +1313,7 @@ static void descriptor_one(const osift_result* r, const osift_ext* ext, float an
                 float mod, th;
                 get_gradiant(&mod, &th, jj, ii, plane, width, height);
                 const float dnx = nx + offx, dny = ny + offy;
-                const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3));   /* __expf */
+                const float ww = CM_FAST_EXPF(-scalbnf(dnx * dnx + dny * dny, -3));   /* __expf */
                 const float wx_ = 1.0f - nnx, wy_ = 1.0f - nny;
                 const float wgt = ww * wx_ * wy_ * mod;
                 th -= ang;
@@ -1355,7 +1356,7 @@ static void normalize_desc(const osift_config* c, float* d)
     if (c->norm_mode == OSIFT_NORM_ROOTSIFT) {
         for (int l = 0; l < 32; l++) lane[l] = d[4 * l] + d[4 * l + 1] + d[4 * l + 2] + d[4 * l + 3];
         const float sum = warp_sum32(lane);
-        for (int i = 0; i < 128; i++) d[i] = scalbnf(sqrtf(d[i] / sum), c->norm_multi);
+        for (int i = 0; i < 128; i++) d[i] = scalbnf(sqrtf(CM_FDIVIDEF(d[i], sum)), c->norm_multi);   /* __fsqrt_rn(__fdividef) */
     } else {
         for (int l = 0; l < 32; l++)
             lane[l] = d[4 * l] * d[4 * l] + d[4 * l + 1] * d[4 * l + 1]
@@ -1366,7 +1367,7 @@ static void normalize_desc(const osift_config* c, float* d)
             lane[l] = d[4 * l] * d[4 * l] + d[4 * l + 1] * d[4 * l + 1]
                     + d[4 * l + 2] * d[4 * l + 2] + d[4 * l + 3] * d[4 * l + 3];
         norm = warp_sum32(lane);
-        norm = 1.0f / sqrtf(norm);           /* __frsqrt_rn */
+        norm = CM_FRSQRT_RN(norm);           /* __frsqrt_rn */
         norm = scalbnf(norm, c->norm_multi);
         for (int i = 0; i < 128; i++) d[i] = d[i] * norm;
     }
@@ -1383,7 +1384,7 @@ static inline void get_gradiant_rot(float* grad, float* theta, float x, float y,
 {
     const float dx = plane_linear(plane, W, H, x + cos_t, y + sin_t) - plane_linear(plane, W, H, x - cos_t, y - sin_t);
     const float dy = plane_linear(plane, W, H, x - sin_t, y + cos_t) - plane_linear(plane, W, H, x + sin_t, y - cos_t);
-    *grad = hypotf(dx, dy);
+    *grad = CM_HYPOTF(dx, dy);
     *theta = atan2f_1r(dy, dx);
 }
 
@@ -1393,7 +1394,7 @@ static inline void get_gradiant_pt(float* grad, float* theta, int x, int y, cons
 {
     const float dx = rdata(plane, W, H, x + 1, y) - rdata(plane, W, H, x - 1, y);
     const float dy = rdata(plane, W, H, x, y + 1) - rdata(plane, W, H, x, y - 1);
-    *grad = hypotf(dx, dy);
+    *grad = CM_HYPOTF(dx, dy);
     *theta = atan2f_1r(dy, dx);
 }
 
@@ -1421,7 +1422,7 @@ static void descriptor_iloop(const osift_result* r, const osift_ext* ext, float 
     const float* plane = r->data[o] + (size_t)clampi(ext->lpos, 0, r->L - 1) * W * H;
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (SBP == 0) return;
-    const float cos_t = cosf(ang), sin_t = sinf(ang);          /* __sincosf */
+    const float cos_t = CM_FAST_COS(cosf(ang)), sin_t = CM_FAST_SIN(sinf(ang));          /* __sincosf */
     const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
     for (int iy = 0; iy < 4; iy++)
     for (int ix = 0; ix < 4; ix++) {
@@ -1445,7 +1446,7 @@ static void descriptor_iloop(const osift_result* r, const osift_ext* ext, float 
                 float mod, th;
                 get_gradiant_rot(&mod, &th, jj, ii, cos_t, sin_t, plane, W, H);
                 const float dnx = nx + offx, dny = ny + offy;
-                const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3));   /* __expf */
+                const float ww = CM_FAST_EXPF(-scalbnf(dnx * dnx + dny * dny, -3));   /* __expf */
                 const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod;
                 th += (th <  0.0f  ? PI2_F : 0.0f);
                 th -= (th >= PI2_F ? PI2_F : 0.0f);
@@ -1475,7 +1476,7 @@ static void descriptor_grid(const osift_result* r, const osift_ext* ext, float a
      * which flips to the neighbouring pixel on the last bit of pt, i.e. of sin / cos: all three sides (this file, the
      * HIP kernel, the shim's __sincosf stand-in) therefore evaluate them in double and round ONCE, so that equal
      * orientation bits give equal sample positions. */
-    const float cos_t = (float)cos((double)ang), sin_t = (float)sin((double)ang);
+    const float cos_t = CM_FAST_COS((float)cos((double)ang)), sin_t = CM_FAST_SIN((float)sin((double)ang));
     const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
     for (int iy = 0; iy < 4; iy++)
     for (int ix = 0; ix < 4; ix++) {
@@ -1502,7 +1503,7 @@ static void descriptor_grid(const osift_result* r, const osift_ext* ext, float a
             const float npx = fmaf(cos_t, pox,  sin_t * poy);
             const float npy = fmaf(cos_t, poy, -sin_t * pox);
             const float dnx = npx + offx, dny = npy + offy;
-            const float ww = expf(-scalbnf(dnx * dnx + dny * dny, -3));
+            const float ww = CM_EXPF(-scalbnf(dnx * dnx + dny * dny, -3));    /* expf, s_desc_grid.cu:82 */
             const float wx = 1.0f - fabsf(npx), wy = 1.0f - fabsf(npy);
             if (wx < 0.0f || wy < 0.0f) continue;
             const float wgt = ww * wx * wy * mod;
@@ -1567,7 +1568,7 @@ static void descriptor_igrid(const osift_result* r, const osift_ext* ext, float 
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (ext->sigma == 0) return;
     const float SBP = fabsf(DESC_MAGNIFY * ext->sigma);
-    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    const float cos_t = CM_FAST_COS(cosf(ang)), sin_t = CM_FAST_SIN(sinf(ang));
     init_desc_tables();
     for (int iy = 0; iy < 4; iy++)
     for (int ix = 0; ix < 4; ix++) {
@@ -1618,7 +1619,7 @@ static void descriptor_notile(const osift_result* r, const osift_ext* ext, float
     for (int i = 0; i < 128; i++) features[i] = 0.0f;
     if (ext->sigma == 0) return;
     const float SBP = fabsf(DESC_MAGNIFY * ext->sigma);
-    const float cos_t = cosf(ang), sin_t = sinf(ang);
+    const float cos_t = CM_FAST_COS(cosf(ang)), sin_t = CM_FAST_SIN(sinf(ang));
     const float stepbase = -2.5f + 1.0f / 16.0f;
     init_desc_tables();
     for (int out_y = 0; out_y < 4; out_y++) {

@@ -154,6 +154,12 @@ struct psx_ctx {
     psx_feature* fx_host_feat = nullptr; float* fx_host_desc = nullptr;
     bool fx_on = false;
 
+    // MEASUREMENT switch PSX_NULL_DEVICE_WORK (bench.py host_ceiling): 1 = after a context's first frame psx_extract launches
+    // nothing -- uploads, the counter read-back and the result downloads still run, on the first frame's results (same
+    // counts, same bytes): what the HOST path and PCIe sustain without the kernels; 2 = the DMAs are skipped as well: the
+    // host software alone (threads, queues, pools, the per-keypoint record loop).  Results are stale by construction.
+    int  null_work = 0;
+    bool null_primed = false;
     bool timers = false;
     bool blocking_wait = false;        // psx_set_wait_mode: sleep on an event instead of spinning in hipStreamSynchronize
     hipEvent_t ev_wait = nullptr;
@@ -610,6 +616,7 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     // (single frame 0.63 vs 0.63 ms, throughput equal): kernel-to-kernel dependencies cost the same either way
     { const char* g = getenv("POPSIFT_HIP_GRAPH"); n->graph_off = !(g != nullptr && g[0] == '1'); }
     { const char* g = getenv("POPSIFT_BATCH_OCTAVES"); n->batch_octaves = !(g != nullptr && g[0] == '0'); }
+    { const char* g = getenv("PSX_NULL_DEVICE_WORK"); if (g != nullptr && (g[0] == '1' || g[0] == '2')) n->null_work = g[0] - '0'; }
     { const char* g = getenv("POPSIFT_TILE"); if (g != nullptr && (g[0] == '0' || g[0] == '1')) n->tile_mode = g[0] - '0'; }
     { const char* g = getenv("POPSIFT_TILE_TY"); if (g != nullptr) { const int v = atoi(g); if (v >= 8 && v <= 128 && (v & 3) == 0) n->tile_ty = v; } }
     { const char* g = getenv("POPSIFT_TILE_NT"); if (g != nullptr) { const int v = atoi(g); if (v == 512 || v == 1024) n->tile_nt = v; } }
@@ -868,7 +875,8 @@ static int upload_common(psx_ctx* ctx, const void* host, int w, int h, int is_fl
     }
     // DMA engine, not a kernel: a copy kernel that reads the mapped host image over PCIe itself was measured
     // (GPU-initiated reads are slow: +0.8 ms per frame in flight, -8 % end-to-end throughput)
-    PSX_HIP(hipMemcpyAsync(ctx->d_input_own, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!(ctx->null_work == 2 && ctx->null_primed))        // PSX_NULL_DEVICE_WORK=2: host software only, no DMA
+        PSX_HIP(hipMemcpyAsync(ctx->d_input_own, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (src == ctx->h_stage) PSX_HIP(hipEventRecord(ctx->ev_upload, ctx->stream));
     ctx->d_input = ctx->d_input_own;
     ctx->input_is_float = is_float;
@@ -1234,6 +1242,14 @@ int psx_extract(psx_ctx* ctx)
 {
     if (!ctx) return PSX_ERR_INVALID;
     if (!ctx->d_input || !ctx->d_pyr) return fail(ctx, PSX_ERR_STATE, "psx_extract: no input image");
+    if (ctx->null_work != 0) {
+        if (ctx->null_primed) {                    // measurement: no kernels; the first frame's results stand in
+            if (ctx->null_work == 1) ctx->counts_valid = false;      // mode 1 reads the counters back per frame, like a real frame
+            snapshot_export(ctx);
+            return PSX_OK;
+        }
+        ctx->null_primed = true;
+    }
     // Optionally replay the 36-launch chain as one hipGraph (POPSIFT_HIP_GRAPH=1).  Not with the grid filter
     // (it reads counters on the host in mid-chain) and not with the per-stage timers.
     const bool use_graph = !ctx->graph_off && !ctx->timers && !ctx->blur_probe && ctx->cfg.filter_max_extrema <= 0;
@@ -1372,6 +1388,9 @@ int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity, floa
     if (no > 0 && !descriptors) return fail(ctx, PSX_ERR_INVALID, "psx_download: null descriptor buffer");
     const bool feat_exported = (ctx->fx_on && features == ctx->fx_host_feat && ne <= ctx->fx.feat_capacity);
     const bool desc_exported = (ctx->fx_on && descriptors == ctx->fx_host_desc && no <= ctx->fx.desc_capacity);
+    static bool null_dl_done = false;      // PSX_NULL_DEVICE_WORK=2: one real download per process keeps the records well formed
+    if (ctx->null_work == 2 && ctx->null_primed && null_dl_done) return PSX_OK;
+    if (ctx->null_work == 2 && ctx->null_primed) null_dl_done = true;
     if (ne > 0 && !feat_exported)
         PSX_HIP(hipMemcpyAsync(features, ctx->d_features, (size_t)ne * sizeof(psx_feature),
                                hipMemcpyDeviceToHost, ctx->stream));
