@@ -99,6 +99,15 @@ def algorithmic_bytes(w, h, octaves, levels=3, input_bytes_per_px=1):
     return stage, pipe
 
 
+def kernel_sources_sha1():
+    """SHA-1 over the sources of the roofline kernel (k_blur): what profiles/pmc_summary.json must have been collected from."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("pyramid.hip", "blur_arith.h"):
+        h.update(open(os.path.join(ROOT, "popsift_amd", "csrc", "hip", f), "rb").read())
+    return h.hexdigest()
+
+
 def read_sclk_mhz(device=0):
     """Current shader clock from sysfs: the line marked '*' in pp_dpm_sclk.  The card index of the visible device is
     not known inside the container (the box exposes every card's sysfs node), so this returns the HIGHEST current
@@ -557,11 +566,97 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of 4 timed frames")
     ap.add_argument("--no-extras", action="store_true", help="only the three timed legs")
+    ap.add_argument("--no-host-ceiling", action="store_true", help="skip the host_ceiling leg (it starts 9 helper processes)")
+    ap.add_argument("--extras", action="store_true",
+                    help="also the slow informational legs (every alternative Gauss / descriptor mode, BASELINE config 3, the full host-ceiling sweep)")
     return ap.parse_args(argv)
 
 
 def main():
     run(parse_args())
+
+
+# homography of the BASELINE config 5 stand-in (tests/test_gpu_configs.py::test_config5_warped_pair_opencv_mode uses the same pair)
+_H5 = [[0.891, -0.125, 60.0], [0.125, 0.891, -20.0], [4.0e-5, -2.0e-5, 1.0]]
+
+
+def config5_leg(capi, np, device):
+    """BASELINE config 5 (Oxford boat / graffiti, OpenCV-mode Config; testScripts/testOxfordDataset.sh.in:48 is the
+    reference's protocol).  The dataset cannot be fetched here (no network; it is not in the reference tree either), so
+    the leg runs the protocol on a stand-in pair: a synthetic 800x600 frame and its copy under a known homography,
+    setMode(OpenCV) + setGaussMode(opencv).  Reported as SURVEY.md 8d asks: descriptor parity of both images against
+    the oracle (the checker, outside any timed region), repeatability of the HIP keypoints under the homography next to
+    the oracle's, and the MatchingMode matcher's inlier rate."""
+    try:
+        from oracle import pyoracle as po
+        from popsift_amd.synth import synth, warp_homography
+        from tests.parity import match_features, repeatability
+        w, h = 800, 600
+        Hm = np.array(_H5)
+        a = synth(w, h, 515)
+        b = warp_homography(a, Hm)
+        kw = dict(octaves=5, sift_mode=1, gauss_mode=3)
+        out, par = [], {"keypoints": 0, "descriptors": 0, "kp_miss": 0, "ori_miss": 0, "desc_miss": 0, "max_desc_dist": 0.0}
+        ms = []
+        for img in (a, b):
+            ctx = capi.Context(capi.default_config(**kw), device=device)
+            ctx.upload(img)
+            ctx.extract(); ctx.counts()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ctx.extract(); ctx.counts()
+            ms.append((time.perf_counter() - t1) / 5 * 1e3)
+            fb, db = ctx.download()
+            ctx.close()
+            ref = po.run(po.default_config(**kw), img)
+            fa, da = ref.features(), ref.descriptors()
+            m = match_features(fa, da, fb, db)
+            par["keypoints"] += len(fa); par["descriptors"] += len(da)
+            par["kp_miss"] += m["kp_miss"] + abs(len(fa) - len(fb)); par["ori_miss"] += m["ori_miss"]; par["desc_miss"] += m["desc_miss"]
+            par["max_desc_dist"] = round(max(par["max_desc_dist"], m["max_desc_dist"]), 6)
+            out.append((fa, fb, db))
+            ref.close()
+        (ra, fa, da), (rb, fb, db) = out
+        rep_hip, n_in = repeatability(fa, fb, Hm, w, h)
+        rep_ref, _ = repeatability(ra, rb, Hm, w, h)
+        xa = np.zeros((len(da), 2)); xb = np.zeros((len(db), 2))
+        for f, x in ((fa, xa), (fb, xb)):
+            for k in range(4):
+                sel = f["num_ori"] > k
+                x[f["desc_idx"][sel, k]] = np.stack([f["xpos"][sel], f["ypos"][sel]], 1)
+        mm, _ = capi.match(da, db, device=device)
+        acc = mm[:, 2] == 1
+        p = np.concatenate([xa[acc], np.ones((int(acc.sum()), 1))], 1) @ Hm.T
+        err = np.linalg.norm(p[:, :2] / p[:, 2:3] - xb[mm[acc, 0]], axis=1)
+        return {"images": "stand-in for the Oxford pair (not obtainable here): synth(800, 600, seed 515) and its warp under a known homography",
+                "config": "setMode(OpenCV), setGaussMode(opencv), octaves=5", "parity_vs_oracle": par,
+                "repeatability_hip": round(rep_hip, 4), "repeatability_oracle": round(rep_ref, 4), "keypoints_inside": n_in,
+                "matcher_accepted": int(acc.sum()), "matcher_inliers_2px": round(float((err < 2.0).mean()), 4),
+                "ms_per_image": [round(v, 4) for v in ms]}
+    except Exception as e:                                   # never lose the headline to an extra
+        return "failed: %s" % e
+
+
+def match_leg(capi, np, device):
+    """MatchingMode's brute-force 2-NN matcher (match.hip) on two descriptor sets of the bench frame's size: G pairs / s and
+    the fraction of the VALU issue peak its operation tree needs (165 lane-instructions per pair: 64 packed differences,
+    64 packed multiply / fma, 31 adds of the reference's reduction tree, the top-2 insert; peak = 256 CUs x 4 SIMDs x 16 lanes
+    per clock x 2.4 GHz)."""
+    try:
+        rng = np.random.default_rng(5)
+        n = 18432
+        l = rng.random((n, 128), dtype=np.float32); r = rng.random((n, 128), dtype=np.float32)
+        capi.match(l[:2048], r[:2048], device=device)
+        t1 = time.perf_counter()
+        capi.match(l, r, device=device)
+        dt = time.perf_counter() - t1
+        gp = n * n / dt / 1e9
+        return {"left": n, "right": n, "seconds_incl_transfers": round(dt, 4), "gpairs_per_s": round(gp, 1),
+                "frac_of_valu_issue_peak": round(gp * 1e9 * 165 / (256 * 4 * 16 * 2.4e9), 4),
+                "what": "capi.match (psx_match: upload both sets, k_match_permute + k_match_partial + k_match_merge, download); bit-identical "
+                        "indices / distances to the reference's scan (tests/test_gpu_parity.py::test_match_bit_exact)"}
+    except Exception as e:
+        return "failed: %s" % e
 
 
 def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
@@ -596,9 +691,16 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         c0.time_blur(0, lvl, 3)
         iso.append(c0.time_blur(0, lvl, 30)[0])
     copy_gbs, copy_ms = capi.copy_bench(device, 1 << 30, 10)
-    traffic = None
+    # roofline.traffic comes from a committed PMC pass (tools/collect_profiles.sh -> profiles/pmc_summary.json), which also
+    # records the SHA-1 of the kernel's sources at collection time: when they have changed since, the number is STALE and
+    # is not reported (null + traffic_stale) -- re-run tools/collect_profiles.sh in the commit that changes the kernel
+    traffic, traffic_stale, traffic_src = None, None, None
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["k_blur_octave0_hbm_bytes_per_launch"]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        traffic_src = pm.get("source")
+        traffic_stale = pm.get("kernel_sources_sha1") != kernel_sources_sha1()
+        if not traffic_stale:
+            traffic = pm["k_blur_octave0_hbm_bytes_per_launch"]
     except Exception:
         pass
     ex["roofline"] = {
@@ -607,8 +709,10 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "avg_launch_ms": round(avg_ms, 5), "per_level_ms": [round(m, 5) for m in per_level],
         "bytes_per_launch": by, "traffic": traffic,
-        "traffic_source": "profiles/pmc_summary.json: a committed rocprofv3 --pmc pass of an earlier builder run (FETCH_SIZE x 2 + WRITE_SIZE, "
-                          "MI355X_MICROARCH.md HBM section), NOT measured in this run",
+        "traffic_stale": traffic_stale,
+        "traffic_source": "profiles/pmc_summary.json (%s): a committed rocprofv3 --pmc pass of THIS kernel source (SHA-1 of pyramid.hip + "
+                          "blur_arith.h checked; stale passes are reported as null), FETCH_SIZE x 2 + WRITE_SIZE per "
+                          "MI355X_MICROARCH.md's HBM section; not measured in this run" % traffic_src,
         "measured_copy": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
         "measured_copy_what": "hand-written 16 B/lane copy kernel, 1 GiB read + 1 GiB written (psx_copy_bench)",
         "isolated_replay_avg_ms": round(sum(iso) / len(iso), 5),
@@ -646,8 +750,26 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
                                "what": "algorithmic bytes of the whole pyramid build (SURVEY.md 8d: 44 N0 + 48 sum N_o + input) / "
                                        "pyramid stage time of one frame on one context (HIP events around psx_build_pyramid)"}
 
-    # ---- every alternative Gauss / scaling / descriptor mode once: single-frame wall time, one context ----
+    # ---- BASELINE config 5 stand-in and the matcher (always on; a few seconds) ----
+    ex["config5"] = config5_leg(capi, np, device)
+    ex["match"] = match_leg(capi, np, device)
+
+    # ---- the host side without the kernels: what bends the 1 -> 8 GPU curve (tools/host_ceiling.py) ----
+    if world == 1 and not getattr(args, "no_host_ceiling", False):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import host_ceiling
+            if args.extras:
+                ex["host_ceiling"] = host_ceiling.measure(seconds=1.5, procs=(1, 2, 4, 8), modes=(1, 2))
+            else:
+                ex["host_ceiling"] = host_ceiling.measure(seconds=1.0, configs=[(2, 8), (1, 1)])
+        except Exception as e:
+            ex["host_ceiling"] = "failed: %s" % e
+
+    # ---- every alternative Gauss / scaling / descriptor mode once: single-frame wall time, one context (--extras) ----
     try:
+        if not args.extras:
+            raise RuntimeError("skipped: informational leg, run with --extras (profiles/ holds the last full line)")
         alt = {}
         for name, kw in (("gauss_relative", dict(gauss_mode=1)), ("gauss_relative_all", dict(gauss_mode=2)),
                          ("gauss_opencv", dict(gauss_mode=3)), ("gauss_fixed9", dict(gauss_mode=4)),
@@ -667,10 +789,12 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         alt["default"] = round(single_ms, 4)
         ex["alt_modes_ms"] = alt
     except Exception as e:
-        ex["alt_modes_ms"] = "failed: %s" % e
+        ex["alt_modes_ms"] = str(e) if str(e).startswith("skipped") else "failed: %s" % e
 
-    # ---- BASELINE config 3: 4096x4096, 6 octaves (octave 0 = 8192x8192), one context, device resident ----
+    # ---- BASELINE config 3: 4096x4096, 6 octaves (octave 0 = 8192x8192), one context, device resident (--extras) ----
     try:
+        if not args.extras:
+            raise RuntimeError("skipped: informational leg, run with --extras (profiles/ holds the last full line)")
         from popsift_amd.synth import synth
         big = torch.from_numpy(np.ascontiguousarray(np.tile(frames_np[0], (4, 3))[:4096, :4096])).to(frames[0].device)
         c3 = capi.Context(capi.default_config(octaves=6, sift_mode=HEADLINE_KW.get("sift_mode", 0)), device=device)
@@ -703,7 +827,7 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         c3.close()
         del big
     except Exception as e:                                   # never lose the headline to an extra
-        ex["config3"] = "failed: %s" % e
+        ex["config3"] = str(e) if str(e).startswith("skipped") else "failed: %s" % e
 
     # ---- CPU baseline (bounded sample) ----
     if world == 1 and not args.no_cpu_baseline:

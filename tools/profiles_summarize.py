@@ -23,7 +23,9 @@ def by_grid(path, dst, header):
             f.write("%-28s wgs=%6d calls=%4d avg=%9.2f min=%9.2f max=%9.2f\n" % (k, w, len(v), sum(v) / len(v), min(v), max(v)))
 
 
-by_grid(bench_trace, out + "/bench_kernel_by_grid.txt",
+import os as _os
+if _os.path.exists(bench_trace):
+  by_grid(bench_trace, out + "/bench_kernel_by_grid.txt",
         "# rocprofv3 --kernel-trace, per (kernel, workgroups): calls avg_us min_us max_us\n"
         "# command: python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (contexts in flight overlap: durations include co-running kernels)\n")
 by_grid(single_trace, out + "/single_kernel_by_grid.txt",
@@ -54,6 +56,13 @@ with open(out + "/pmc_hbm_traffic.txt", "w") as f:
     for r in rows:
         f.write("%-28s %6d %14.0f %14.0f %16.0f\n" % r)
 blur0 = [r[4] for r in rows if r[0].startswith("k_blur") and ", false," in r[0] and r[1] >= 900]
+import hashlib
+import os
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha1()
+for _f in ("pyramid.hip", "blur_arith.h"):
+    _h.update(open(os.path.join(_root, "popsift_amd", "csrc", "hip", _f), "rb").read())
 json.dump({"k_blur_octave0_hbm_bytes_per_launch": sum(blur0) / max(1, len(blur0)), "n_launch_kinds": len(blur0),
-           "source": "profiles/r04_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2xFETCH correction)"},
+           "kernel_sources_sha1": _h.hexdigest(),        # bench.py reports the traffic only while the kernel's sources still hash to this
+           "source": "pmc_hbm_traffic.txt of the same tools/collect_profiles.sh run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2xFETCH correction)"},
           open(out + "/pmc_summary.json", "w"), indent=1)
