@@ -648,7 +648,14 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
     // used prefix of it
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_cnt), CNT_BLOCK + FLOW_MAX_BYTES + CAND_CT_BYTES));
     n->d_cand_ct = reinterpret_cast<int*>(reinterpret_cast<char*>(n->d_cnt) + CNT_BLOCK);
-    { const char* g = getenv("POPSIFT_FLOW"); if (g != nullptr && g[0] >= '0' && g[0] <= '2') n->flow_mode = g[0] - '0'; }
+    {
+        const char* g = getenv("POPSIFT_FLOW");
+        if (g != nullptr && g[0] >= '0' && g[0] <= '2' && g[1] == 0) n->flow_mode = g[0] - '0';
+        else if (g != nullptr && g[0] != 0) {          // a mislabelled A/B run is worse than no run
+            psx_destroy(n);
+            return fail(nullptr, PSX_ERR_INVALID, std::string("POPSIFT_FLOW=") + g + ": valid values are 0 (one launch per level), 1 (every level in one launch), 2 (octave 0 by launches)");
+        }
+    }
     { const char* g = getenv("POPSIFT_FLOW_LD"); if (g != nullptr && (g[0] == '1' || g[0] == '2')) n->flow_ld = g[0] - '0'; }
     { const char* g = getenv("POPSIFT_FLOW_ORDER"); if (g != nullptr && g[0] >= '0' && g[0] <= '2') n->flow_order = g[0] - '0'; }
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_cnt), sizeof(PsxCounters), hipHostMallocDefault));

@@ -16,7 +16,7 @@
 //
 // The phase functions take the thread index as an argument and touch nothing but their arguments, so the SAME code
 // runs on the CPU, one "thread" after the other and one phase after the other (tests/cpp/tile_emu.cpp, built with
-// PSX_TILE_EMU; tests/test_tile_emu_cpu.py compares its planes with the oracle's bit for bit, without a GPU).
+// PSX_TILE_EMU; tests/test_tile_emu_cpu.py compares its planes with the CPU checker's bit for bit, without a GPU).
 #pragma once
 
 #include "blur_arith.h"

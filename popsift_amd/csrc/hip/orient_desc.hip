@@ -328,8 +328,10 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
         // EQUAL top bins, which the strict test would drop altogether -- the keypoint would get the orientation of some
         // minor peak.  In the reference's float accumulation (and the oracle's) rounding noise breaks such ties, one of the
         // two bins wins and the parabola puts the angle at their common boundary; the left bin of the pair with hn == hval
-        // gives exactly that (newbin = 1.5).  Bins that differ are treated as before.
-        bool predicate = isbin && hval > hp && hval >= hn;
+        // gives exactly that (newbin = 1.5).  Bins that differ are treated as before.  The tie counts only when the PAIR is a
+        // local maximum (the bin behind it is lower): an equal pair on an ascending shoulder (1, 2, 2, 3) is no peak.
+        const float hnn = from(next_a, hn);
+        bool predicate = isbin && hval > hp && (hval > hn || (hval == hn && hn > hnn));
         const float num  = predicate ? 3.0f * hp - 4.0f * hval + 1.0f * hn : 0.0f;
         const float denB = predicate ? 2.0f * (hp - 2.0f * hval + hn) : 1.0f;
         const float newbin = num / denB;

@@ -105,10 +105,12 @@ def test_product_does_not_reference_the_oracle():
     hdr = open(os.path.join(ROOT, "include", "popsift_hip.h")).read()
     assert "oracle" not in hdr
     assert not bad, bad
-    # bench.py: the oracle is imported in exactly two places -- the CPU baseline and the post-run parity check --
-    # and neither sits inside a timed leg (e2e_parity is a backend method called after timed(); extras() runs last)
+    # bench.py: the oracle is imported in exactly three places -- the CPU baseline, the post-run parity check and the
+    # config5 leg's checker -- and none sits inside a timed leg (e2e_parity is a backend method called after timed();
+    # config5_leg and extras() run last, outside every timed region)
     btxt = open(os.path.join(ROOT, "bench.py")).read()
-    assert btxt.count("from oracle import pyoracle") == 2
+    assert btxt.count("from oracle import pyoracle") == 3
+    assert "from oracle import pyoracle as po" in btxt.split("def config5_leg")[1].split("def match_leg")[0]
     assert "def e2e_parity" in btxt and "from oracle import pyoracle as po" in btxt.split("def e2e_parity")[1].split("def ")[0]
     timed_body = btxt.split("def timed(step, drain, probe=None):")[1].split("def reduce_sum_dict")[0]
     assert "oracle" not in timed_body and "parity" not in timed_body
