@@ -165,6 +165,45 @@ def match(left, right, device=0):
             L.psx_dev_free(device, p)
 
 
+class DeviceDescriptors:
+    """Descriptor sets resident on the device (what FeaturesDev holds, popsift.cpp:346-383): upload once, match many times."""
+
+    def __init__(self, arr, device=0):
+        L = lib()
+        L.psx_dev_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.psx_dev_free.argtypes = [C.c_int, C.c_void_p]
+        L.psx_dev_write.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, 128)
+        self.n, self.device, self.ptr = len(arr), device, C.c_void_p()
+        if self.n:
+            if L.psx_dev_alloc(device, arr.nbytes, C.byref(self.ptr)) != 0:
+                raise PopSiftError("psx_dev_alloc failed")
+            if L.psx_dev_write(device, self.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes) != 0:
+                raise PopSiftError("psx_dev_write failed")
+
+    def match(self, right):
+        """psx_match(self as left, right: DeviceDescriptors): (n,3) int32 and (n,2) float32 host arrays"""
+        L = lib()
+        L.psx_match.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        mm = np.zeros((self.n, 3), np.int32)
+        dd = np.zeros((self.n, 2), np.float32)
+        rc = L.psx_match(self.device, self.ptr, self.n, right.ptr, right.n, mm.ctypes.data_as(C.c_void_p), dd.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise PopSiftError("psx_match failed (%d)" % rc)
+        return mm, dd
+
+    def close(self):
+        if self.ptr:
+            lib().psx_dev_free(self.device, self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def gauss_tables(cfg):
     inc_f = (C.c_float * (GAUSS_LEVELS * GAUSS_ALIGN))()
     inc_sp = (C.c_int * GAUSS_LEVELS)()

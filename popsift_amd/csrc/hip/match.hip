@@ -5,10 +5,12 @@
 // with strict '<' (ties keep the earlier index), accept = d1 / d2 < 0.8.  The reference runs one
 // 32-thread block per left descriptor and walks the right side serially with a __syncthreads per pair.
 //
-// The distance is NOT reshaped into a GEMM (|a|^2 + |b|^2 - 2ab cancels catastrophically for near
-// matches, and the indices are integer output that has to agree with the reference): every pair is
-// evaluated with the reference's own operation tree, so the distances are bit-identical to
-// oracle/sift_oracle.c:
+// The RESULT is never taken from a GEMM form (|a|^2 + |b|^2 - 2ab cancels catastrophically for near
+// matches, and the indices are integer output that has to agree with the reference): every pair that can
+// matter is evaluated with the reference's own operation tree, so the distances are bit-identical to
+// oracle/sift_oracle.c.  Round 5: an f16-MFMA form of that expression with a PROVEN error margin only DISCARDS
+// pairs (k_match_mfma below); rounds 1-4 evaluated every pair exactly (k_match_partial, still the path for small
+// sets, for POPSIFT_MATCH_MFMA=0 and whenever the prefilter cannot bound its candidates).  The tree:
 //   lane t of the reference's warp: q = l[4t..4t+3] - r[4t..4t+3];  p_t = q.x*q.x + q.y*q.y + q.z*q.z + q.w*q.w
 //   (contracted left to right: fma(q.w,q.w, fma(q.z,q.z, fma(q.x,q.x, q.y*q.y))))
 //   then the shuffle_down tree 16, 8, 4, 2, 1:  a_i = p_i + p_{i+16}, b_i = a_i + a_{i+8}, ... (lane 0's value)
@@ -20,6 +22,11 @@
 // k_match_merge combines the per-chunk top-2 with the (distance, index) order that the sequential scan
 // of the reference produces.
 #include "psx_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 
 namespace {
 
@@ -120,6 +127,308 @@ __global__ void k_match_merge(const Top2* __restrict__ partial, int l_len, int n
     if (dist) { dist[2 * li + 0] = t.d1; dist[2 * li + 1] = t.d2; }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA prefilter (round 5).  The exact scan above costs 165 lane instructions per pair and runs at ~1/3 of the VALU issue
+// peak.  The RESULT must stay the reference's -- integer indices, bit-identical distances -- so nothing approximate may
+// decide anything; but an approximate distance with a PROVEN error bound can discard almost every pair:
+//   s(l, r) = |l|^2 + |r|^2 - 2 <f16(l), f16(r)>          (v_mfma_f32_32x32x16_f16, f32 accumulation)
+//   |s - d| <= E(l, r),   d = the reference's float distance of the pair:
+//       f16 keeps 11 significant bits (round to nearest even): an element >= 2^-14 in magnitude has relative error <= u = 2^-11,
+//       a smaller one absolute error <= 2^-25, so |<f16 l, f16 r> - <l, r>| <= 2.002 u |l| |r| + 2^-25 sqrt(128) (|l| + |r|)
+//       (Cauchy-Schwarz); the f32 accumulation of 128 exact products, the f32 norms and the rounding of the reference's own
+//       operation tree add <= 2e-5 (|l|^2 + |r|^2).  With Rmax = max |r|:
+//       E_l := 0.00197 |l| Rmax + 7e-7 (|l| + Rmax) + 4e-5 (|l|^2 + Rmax^2)  (bf16, 8 bits, had 0.0157: on random descriptors,
+//       whose distances concentrate, hundreds of neighbours fell inside the margin).  Elements beyond f16's range (65504)
+//       cannot occur below a squared norm of 4e9; above it the prefilter is not used (overflow flag -> exact scan).
+// If s2 is the second smallest s of a left descriptor, its true second-best distance is <= s2 + E_l (two pairs have
+// d <= s + E_l <= s2 + E_l), and every pair with d <= that has s <= s2 + 2 E_l.  So the set {r : s <= s2 + 2 E_l} contains
+// every pair that can be best or second best INCLUDING all ties, and the reference's scan restricted to it (same operation
+// tree, (distance, index) order) returns the reference's answer.  A running s2 (per half wave, per chunk of the right
+// side, started from a seeding pass over the first 2048 right descriptors) is >= the final one: the candidate set only
+// grows.  A lane appends its candidates to ITS segment of the left descriptor's list (no atomics); a segment that overflows
+// (thousands of near-equal neighbours: duplicates, constant descriptors) sends the whole call through the exact scan of
+// every pair.  k_match_exact evaluates the candidates in the reference's own 32-threads-per-pair shape, one wave per left
+// descriptor.  18 432 x 18 432 unit-norm descriptors: 26 candidates per left descriptor on average, 3.8 ms -> 0.34 ms of
+// kernel time (profiles/r05_match_prefilter.txt).
+// MFMA operand layout: only "lane l supplies row / column l & 31 and the k-slots of half l >> 5" is used -- the SAME 16
+// bytes of a descriptor go into the same operand slot on both sides, so whatever k the hardware assigns to a slot, the
+// products pair up (the sum over k is what matters); C/D: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MF_SEGS = 32;                  // candidate segments per left descriptor: one per (chunk of the right side, half wave) ...
+constexpr int MF_SEGCAP = 32;                // ... of this many slots: private to one lane of one workgroup, so appending needs no atomic
+constexpr int MF_CAP = MF_SEGS * MF_SEGCAP;  // (a returned global atomic per candidate made the scan wait ~1 us per tile and column set)
+constexpr int MF_TILE = 32;                  // right descriptors per MFMA tile
+constexpr int MF_ROW = 272;                  // bytes per staged right descriptor: 256 + 16 (rows 4 banks apart: conflict-free b128 reads)
+constexpr int MF_SEED = 2048;                // right descriptors of the seeding pass ...
+constexpr int MF_SEEDCH = 8;                 // ... in this many chunks (workgroups per 256 left descriptors)
+constexpr int MF_MAXSLOTS = 64;              // the largest squared norm of the right side is kept in 64 slots (same-address atomics serialise)
+
+__device__ __forceinline__ unsigned short to_f16(float f)
+{
+    const _Float16 h = (_Float16)f;                                                // v_cvt_f16_f32: round to nearest even
+    unsigned short b; __builtin_memcpy(&b, &h, 2);
+    return b;
+}
+
+// f16 copy + squared norm of every descriptor, and the largest squared norm (bits of a non-negative float, 64 slots)
+__global__ void k_match_prep(const float* __restrict__ src, int n, unsigned short* __restrict__ dst, float* __restrict__ norm2,
+                             unsigned* __restrict__ maxbits)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 elements, 32 threads per descriptor
+    const int d = g >> 5, q = g & 31;
+    float ss = 0.0f;
+    if (d < n) {
+        const float4 v = reinterpret_cast<const float4*>(src + (size_t)d * 128)[q];
+        ss = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+        ushort4 o; o.x = to_f16(v.x); o.y = to_f16(v.y); o.z = to_f16(v.z); o.w = to_f16(v.w);
+        reinterpret_cast<ushort4*>(dst + (size_t)d * 128)[q] = o;
+    }
+    for (int k = 16; k >= 1; k >>= 1) ss += __shfl_xor(ss, k, 32);
+    if (d < n && q == 0) norm2[d] = ss;
+    if (maxbits != nullptr) {
+        // block maximum first (8 descriptors), then one atomic per block into one of 64 slots
+        __shared__ unsigned s_max;
+        if (threadIdx.x == 0) s_max = 0u;
+        __syncthreads();
+        if (d < n && q == 0 && ss == ss) atomicMax(&s_max, __float_as_uint(fmaxf(ss, 0.0f)));
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&maxbits[blockIdx.x & (MF_MAXSLOTS - 1)], s_max);
+    }
+}
+
+// grid (ceil(l_len / 256), nchunks), 256 threads: wave w owns left descriptors [256 bx + 64 w, + 64) as two B fragment
+// sets (32 columns each); the block stages tiles of 32 right descriptors in LDS (double buffered) and every wave runs
+// 2 x 8 MFMAs per tile, then the epilogue on its 2 x 16 accumulators per lane.
+//   SEED = true : the first MF_SEED right descriptors in MF_SEEDCH chunks; no candidates, the result is every chunk's (smallest,
+//                 second smallest) s' per left descriptor: the second smallest of their union is an upper bound of the final
+//                 one and lets every chunk of the real pass start tight (an empty running minimum makes the first rows of
+//                 every chunk candidates: ~26 per chunk and descriptor)
+//   SEED = false: every chunk of the right side; running minima start at seed[l]; candidates appended to the left's list
+template <bool SEED>
+__global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __restrict__ lh, const float* __restrict__ ln2, int l_len,
+                                                       const unsigned short* __restrict__ rh, const float* __restrict__ rn2, int r_len,
+                                                       int chunk_len, const unsigned* __restrict__ maxbits, float* __restrict__ seed,
+                                                       int* __restrict__ cand_ct, int* __restrict__ cand)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_r[2][MF_TILE * MF_ROW];
+    __shared__ __attribute__((aligned(16))) float s_n[2][MF_TILE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int r0 = blockIdx.y * chunk_len, r1 = min(r0 + chunk_len, r_len);
+    const int ntiles = (r1 - r0 + MF_TILE - 1) / MF_TILE;
+    float rmax2 = 0.0f;
+    for (int i = 0; i < MF_MAXSLOTS; i++) rmax2 = fmaxf(rmax2, __uint_as_float(maxbits[i]));
+    const float rmax = sqrtf(rmax2);
+
+    // ---- this wave's left descriptors: B operands (8 K-steps x 2 column sets), norms, margins ----
+    f16x8 bfrag[2][8];
+    float twoE[2], m1[2], m2[2];
+    int lidx[2];
+    bool bad[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int li = blockIdx.x * 256 + wave * 64 + c * 32 + col;
+        lidx[c] = li;
+        const int lq = min(li, l_len - 1);
+        const unsigned short* lp = lh + (size_t)lq * 128 + half * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) bfrag[c][kk] = *reinterpret_cast<const f16x8*>(lp + kk * 16);
+        const float nl = ln2[lq];
+        const float E = 0.00197f * sqrtf(nl) * rmax + 7e-7f * (sqrtf(nl) + rmax) + 4e-5f * (nl + rmax2);
+        twoE[c] = 2.0f * E;
+        // running smallest / second smallest of s' = |r|^2 - 2 <l, r> (|l|^2 is the same for every pair of a column).  The
+        // real pass starts both at the sample's second smallest: "two values <= S exist" is all a threshold needs.
+        if (SEED) m1[c] = m2[c] = INFINITY;
+        else {
+            // second smallest of the seeding pass' MF_SEEDCH (smallest, second smallest) pairs
+            float a1 = INFINITY, a2 = INFINITY;
+#pragma unroll
+            for (int q = 0; q < 2 * MF_SEEDCH; q++) {
+                const float v = seed[((size_t)(q >> 1) * l_len + lq) * 2 + (q & 1)];
+                a2 = fminf(a2, fmaxf(a1, v)); a1 = fminf(a1, v);
+            }
+            m1[c] = m2[c] = a2;
+        }
+        // an element beyond f16's range would turn the approximate distance into inf / nan, which the threshold test would
+        // silently drop: such a left descriptor (or any, when a right one is that large) gets an overflowed segment instead
+        bad[c] = !(nl < 4e9f) || !(rmax2 < 4e9f);
+    }
+    int cnt[2] = {0, 0};                         // candidates of this lane's segment = (left descriptor, chunk, half wave)
+    const int seg = blockIdx.y * 2 + half;
+
+    // ---- staging of a right tile: 32 descriptors x 256 bytes = 512 16-byte pieces, two per thread; norms by 32 threads.
+    // Two steps, so that the global loads of tile k + 2 are in flight while tile k is computed: issue() = loads into
+    // registers; commit() = registers into the LDS buffer of tile k + 1 (free since the barrier that ended iteration k - 1) ----
+    uint4 pre[2];
+    float pre_n = INFINITY;
+    auto issue = [&](int tile) {
+        const int base = r0 + tile * MF_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int piece = t + j * 256;
+            const int row = piece >> 4, c16 = piece & 15;
+            const int ri = min(base + row, r_len - 1);
+            pre[j] = *reinterpret_cast<const uint4*>(rh + (size_t)ri * 128 + c16 * 8);
+        }
+        if (t < MF_TILE) pre_n = (base + t < r1) ? rn2[min(base + t, r_len - 1)] : INFINITY;     // rows beyond the chunk never win
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int piece = t + j * 256;
+            const int row = piece >> 4, c16 = piece & 15;
+            *reinterpret_cast<uint4*>(&s_r[buf][row * MF_ROW + c16 * 16]) = pre[j];
+        }
+        if (t < MF_TILE) s_n[buf][t] = pre_n;
+    };
+
+    if (ntiles > 0) { issue(0); commit(0); }
+    if (ntiles > 1) issue(1);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) commit(buf ^ 1);          // loaded during the previous iteration
+        if (tile + 2 < ntiles) issue(tile + 2);
+        f32x16 acc[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[c][i] = 0.0f;
+        const unsigned char* rp = &s_r[buf][col * MF_ROW + half * 16];
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            const f16x8 a = *reinterpret_cast<const f16x8*>(rp + kk * 32);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfrag[0][kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfrag[1][kk], acc[1], 0, 0, 0);
+        }
+        const int base = r0 + tile * MF_TILE;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            // first the whole tile's values against the threshold the column had BEFORE this tile (a superset test), in
+            // one wave-wide decision: the common case "nobody has a candidate" costs a compare per element and one branch
+            float sp[16];
+            float thr = m2[c] + twoE[c];
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 nr = *reinterpret_cast<const f32x4*>(&s_n[buf][8 * g + 4 * half]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    sp[4 * g + e] = fmaf(-2.0f, acc[c][4 * g + e], nr[e]);
+                    any |= sp[4 * g + e] <= thr;
+                    m2[c] = fminf(m2[c], fmaxf(m1[c], sp[4 * g + e]));
+                    m1[c] = fminf(m1[c], sp[4 * g + e]);
+                }
+            }
+            if (!SEED && __ballot(any && lidx[c] < l_len) != 0ull) {
+                if (any && lidx[c] < l_len) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) {
+                        const int ridx = base + 8 * (reg >> 2) + 4 * half + (reg & 3);
+                        if (sp[reg] <= thr && ridx < r1) {
+                            if (cnt[c] < MF_SEGCAP) cand[((size_t)lidx[c] * MF_SEGS + seg) * MF_SEGCAP + cnt[c]] = ridx;
+                            cnt[c]++;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!SEED) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+            if (lidx[c] < l_len) cand_ct[(size_t)lidx[c] * MF_SEGS + seg] = bad[c] ? MF_SEGCAP + 1 : cnt[c];
+    }
+    if (SEED) {
+        // the two half waves saw different rows of the same columns: second smallest of the union
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float o1 = __shfl_xor(m1[c], 32), o2 = __shfl_xor(m2[c], 32);
+            const float s1 = fminf(m1[c], o1), s2 = fminf(fmaxf(m1[c], o1), fminf(m2[c], o2));
+            if (half == 0 && lidx[c] < l_len) {
+                float* sd = seed + ((size_t)blockIdx.y * l_len + lidx[c]) * 2;
+                sd[0] = s1; sd[1] = s2;
+            }
+        }
+    }
+}
+
+// (distance, index) lexicographic order: what the reference's sequential scan with strict '<' yields
+__device__ __forceinline__ bool lex_less(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
+__device__ __forceinline__ void top2_insert_lex(Top2& t, float d, int i)
+{
+    if (!(d == d)) return;                                   // NaN never passes the reference's '<'
+    if (lex_less(d, i, t.d1, t.i1)) { t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = i; }
+    else if (lex_less(d, i, t.d2, t.i2)) { t.d2 = d; t.i2 = i; }
+}
+
+// Exact distances of the candidates, one wave per left descriptor, one HALF WAVE per pair -- the reference's own shape
+// (l2_in_t0, features.cu:160-189: 32 threads, thread t takes floats 4t..4t+3, then shuffle_down 16, 8, 4, 2, 1): one
+// coalesced 512-byte read per pair instead of 64 scattered ones per lane, 10 registers instead of 256.  Lane t of a half:
+//   q = l4 - r4;  p_t = fma(q.w, q.w, fma(q.z, q.z, fma(q.x, q.x, q.y * q.y)));  then v += shfl_down(v, 16 / 8 / 4 / 2 / 1):
+// lane 0 ends with ((((p0 + p16) + (p8 + p24)) + ...)), the tree of l2_tree above.  `left` / `right` in ORIGINAL layout.
+__global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ left, int l_len, const float* __restrict__ right, int r_len,
+                                                     const int* __restrict__ cand_ct, const int* __restrict__ cand,
+                                                     int* __restrict__ out, float* __restrict__ dist)
+{
+    const int lane = threadIdx.x & 63, tl = lane & 31, half = lane >> 5;
+    const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (li >= l_len) return;
+    const float4 l4 = reinterpret_cast<const float4*>(left + (size_t)li * 128)[tl];
+    // the left descriptor's segments, compacted into one list in LDS: lane s < MF_SEGS owns segment s
+    __shared__ int s_list[4][MF_CAP];
+    int* cl = s_list[threadIdx.x >> 6];
+    int myct = lane < MF_SEGS ? min(cand_ct[(size_t)li * MF_SEGS + lane], MF_SEGCAP) : 0;      // an overflowed segment never gets here
+    int off = myct;                                          // inclusive prefix sum over the 64 lanes
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) { const int o = __shfl_up(off, k); if (lane >= k) off += o; }
+    const int n = __shfl(off, 63);
+    off -= myct;
+    for (int k = 0; k < myct; k++) cl[off + k] = cand[((size_t)li * MF_SEGS + lane) * MF_SEGCAP + k];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the wave reads what its own lanes wrote
+    __builtin_amdgcn_wave_barrier();
+    // the sentinel index is larger than any real one: an empty slot loses every tie
+    Top2 t = {INFINITY, INFINITY, 0x7fffffff, 0x7fffffff};
+    for (int c0 = 0; c0 < n; c0 += 2) {
+        const int c = c0 + half;
+        const bool on = c < n;
+        const int ri = on ? cl[c] : 0;
+        const float4 r4 = reinterpret_cast<const float4*>(right + (size_t)ri * 128)[tl];
+        const float qx = l4.x - r4.x, qy = l4.y - r4.y, qz = l4.z - r4.z, qw = l4.w - r4.w;
+        float v = fmaf(qw, qw, fmaf(qz, qz, fmaf(qx, qx, qy * qy)));
+        v += __shfl_down(v, 16, 32); v += __shfl_down(v, 8, 32); v += __shfl_down(v, 4, 32);
+        v += __shfl_down(v, 2, 32);  v += __shfl_down(v, 1, 32);
+        const float d = __shfl(v, 0, 32);                    // the half's distance, in all of its lanes
+        if (on) top2_insert_lex(t, d, ri);
+    }
+    {   // the two halves hold disjoint candidate subsets: merge
+        const float od1 = __shfl_xor(t.d1, 32), od2 = __shfl_xor(t.d2, 32);
+        const int oi1 = __shfl_xor(t.i1, 32), oi2 = __shfl_xor(t.i2, 32);
+        top2_insert_lex(t, od1, oi1);
+        top2_insert_lex(t, od2, oi2);
+    }
+    if (lane == 0) {
+        // the reference starts from (inf, inf, index 0, index 0) and never replaces an entry by an equal one
+        const int i1 = t.i1 == 0x7fffffff ? 0 : t.i1, i2 = t.i2 == 0x7fffffff ? 0 : t.i2;
+        const bool accept = (t.d1 / t.d2 < 0.8f);
+        out[3 * li + 0] = i1; out[3 * li + 1] = i2; out[3 * li + 2] = accept ? 1 : 0;
+        if (dist) { dist[2 * li + 0] = t.d1; dist[2 * li + 1] = t.d2; }
+    }
+}
+
+// any left descriptor whose candidate list overflowed? (then psx_match runs the exact scan of every pair)
+__global__ void k_match_overflow(const int* __restrict__ cand_ct, int l_len, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < l_len * MF_SEGS && cand_ct[i] > MF_SEGCAP) *flag = 1;
+}
+
 } // namespace
 
 // Scratch of one calling thread: a private non-blocking stream (no null-stream launch, so nothing else on
@@ -128,18 +437,31 @@ namespace {
 struct MatchScratch {
     int device = -1;
     hipStream_t stream = nullptr;
-    void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t cap[4] = {0, 0, 0, 0};
+    void* buf[10] = {};
+    size_t cap[10] = {};
+    void* hpin = nullptr;                // pinned staging of the results: a DMA into pageable caller memory goes through the
+    size_t hpin_cap = 0;                 // runtime's own bounce buffers, ~0.5 ms per call on this stack
     void release()
     {
         if (device < 0) return;
         int cur = -1;                                        // the caller's current device is left as it was
         if (hipGetDevice(&cur) != hipSuccess) cur = -1;
         (void)hipSetDevice(device);
-        for (int i = 0; i < 4; i++) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+        for (int i = 0; i < 10; i++) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+        if (hpin) (void)hipHostFree(hpin);
+        hpin = nullptr; hpin_cap = 0;
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr; device = -1;
         if (cur >= 0) (void)hipSetDevice(cur);
+    }
+    bool need_pinned(size_t bytes)
+    {
+        if (bytes <= hpin_cap && hpin) return true;
+        if (hpin) (void)hipHostFree(hpin);
+        hpin = nullptr; hpin_cap = 0;
+        if (hipHostMalloc(&hpin, bytes, hipHostMallocDefault) != hipSuccess) return false;
+        hpin_cap = bytes;
+        return true;
     }
     bool need(int i, size_t bytes)
     {
@@ -156,7 +478,7 @@ struct MatchScratch {
 thread_local MatchScratch t_scratch;
 } // namespace
 
-// frees the calling thread's matcher scratch (stream + up to 4 device buffers); an explicit user call -- PopSift::uninit
+// frees the calling thread's matcher scratch (stream + up to 10 device buffers); an explicit user call -- PopSift::uninit
 // does NOT call it: the scratch belongs to the thread, not to one PopSift object (another replica may be using it)
 extern "C" int psx_match_release(void)
 {
@@ -194,16 +516,83 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
     int* d_out = static_cast<int*>(sc.buf[2]);
     float* d_dist = static_cast<float*>(sc.buf[3]);
     hipStream_t st = sc.stream;
+    // POPSIFT_MATCH_MFMA=0: the exact scan of every pair (rounds 1-4); default: MFMA prefilter + exact evaluation of the
+    // candidates (identical results by construction; used from 2048 right / 256 left descriptors on)
+    static const bool use_mfma = [] { const char* e = getenv("POPSIFT_MATCH_MFMA"); return !(e != nullptr && e[0] == '0'); }();
+    bool exact_scan = true;
+    if (use_mfma && r_len >= 2 * MF_SEED && l_len >= 256) {
+        if (!sc.need(4, sizeof(unsigned short) * 128 * (size_t)l_len) || !sc.need(5, sizeof(unsigned short) * 128 * (size_t)r_len) ||
+            !sc.need(6, sizeof(float) * (1 + 2 * MF_SEEDCH) * (size_t)l_len) || !sc.need(7, sizeof(float) * (size_t)r_len + 1024) ||
+            !sc.need(8, sizeof(int) * (size_t)MF_SEGS * l_len) || !sc.need(9, sizeof(int) * (size_t)MF_CAP * l_len))
+            return PSX_ERR_NOMEM;
+        unsigned short* d_lf16 = static_cast<unsigned short*>(sc.buf[4]);
+        unsigned short* d_rf16 = static_cast<unsigned short*>(sc.buf[5]);
+        float* d_ln2 = static_cast<float*>(sc.buf[6]);
+        float* d_seed = d_ln2 + l_len;
+        float* d_rn2 = static_cast<float*>(sc.buf[7]);
+        unsigned* d_max = reinterpret_cast<unsigned*>(d_rn2 + r_len);          // MF_MAXSLOTS words + the overflow flag behind the right norms
+        int* d_flag = reinterpret_cast<int*>(d_max + MF_MAXSLOTS);
+        int* d_cct = static_cast<int*>(sc.buf[8]);
+        int* d_cand = static_cast<int*>(sc.buf[9]);
+        if (hipMemsetAsync(d_cct, 0, sizeof(int) * (size_t)MF_SEGS * l_len, st) != hipSuccess ||
+            hipMemsetAsync(d_max, 0, sizeof(unsigned) * (MF_MAXSLOTS + 1), st) != hipSuccess) return PSX_ERR_HIP;
+        hipLaunchKernelGGL(k_match_prep, dim3((r_len * 32 + 255) / 256), dim3(256), 0, st, d_right, r_len, d_rf16, d_rn2, d_max);
+        hipLaunchKernelGGL(k_match_prep, dim3((l_len * 32 + 255) / 256), dim3(256), 0, st, d_left, l_len, d_lf16, d_ln2, (unsigned*)nullptr);
+        const int lblocks = (l_len + 255) / 256;
+        // seeding pass over the first MF_SEED right descriptors, then every chunk of the right side: enough workgroups for
+        // a round or two of the chip, whole tiles per chunk
+        hipLaunchKernelGGL((k_match_mfma<true>), dim3(lblocks, MF_SEEDCH), dim3(256), 0, st, d_lf16, d_ln2, l_len, d_rf16, d_rn2, r_len,
+                           MF_SEED / MF_SEEDCH, d_max, d_seed, d_cct, d_cand);
+        int mchunks = (1024 + lblocks - 1) / lblocks;
+        if (mchunks > (r_len + 8 * MF_TILE - 1) / (8 * MF_TILE)) mchunks = (r_len + 8 * MF_TILE - 1) / (8 * MF_TILE);
+        if (mchunks > MF_SEGS / 2) mchunks = MF_SEGS / 2;          // one candidate segment per (chunk, half wave)
+        if (mchunks < 1) mchunks = 1;
+        int mlen = (r_len + mchunks - 1) / mchunks;
+        mlen = ((mlen + MF_TILE - 1) / MF_TILE) * MF_TILE;
+        mchunks = (r_len + mlen - 1) / mlen;
+        hipLaunchKernelGGL((k_match_mfma<false>), dim3(lblocks, mchunks), dim3(256), 0, st, d_lf16, d_ln2, l_len, d_rf16, d_rn2, r_len, mlen,
+                           d_max, d_seed, d_cct, d_cand);
+        hipLaunchKernelGGL(k_match_overflow, dim3((l_len * MF_SEGS + 255) / 256), dim3(256), 0, st, d_cct, l_len, d_flag);
+        if (!sc.need_pinned(64)) return PSX_ERR_NOMEM;
+        int* h_flagp = static_cast<int*>(sc.hpin);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(h_flagp, d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) return PSX_ERR_HIP;
+        const int h_flag = *h_flagp;
+        static const bool stats = getenv("POPSIFT_MATCH_STATS") != nullptr;       // measurement: candidates per left descriptor
+        if (stats) {
+            std::vector<int> h((size_t)l_len * MF_SEGS);
+            if (hipMemcpy(h.data(), d_cct, sizeof(int) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+                long long sum = 0; int mx = 0, mxl = 0;
+                for (int i = 0; i < l_len; i++) { int t = 0; for (int q = 0; q < MF_SEGS; q++) { const int v = h[(size_t)i * MF_SEGS + q]; t += v; if (v > mx) mx = v; } sum += t; if (t > mxl) mxl = t; }
+                fprintf(stderr, "psx_match prefilter: %d x %d, candidates per left descriptor: mean %.1f, max %d; fullest segment %d of %d%s\n", l_len, r_len,
+                        (double)sum / l_len, mxl, mx, MF_SEGCAP, h_flag ? " -> exact scan of every pair" : "");
+            }
+        }
+        if (h_flag == 0) {
+            hipLaunchKernelGGL(k_match_exact, dim3((l_len + 3) / 4), dim3(256), 0, st, d_left, l_len, d_right, r_len, d_cct, d_cand,
+                               d_out, d_dist);
+            exact_scan = false;
+        }
+        // else: some list overflowed (thousands of near-equal neighbours): the exact scan of every pair below
+    }
+    if (exact_scan) {
     if (r_len > 0)
         hipLaunchKernelGGL(k_match_permute, dim3((r_len * 64 + 255) / 256), dim3(256), 0, st, d_right, r_len, d_rperm);
     hipLaunchKernelGGL(k_match_partial, dim3(lgroups, nchunks), dim3(64), 0, st, d_left, l_len, d_rperm, r_len,
                        chunk_len, d_partial);
     hipLaunchKernelGGL(k_match_merge, dim3((l_len + 255) / 256), dim3(256), 0, st, d_partial, l_len, nchunks,
                        r_len, d_out, d_dist);
+    }
+    const size_t mb = sizeof(int) * 3 * (size_t)l_len, db = sizeof(float) * 2 * (size_t)l_len;
+    if (!sc.need_pinned(mb + db)) return PSX_ERR_NOMEM;
+    char* hp = static_cast<char*>(sc.hpin);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(host_match, d_out, sizeof(int) * 3 * (size_t)l_len, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        (host_dist && hipMemcpyAsync(host_dist, d_dist, sizeof(float) * 2 * (size_t)l_len, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        hipMemcpyAsync(hp, d_out, mb, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (host_dist && hipMemcpyAsync(hp + mb, d_dist, db, hipMemcpyDeviceToHost, st) != hipSuccess) ||
         hipStreamSynchronize(st) != hipSuccess)
         return PSX_ERR_HIP;
+    memcpy(host_match, hp, mb);
+    if (host_dist) memcpy(host_dist, hp + mb, db);
     return PSX_OK;
 }

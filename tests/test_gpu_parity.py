@@ -471,6 +471,64 @@ def test_match_bit_exact(oracle, capi, nl, nr, seed):
     assert np.array_equal(do_.view(np.uint32), dg.view(np.uint32))
 
 
+def test_match_mfma_prefilter_equals_exact_scan(oracle, capi):
+    """Round 5: psx_match's default path discards pairs with a bf16-MFMA distance and a proven error margin and evaluates
+    the survivors with the reference's operation tree (match.hip).  Indices, accept flags and distances must be
+    BIT-IDENTICAL to the oracle's sequential scan on: random descriptors, RootSift-like unit-norm descriptors, descriptors
+    scaled by 2^9 (setNormalizationMultiplier(9)), exact duplicates and near-duplicates (ties keep the earlier index),
+    thousands of identical right descriptors (candidate lists overflow: the full-scan fallback), all-zero descriptors, a
+    right side that is not a multiple of the tile or chunk size."""
+    rng = np.random.default_rng(11)
+
+    def unit(n):
+        v = rng.random((n, 128), dtype=np.float32) ** 4
+        return np.sqrt(v / v.sum(1, keepdims=True)).astype(np.float32)
+
+    cases = []
+    cases.append(("random", rng.random((700, 128), dtype=np.float32), rng.random((4531, 128), dtype=np.float32)))
+    l, r = unit(1024), unit(5000)
+    r[100] = l[5]; r[4000] = l[5]; r[17] = l[9]; r[18] = l[9] + np.float32(1e-4)
+    cases.append(("unit norm + duplicates", l, r))
+    cases.append(("scaled 2^9", (unit(512) * 512).astype(np.float32), (unit(4200) * 512).astype(np.float32)))
+    l, r = unit(300), unit(9000)
+    r[1000:8500] = r[999]                                    # 7500 identical neighbours: segments overflow -> exact scan of every pair
+    cases.append(("overflow", l, r))
+    l, r = unit(260), unit(4100)
+    l[3] = 0.0; r[5] = 0.0; r[6] = 0.0
+    cases.append(("zeros", l, r))
+    l, r = unit(256), unit(4096)
+    r[77] *= np.float32(3e5)                                 # beyond f16's range: the prefilter must step aside, not lose the pair
+    l[9] *= np.float32(3e5); r[78] = l[9]
+    cases.append(("beyond f16 range", l, r))
+    cases.append(("sizes at the limits", unit(256), unit(4096)))
+    cases.append(("just below: exact scan", unit(255), unit(4095)))
+    for name, l, r in cases:
+        mo, do_ = oracle.match(l, r)
+        mg, dg = capi.match(l, r)
+        assert np.array_equal(mo, mg), name
+        assert np.array_equal(do_.view(np.uint32), dg.view(np.uint32)), name
+
+
+def test_match_prefilter_on_real_descriptors(oracle, capi):
+    """The prefilter path on what it is for: the descriptors of two views of a scene (1280x720, ~8 k descriptors each, the second
+    view shifted by 3 pixels: most left descriptors have a near-identical partner, i.e. distances close to zero where the
+    GEMM form of the distance cancels) -- indices, flags and distances bit-identical to the oracle's sequential scan."""
+    a = synth(1280, 720, 4242)
+    ds = []
+    for img in (a, np.roll(a, 3, axis=1)):
+        ctx = capi.Context(capi.default_config(octaves=5, sift_mode=2))
+        ctx.upload(img)
+        ctx.extract()
+        ds.append(ctx.download()[1])
+        ctx.close()
+    assert len(ds[0]) >= 4096 and len(ds[1]) >= 4096         # large enough for the MFMA path
+    mo, do_ = oracle.match(ds[0], ds[1])
+    mg, dg = capi.match(ds[0], ds[1])
+    assert np.array_equal(mo, mg)
+    assert np.array_equal(do_.view(np.uint32), dg.view(np.uint32))
+    assert (mg[:, 2] == 1).sum() > 0.8 * len(ds[0])          # the views do match
+
+
 def test_match_on_extracted_descriptors(oracle, capi):
     """Two views of the same scene through the whole pipe, then the matcher on the real descriptors."""
     a, b = synth(320, 240, 77), np.roll(synth(320, 240, 77), 3, axis=1)
