@@ -298,6 +298,7 @@ class GpuBackend:
 def run(args, backend_cls=GpuBackend, out=sys.stdout):
     """The bench proper: rank / world from the environment, one process per GPU, three timed legs, rank 0
     prints ONE JSON line.  Returns the dict (rank 0) or None."""
+    t_wall = {"start": time.perf_counter()}
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -309,6 +310,7 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
     else:
         dist = None
     be = backend_cls(rank, local_rank, world)
+    t_wall["setup"] = time.perf_counter()
 
     def barrier():
         if dist is not None:
@@ -468,6 +470,7 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
                               "the grid filter's host-side counter read once per frame (stalls one worker, not the pipe)"}
         be.e2e_close()
 
+    t_wall["e2e_legs"] = time.perf_counter()
     # ---- legs 2 and 3: C-ABI, inputs already resident in HBM ----
     be.abi_open()
     inflight = deque()
@@ -545,8 +548,16 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
             "frac_end_to_end": round(pipe_b * n_frames / dt_e2e / 1e9 / HBM_PEAK_GBS / world, 4),
             "frac_device_resident": round(pipe_b * n_frames / dt_dev / 1e9 / HBM_PEAK_GBS / world, 4),
             "what": "A_min of SURVEY.md 8d (68 N0 + 72 sum N_o + input) x frames / time, per GPU fraction of 8 TB/s"}
+        t_wall["abi_legs"] = time.perf_counter()
         if not args.no_extras:
             result.update(be.extras(args, world))
+        t_wall["extras"] = time.perf_counter()
+        # where this run's wall time went (the driver allows the default run about a minute)
+        result["wall_s"] = {"setup_frames_and_import": round(t_wall["setup"] - t_wall["start"], 1),
+                            "end_to_end_legs": round(t_wall["e2e_legs"] - t_wall["setup"], 1),
+                            "c_abi_legs": round(t_wall["abi_legs"] - t_wall["e2e_legs"], 1),
+                            "extras": round(t_wall["extras"] - t_wall["abi_legs"], 1),
+                            "total": round(t_wall["extras"] - t_wall["start"], 1)}
         print(json.dumps(result), file=out, flush=True)
 
     be.abi_close()
@@ -672,6 +683,12 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
     """Rank-0 measurements outside the timed legs: roofline of the dominant kernel, single-frame latency and
     stage times, BASELINE config 3, CPU baseline."""
     ex = {}
+    laps, t_lap = {}, [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        laps[name] = round(now - t_lap[0], 1)
+        t_lap[0] = now
     c0 = ctxs[0]
     c0.sync()
 
@@ -734,6 +751,7 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
                     "frac": round(x0_by / (x0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if x0_ms > 0 else None},
     }
 
+    lap("roofline")
     # ---- one frame at a time on one context (BASELINE config 2, "single frame") ----
     lat = []
     for i in range(25):
@@ -759,9 +777,12 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
                                "what": "algorithmic bytes of the whole pyramid build (SURVEY.md 8d: 44 N0 + 48 sum N_o + input) / "
                                        "pyramid stage time of one frame on one context (HIP events around psx_build_pyramid)"}
 
+    lap("single_frame")
     # ---- BASELINE config 5 stand-in and the matcher (always on; a few seconds) ----
     ex["config5"] = config5_leg(capi, np, device)
+    lap("config5")
     ex["match"] = match_leg(capi, np, device)
+    lap("match")
 
     # ---- the host side without the kernels: what bends the 1 -> 8 GPU curve (tools/host_ceiling.py) ----
     if world == 1 and not getattr(args, "no_host_ceiling", False):
@@ -771,10 +792,11 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
             if args.extras:
                 ex["host_ceiling"] = host_ceiling.measure(seconds=1.5, procs=(1, 2, 4, 8), modes=(1, 2))
             else:
-                ex["host_ceiling"] = host_ceiling.measure(seconds=1.0, configs=[(2, 8), (1, 1)])
+                ex["host_ceiling"] = host_ceiling.measure(seconds=1.0, configs=[(2, 8)])      # the PCIe-link rows: --extras, profiles/r05_host_ceiling.json
         except Exception as e:
             ex["host_ceiling"] = "failed: %s" % e
 
+    lap("host_ceiling")
     # ---- every alternative Gauss / scaling / descriptor mode once: single-frame wall time, one context (--extras) ----
     try:
         if not args.extras:
@@ -838,6 +860,7 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
     except Exception as e:                                   # never lose the headline to an extra
         ex["config3"] = str(e) if str(e).startswith("skipped") else "failed: %s" % e
 
+    lap("alt_modes_and_config3")
     # ---- CPU baseline (bounded sample) ----
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as po
@@ -846,7 +869,7 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         po.run(ocfg, frames_np[0], threads=ncores).close()     # warm
         n_s = 0
         t1 = time.perf_counter()
-        while n_s < NBASE and (n_s < 2 or time.perf_counter() - t1 < 8.0):
+        while n_s < NBASE and (n_s < 2 or time.perf_counter() - t1 < 6.0):
             po.run(ocfg, frames_np[n_s], threads=ncores).close()
             n_s += 1
         cdt = time.perf_counter() - t1
@@ -873,6 +896,8 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         ex["cpu_baseline"] = cpu
     else:
         ex["cpu_baseline"] = None
+    lap("cpu_baseline")
+    ex["extras_wall_s"] = laps
     return ex
 
 
