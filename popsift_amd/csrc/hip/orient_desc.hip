@@ -857,7 +857,7 @@ __device__ __forceinline__ float desc_gauss_entry(int yy, int xx)
     const float dn_base = 0.5f * dn_step - 20.0f * dn_step;
     const float dnx = dn_base + xx * dn_step;
     const float dny = dn_base + yy * dn_step;
-    return expf(-ldexpf(dnx * dnx + dny * dny, -3));
+    return __builtin_amdgcn_exp2f((dnx * dnx + dny * dny) * (-0.125f * 1.4426950408889634f));      // v_exp_f32, as the default kernel's window weight
 }
 __device__ __forceinline__ float desc_tile_entry(int i)
 {
@@ -896,8 +896,11 @@ __device__ __forceinline__ void d_gradiant_rot(float& grad, float& theta, float 
 {
     const float dx = d_plane_linear(plane, W, H, pitch, x + cos_t, y + sin_t) - d_plane_linear(plane, W, H, pitch, x - cos_t, y - sin_t);
     const float dy = d_plane_linear(plane, W, H, pitch, x - sin_t, y + cos_t) - d_plane_linear(plane, W, H, pitch, x + sin_t, y - cos_t);
-    grad = hypotf(dx, dy);
-    theta = atan2_1r(dy, dx);
+    // magnitude and angle only SCALE / interpolate a contribution (bin weights are continuous in the angle): v_sqrt_f32 and the
+    // degree-13 atan polynomial (3.3e-7 rad) of the default kernel instead of hypotf and a double-precision atan2 (round 5:
+    // the f64 atan2 alone was most of these kernels' instructions)
+    grad = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+    theta = fast_atan2(dy, dx);
 }
 // get_gradiant on the point texture at integer coordinates (s_gradiant.h:56-69)
 __device__ __forceinline__ void d_gradiant_pt(float& grad, float& theta, int x, int y, const float* plane, int W, int H, int pitch)
@@ -905,8 +908,8 @@ __device__ __forceinline__ void d_gradiant_pt(float& grad, float& theta, int x, 
     auto rd = [&](int xx, int yy) { return plane[(size_t)psx_clampi(yy, 0, H - 1) * pitch + psx_clampi(xx, 0, W - 1)]; };
     const float dx = rd(x + 1, y) - rd(x - 1, y);
     const float dy = rd(x, y + 1) - rd(x, y - 1);
-    grad = hypotf(dx, dy);
-    theta = atan2_1r(dy, dx);
+    grad = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+    theta = fast_atan2(dy, dx);
 }
 
 constexpr int ALT_BINS = 9;
@@ -971,7 +974,7 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
                             float mod, th;
                             d_gradiant_rot(mod, th, jj, ii, cos_t, sin_t, plane, W, H, pitch);
                             const float dnx = nx + offx, dny = ny + offy;
-                            const float ww = expf(-ldexpf(dnx * dnx + dny * dny, -3));
+                            const float ww = __builtin_amdgcn_exp2f((dnx * dnx + dny * dny) * (-0.125f * 1.4426950408889634f));
                             const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod;
                             th += (th <  0.0f  ? PI2_F : 0.0f);
                             th -= (th >= PI2_F ? PI2_F : 0.0f);
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
                             const float npx = fmaf(cos_t, pox,  sin_t * poy);
                             const float npy = fmaf(cos_t, poy, -sin_t * pox);
                             const float dnx = npx + offx, dny = npy + offy;
-                            const float ww = expf(-ldexpf(dnx * dnx + dny * dny, -3));
+                            const float ww = __builtin_amdgcn_exp2f((dnx * dnx + dny * dny) * (-0.125f * 1.4426950408889634f));
                             const float wx = 1.0f - fabsf(npx), wy = 1.0f - fabsf(npy);
                             if (wx < 0.0f || wy < 0.0f) continue;
                             const float wgt = ww * wx * wy * mod;
