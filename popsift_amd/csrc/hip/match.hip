@@ -138,9 +138,13 @@ __global__ void k_match_merge(const Top2* __restrict__ partial, int l_len, int n
 //       a smaller one absolute error <= 2^-25, so |<f16 l, f16 r> - <l, r>| <= 2.002 u |l| |r| + 2^-25 sqrt(128) (|l| + |r|)
 //       (Cauchy-Schwarz); the f32 accumulation of 128 exact products, the f32 norms and the rounding of the reference's own
 //       operation tree add <= 2e-5 (|l|^2 + |r|^2).  With Rmax = max |r|:
-//       E_l := 0.00197 |l| Rmax + 7e-7 (|l| + Rmax) + 4e-5 (|l|^2 + Rmax^2)  (bf16, 8 bits, had 0.0157: on random descriptors,
-//       whose distances concentrate, hundreds of neighbours fell inside the margin).  Elements beyond f16's range (65504)
-//       cannot occur below a squared norm of 4e9; above it the prefilter is not used (overflow flag -> exact scan).
+//       E_l := 0.00197 |l| Rmax + 2e-7 M (|l| + Rmax) + 4e-5 (|l|^2 + Rmax^2)  (bf16, 8 bits, had 0.0157: on random descriptors,
+//       whose distances concentrate, hundreds of neighbours fell inside the margin).
+//       f16's RANGE is taken out of the picture by scaling both sides with a power of two 2^k (exact) before the conversion,
+//       k = floor(log2(16384 / M)), M = the largest norm of either side: no element exceeds 16384 (f16 max 65504), and an
+//       element that falls below 2^-14 after scaling -- where f16 loses relative precision, or the matrix unit may flush
+//       it to zero -- is below M 2^-27, which is the "2e-7 M (|l| + Rmax)" term (with either behaviour).  -2 / 4^k rides on the
+//       epilogue's fma.  Norms that are zero, infinite or NaN switch the prefilter off (overflow flag -> exact scan).
 // If s2 is the second smallest s of a left descriptor, its true second-best distance is <= s2 + E_l (two pairs have
 // d <= s + E_l <= s2 + E_l), and every pair with d <= that has s <= s2 + 2 E_l.  So the set {r : s <= s2 + 2 E_l} contains
 // every pair that can be best or second best INCLUDING all ties, and the reference's scan restricted to it (same operation
@@ -175,9 +179,8 @@ __device__ __forceinline__ unsigned short to_f16(float f)
     return b;
 }
 
-// f16 copy + squared norm of every descriptor, and the largest squared norm (bits of a non-negative float, 64 slots)
-__global__ void k_match_prep(const float* __restrict__ src, int n, unsigned short* __restrict__ dst, float* __restrict__ norm2,
-                             unsigned* __restrict__ maxbits)
+// squared norm of every descriptor and the largest one (bits of a non-negative float, 64 slots: same-address atomics serialise)
+__global__ void k_match_norms(const float* __restrict__ src, int n, float* __restrict__ norm2, unsigned* __restrict__ maxbits)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 elements, 32 threads per descriptor
     const int d = g >> 5, q = g & 31;
@@ -185,20 +188,45 @@ __global__ void k_match_prep(const float* __restrict__ src, int n, unsigned shor
     if (d < n) {
         const float4 v = reinterpret_cast<const float4*>(src + (size_t)d * 128)[q];
         ss = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
-        ushort4 o; o.x = to_f16(v.x); o.y = to_f16(v.y); o.z = to_f16(v.z); o.w = to_f16(v.w);
-        reinterpret_cast<ushort4*>(dst + (size_t)d * 128)[q] = o;
     }
     for (int k = 16; k >= 1; k >>= 1) ss += __shfl_xor(ss, k, 32);
     if (d < n && q == 0) norm2[d] = ss;
-    if (maxbits != nullptr) {
-        // block maximum first (8 descriptors), then one atomic per block into one of 64 slots
-        __shared__ unsigned s_max;
-        if (threadIdx.x == 0) s_max = 0u;
-        __syncthreads();
-        if (d < n && q == 0 && ss == ss) atomicMax(&s_max, __float_as_uint(fmaxf(ss, 0.0f)));
-        __syncthreads();
-        if (threadIdx.x == 0) atomicMax(&maxbits[blockIdx.x & (MF_MAXSLOTS - 1)], s_max);
-    }
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0) s_max = 0u;
+    __syncthreads();
+    // a NaN norm has the bit pattern of a huge unsigned: it wins the maximum and switches the prefilter off (k_match_scale)
+    if (d < n && q == 0) atomicMax(&s_max, __float_as_uint(ss < 0.0f ? 0.0f : ss));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&maxbits[blockIdx.x & (MF_MAXSLOTS - 1)], s_max);
+}
+
+// par[0] = 2^k, par[1] = -2 / 4^k, par[2] = Rmax^2, par[3] = M; *flag = 1 when the prefilter cannot be used
+__global__ void k_match_scale(const unsigned* __restrict__ lmax, const unsigned* __restrict__ rmax, float* __restrict__ par, int* __restrict__ flag)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned lb = 0u, rb = 0u;
+    for (int i = 0; i < MF_MAXSLOTS; i++) { lb = max(lb, lmax[i]); rb = max(rb, rmax[i]); }
+    const float l2 = __uint_as_float(lb), r2 = __uint_as_float(rb);
+    const float m2 = fmaxf(l2, r2);
+    // finite, positive, and far enough from both ends of the float range for the squares below
+    if (!(l2 == l2) || !(r2 == r2) || !(m2 > 1e-30f) || !(m2 < 1e30f)) { *flag = 1; par[0] = 1.0f; par[1] = -2.0f; par[2] = 0.0f; par[3] = 0.0f; return; }
+    const float M = sqrtf(m2);
+    const int k = (int)floorf(log2f(16384.0f / M));
+    par[0] = ldexpf(1.0f, k);
+    par[1] = ldexpf(-2.0f, -2 * k);
+    par[2] = r2;
+    par[3] = M;
+}
+
+// f16 copy of every descriptor, scaled by par[0] = 2^k
+__global__ void k_match_cvt(const float* __restrict__ src, int n, unsigned short* __restrict__ dst, const float* __restrict__ par)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 elements
+    if (g >= n * 32) return;
+    const float sc = par[0];
+    const float4 v = reinterpret_cast<const float4*>(src)[g];
+    ushort4 o; o.x = to_f16(v.x * sc); o.y = to_f16(v.y * sc); o.z = to_f16(v.z * sc); o.w = to_f16(v.w * sc);
+    reinterpret_cast<ushort4*>(dst)[g] = o;
 }
 
 // grid (ceil(l_len / 256), nchunks), 256 threads: wave w owns left descriptors [256 bx + 64 w, + 64) as two B fragment
@@ -212,7 +240,7 @@ __global__ void k_match_prep(const float* __restrict__ src, int n, unsigned shor
 template <bool SEED>
 __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __restrict__ lh, const float* __restrict__ ln2, int l_len,
                                                        const unsigned short* __restrict__ rh, const float* __restrict__ rn2, int r_len,
-                                                       int chunk_len, const unsigned* __restrict__ maxbits, float* __restrict__ seed,
+                                                       int chunk_len, const float* __restrict__ par, float* __restrict__ seed,
                                                        int* __restrict__ cand_ct, int* __restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_r[2][MF_TILE * MF_ROW];
@@ -221,15 +249,13 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
     const int col = lane & 31, half = lane >> 5;
     const int r0 = blockIdx.y * chunk_len, r1 = min(r0 + chunk_len, r_len);
     const int ntiles = (r1 - r0 + MF_TILE - 1) / MF_TILE;
-    float rmax2 = 0.0f;
-    for (int i = 0; i < MF_MAXSLOTS; i++) rmax2 = fmaxf(rmax2, __uint_as_float(maxbits[i]));
+    const float fneg2 = par[1], rmax2 = par[2], bigM = par[3];
     const float rmax = sqrtf(rmax2);
 
     // ---- this wave's left descriptors: B operands (8 K-steps x 2 column sets), norms, margins ----
     f16x8 bfrag[2][8];
     float twoE[2], m1[2], m2[2];
     int lidx[2];
-    bool bad[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int li = blockIdx.x * 256 + wave * 64 + c * 32 + col;
@@ -239,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) bfrag[c][kk] = *reinterpret_cast<const f16x8*>(lp + kk * 16);
         const float nl = ln2[lq];
-        const float E = 0.00197f * sqrtf(nl) * rmax + 7e-7f * (sqrtf(nl) + rmax) + 4e-5f * (nl + rmax2);
+        const float E = 0.00197f * sqrtf(nl) * rmax + 2e-7f * bigM * (sqrtf(nl) + rmax) + 4e-5f * (nl + rmax2);
         twoE[c] = 2.0f * E;
         // running smallest / second smallest of s' = |r|^2 - 2 <l, r> (|l|^2 is the same for every pair of a column).  The
         // real pass starts both at the sample's second smallest: "two values <= S exist" is all a threshold needs.
@@ -254,9 +280,6 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
             }
             m1[c] = m2[c] = a2;
         }
-        // an element beyond f16's range would turn the approximate distance into inf / nan, which the threshold test would
-        // silently drop: such a left descriptor (or any, when a right one is that large) gets an overflowed segment instead
-        bad[c] = !(nl < 4e9f) || !(rmax2 < 4e9f);
     }
     int cnt[2] = {0, 0};                         // candidates of this lane's segment = (left descriptor, chunk, half wave)
     const int seg = blockIdx.y * 2 + half;
@@ -319,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
                 const f32x4 nr = *reinterpret_cast<const f32x4*>(&s_n[buf][8 * g + 4 * half]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    sp[4 * g + e] = fmaf(-2.0f, acc[c][4 * g + e], nr[e]);
+                    sp[4 * g + e] = fmaf(fneg2, acc[c][4 * g + e], nr[e]);
                     any |= sp[4 * g + e] <= thr;
                     m2[c] = fminf(m2[c], fmaxf(m1[c], sp[4 * g + e]));
                     m1[c] = fminf(m1[c], sp[4 * g + e]);
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
     if (!SEED) {
 #pragma unroll
         for (int c = 0; c < 2; c++)
-            if (lidx[c] < l_len) cand_ct[(size_t)lidx[c] * MF_SEGS + seg] = bad[c] ? MF_SEGCAP + 1 : cnt[c];
+            if (lidx[c] < l_len) cand_ct[(size_t)lidx[c] * MF_SEGS + seg] = cnt[c];
     }
     if (SEED) {
         // the two half waves saw different rows of the same columns: second smallest of the union
@@ -530,19 +553,25 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         float* d_ln2 = static_cast<float*>(sc.buf[6]);
         float* d_seed = d_ln2 + l_len;
         float* d_rn2 = static_cast<float*>(sc.buf[7]);
-        unsigned* d_max = reinterpret_cast<unsigned*>(d_rn2 + r_len);          // MF_MAXSLOTS words + the overflow flag behind the right norms
-        int* d_flag = reinterpret_cast<int*>(d_max + MF_MAXSLOTS);
+        // behind the right norms: 2 x MF_MAXSLOTS maximum slots, the overflow flag, 4 parameters
+        unsigned* d_rmax = reinterpret_cast<unsigned*>(d_rn2 + r_len);
+        unsigned* d_lmax = d_rmax + MF_MAXSLOTS;
+        int* d_flag = reinterpret_cast<int*>(d_lmax + MF_MAXSLOTS);
+        float* d_par = reinterpret_cast<float*>(d_flag + 1);
         int* d_cct = static_cast<int*>(sc.buf[8]);
         int* d_cand = static_cast<int*>(sc.buf[9]);
         if (hipMemsetAsync(d_cct, 0, sizeof(int) * (size_t)MF_SEGS * l_len, st) != hipSuccess ||
-            hipMemsetAsync(d_max, 0, sizeof(unsigned) * (MF_MAXSLOTS + 1), st) != hipSuccess) return PSX_ERR_HIP;
-        hipLaunchKernelGGL(k_match_prep, dim3((r_len * 32 + 255) / 256), dim3(256), 0, st, d_right, r_len, d_rf16, d_rn2, d_max);
-        hipLaunchKernelGGL(k_match_prep, dim3((l_len * 32 + 255) / 256), dim3(256), 0, st, d_left, l_len, d_lf16, d_ln2, (unsigned*)nullptr);
+            hipMemsetAsync(d_rmax, 0, sizeof(unsigned) * (2 * MF_MAXSLOTS + 1), st) != hipSuccess) return PSX_ERR_HIP;
+        hipLaunchKernelGGL(k_match_norms, dim3((r_len * 32 + 255) / 256), dim3(256), 0, st, d_right, r_len, d_rn2, d_rmax);
+        hipLaunchKernelGGL(k_match_norms, dim3((l_len * 32 + 255) / 256), dim3(256), 0, st, d_left, l_len, d_ln2, d_lmax);
+        hipLaunchKernelGGL(k_match_scale, dim3(1), dim3(64), 0, st, d_lmax, d_rmax, d_par, d_flag);
+        hipLaunchKernelGGL(k_match_cvt, dim3((r_len * 32 + 255) / 256), dim3(256), 0, st, d_right, r_len, d_rf16, d_par);
+        hipLaunchKernelGGL(k_match_cvt, dim3((l_len * 32 + 255) / 256), dim3(256), 0, st, d_left, l_len, d_lf16, d_par);
         const int lblocks = (l_len + 255) / 256;
         // seeding pass over the first MF_SEED right descriptors, then every chunk of the right side: enough workgroups for
         // a round or two of the chip, whole tiles per chunk
         hipLaunchKernelGGL((k_match_mfma<true>), dim3(lblocks, MF_SEEDCH), dim3(256), 0, st, d_lf16, d_ln2, l_len, d_rf16, d_rn2, r_len,
-                           MF_SEED / MF_SEEDCH, d_max, d_seed, d_cct, d_cand);
+                           MF_SEED / MF_SEEDCH, d_par, d_seed, d_cct, d_cand);
         int mchunks = (1024 + lblocks - 1) / lblocks;
         if (mchunks > (r_len + 8 * MF_TILE - 1) / (8 * MF_TILE)) mchunks = (r_len + 8 * MF_TILE - 1) / (8 * MF_TILE);
         if (mchunks > MF_SEGS / 2) mchunks = MF_SEGS / 2;          // one candidate segment per (chunk, half wave)
@@ -551,7 +580,7 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         mlen = ((mlen + MF_TILE - 1) / MF_TILE) * MF_TILE;
         mchunks = (r_len + mlen - 1) / mlen;
         hipLaunchKernelGGL((k_match_mfma<false>), dim3(lblocks, mchunks), dim3(256), 0, st, d_lf16, d_ln2, l_len, d_rf16, d_rn2, r_len, mlen,
-                           d_max, d_seed, d_cct, d_cand);
+                           d_par, d_seed, d_cct, d_cand);
         hipLaunchKernelGGL(k_match_overflow, dim3((l_len * MF_SEGS + 255) / 256), dim3(256), 0, st, d_cct, l_len, d_flag);
         if (!sc.need_pinned(64)) return PSX_ERR_NOMEM;
         int* h_flagp = static_cast<int*>(sc.hpin);

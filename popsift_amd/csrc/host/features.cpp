@@ -135,7 +135,8 @@ struct Pool
     {
         void* p = nullptr;
         DeviceCpus& dc = device_cpus( device );
-        if( !multi_node_host() || !dc.valid ) { if( psx_host_alloc_near( device, c, &p ) != PSX_OK ) return nullptr; return p; }
+        // single-node host (or CPUs unknown): placement does not matter, and the CALLER's current device must not change
+        if( !multi_node_host() || !dc.valid ) { if( psx_host_alloc( c, &p ) != PSX_OK ) return nullptr; return p; }
         const int dev = device;
         const cpu_set_t* set = &dc.set;
         std::thread t( [&p, c, dev, set]{ (void)sched_setaffinity( 0, sizeof(cpu_set_t), set ); if( psx_host_alloc_near( dev, c, &p ) != PSX_OK ) p = nullptr; } );

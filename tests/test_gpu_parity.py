@@ -501,6 +501,12 @@ def test_match_mfma_prefilter_equals_exact_scan(oracle, capi):
     l[9] *= np.float32(3e5); r[78] = l[9]
     cases.append(("beyond f16 range", l, r))
     cases.append(("sizes at the limits", unit(256), unit(4096)))
+    cases.append(("tiny scale (x 1e-9)", (unit(300) * np.float32(1e-9)).astype(np.float32), (unit(4200) * np.float32(1e-9)).astype(np.float32)))
+    cases.append(("huge scale (x 1e9)", (unit(300) * np.float32(1e9)).astype(np.float32), (unit(4200) * np.float32(1e9)).astype(np.float32)))
+    l, r = unit(400), unit(4300)
+    l[::3] *= np.float32(1e-4); r[::5] *= np.float32(1e-3)   # norms spread over four decades: small descriptors lose f16 bits after the common scaling
+    cases.append(("mixed norms", l, r))
+    cases.append(("all zero", np.zeros((256, 128), np.float32), np.zeros((4096, 128), np.float32)))
     cases.append(("just below: exact scan", unit(255), unit(4095)))
     for name, l, r in cases:
         mo, do_ = oracle.match(l, r)
