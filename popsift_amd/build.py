@@ -6,12 +6,18 @@
   popsift_amd/lib/popsift-demo        the command line extractor (PGM/PPM in, output-features.txt out; reference main.cpp)
   popsift_amd/lib/popsift-match       the MatchingMode tool (reference match.cpp)
 
-hipcc cross-compiles gfx950 without a GPU.  Objects are cached by source mtime.
+hipcc cross-compiles gfx950 without a GPU.  Objects are cached by CONTENT: popsift_amd/build/manifest.json records, per object,
+the SHA-1 of its source, of every header it may include and of its command line; an object is rebuilt when that hash
+differs (file times say nothing after a checkout).  `python -m popsift_amd.build -v` prints what was rebuilt and what was
+reused; POPSIFT_BUILD_FORCE=1 rebuilds everything; manifest.json also records when each object was built.
 """
 import concurrent.futures as cf
+import hashlib
+import json
 import os
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -47,6 +53,47 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+MANIFEST = os.path.join(OBJDIR, "manifest.json")
+_manifest = None
+LAST_BUILD = {"rebuilt": [], "reused": []}       # what the last build_all() did (for __graft_entry__.build())
+
+
+def _load_manifest():
+    global _manifest
+    if _manifest is None:
+        try:
+            _manifest = json.load(open(MANIFEST))
+        except Exception:
+            _manifest = {}
+    return _manifest
+
+
+def _digest(cmd, files):
+    h = hashlib.sha1(" ".join(cmd).encode())
+    for f in sorted(files):
+        if os.path.exists(f):
+            h.update(f.encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def _stale(target, cmd, files):
+    """True when `target` must be (re)built: missing, forced, or its recorded content hash differs"""
+    key = os.path.relpath(target, HERE)
+    d = _digest(cmd, files)
+    m = _load_manifest()
+    stale = os.environ.get("POPSIFT_BUILD_FORCE") == "1" or not os.path.exists(target) or m.get(key, {}).get("sha1") != d
+    (LAST_BUILD["rebuilt"] if stale else LAST_BUILD["reused"]).append(key)
+    return stale, key, d
+
+
+def _record(key, digest):
+    m = _load_manifest()
+    m[key] = {"sha1": digest, "built": time.strftime("%Y-%m-%dT%H:%M:%S")}
+    os.makedirs(OBJDIR, exist_ok=True)
+    json.dump(m, open(MANIFEST, "w"), indent=1, sort_keys=True)
+
+
 def _run(cmd):
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if p.returncode != 0:
@@ -71,10 +118,13 @@ def build_hip(verbose=False):
         src = os.path.join(CSRC, "hip", s)
         obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if _newer(obj, [src] + hdrs):
-            jobs.append([_hipcc()] + HIP_FLAGS + ["-c", src, "-o", obj])
+        cmd = [_hipcc()] + HIP_FLAGS + ["-c", src, "-o", obj]
+        stale, key, dg = _stale(obj, cmd, [src] + hdrs)
+        if stale:
+            jobs.append((cmd, key, dg))
     with cf.ThreadPoolExecutor(max_workers=max(1, min(4, len(jobs) or 1))) as ex:
-        for out in ex.map(_run, jobs):
+        for out, (cmd, key, dg) in zip(ex.map(_run, [j[0] for j in jobs]), jobs):
+            _record(key, dg)
             if verbose and out.strip():
                 print(out)
     so = os.path.join(LIBDIR, "libpopsift_hip.so")
@@ -95,8 +145,11 @@ def build_host(verbose=False):
         src = os.path.join(hostdir, s)
         obj = os.path.join(OBJDIR, "host_" + s.replace(".cpp", ".o"))
         objs.append(obj)
-        if _newer(obj, [src] + hdrs):
-            _run(["g++"] + HOST_FLAGS + ["-c", src, "-o", obj])
+        cmd = ["g++"] + HOST_FLAGS + ["-c", src, "-o", obj]
+        stale, key, dg = _stale(obj, cmd, [src] + hdrs + _headers(hostdir))
+        if stale:
+            _run(cmd)
+            _record(key, dg)
             rebuilt = True
     so = os.path.join(LIBDIR, "libpopsift.so")
     if rebuilt or not os.path.exists(so):
@@ -118,8 +171,12 @@ def build_host(verbose=False):
 
 
 def build_all(verbose=False):
+    LAST_BUILD["rebuilt"], LAST_BUILD["reused"] = [], []
     hip = build_hip(verbose)
     host = build_host(verbose)
+    if verbose:
+        print("rebuilt: %s" % (", ".join(LAST_BUILD["rebuilt"]) or "nothing"))
+        print("reused (content hash unchanged): %s" % (", ".join(LAST_BUILD["reused"]) or "nothing"))
     return hip, host
 
 

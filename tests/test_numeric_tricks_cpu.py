@@ -323,3 +323,57 @@ def test_two_bin_plateau_peaks_on_the_common_boundary():
     h3 = np.array([0.05] * 34 + [1.0, 1.0])                    # a plateau across the wrap-around neighbour
     pw = peaks(np.roll(h3, 1))
     assert len(pw) == 1 and abs(pw[0] - 35.5) < 1e-9
+
+
+def test_matcher_prefilter_margin_holds():
+    """match.hip k_match_mfma discards a pair when its approximate distance s = |l|^2 + |r|^2 - 2 <f16(2^k l), f16(2^k r)> / 4^k lies
+    more than 2 E_l above a running second-smallest s, with E_l = 0.00197 |l| Rmax + 2e-7 M (|l| + Rmax) + 4e-5 (|l|^2 + Rmax^2)
+    claimed to bound |s - d| for the float distance d of the reference's operation tree.  Replay in numpy -- float16
+    conversion (round to nearest even), also with every f16 denormal flushed to zero as a matrix unit may do, exact products,
+    float32 sums -- on the descriptor families of the GPU test: the worst |s - d| / E_l must stay below 1 (it sits near 0.3)."""
+    rng = np.random.default_rng(17)
+
+    def unit(n):
+        v = rng.random((n, 128), dtype=f32) ** 4
+        return np.sqrt(v / v.sum(1, keepdims=True)).astype(f32)
+
+    def tree(l, r):
+        """the reference's distance (features.cu:160-189): per float4 a left-to-right fma chain, then the 16/8/4/2/1 tree"""
+        q = (l[:, None, :] - r[None, :, :]).astype(f32).reshape(len(l), len(r), 32, 4)
+        p = (q[..., 1] * q[..., 1]).astype(f32)
+        for c in (0, 2, 3):
+            p = (q[..., c].astype(np.float64) * q[..., c].astype(np.float64) + p.astype(np.float64)).astype(f32)
+        for step in (16, 8, 4, 2, 1):
+            p = (p[..., :step] + p[..., step:2 * step]).astype(f32)
+        return p[..., 0]
+
+    families = [("random", rng.random((96, 128), dtype=f32), rng.random((160, 128), dtype=f32)),
+                ("unit", unit(96), unit(160)),
+                ("unit x 512", (unit(96) * f32(512)).astype(f32), (unit(160) * f32(512)).astype(f32)),
+                ("unit x 1e-9", (unit(96) * f32(1e-9)).astype(f32), (unit(160) * f32(1e-9)).astype(f32)),
+                ("unit x 1e9", (unit(96) * f32(1e9)).astype(f32), (unit(160) * f32(1e9)).astype(f32))]
+    l, r = unit(96), unit(160)
+    l[::3] *= f32(1e-4); r[::5] *= f32(1e-3); r[7] = l[4]; r[8] = l[4] + f32(1e-5)
+    families.append(("mixed norms + near duplicates", l, r))
+    sparse = unit(96); sparse[:, 16:] = 0; sparse = (sparse / np.linalg.norm(sparse, axis=1, keepdims=True)).astype(f32)
+    families.append(("sparse", sparse, unit(160)))
+    worst = 0.0
+    for name, l, r in families:
+        nl = (l.astype(np.float64) ** 2).sum(1).astype(f32); nr = (r.astype(np.float64) ** 2).sum(1).astype(f32)
+        M = f32(np.sqrt(max(nl.max(), nr.max()))); rmax2 = nr.max(); rmax = f32(np.sqrt(rmax2))
+        k = int(np.floor(np.log2(f32(16384.0) / M)))
+        sc = f32(2.0) ** k
+        d = tree(l, r).astype(np.float64)
+        for flush in (False, True):
+            lh, rh = (l * sc).astype(np.float16), (r * sc).astype(np.float16)
+            assert np.isfinite(lh).all() and np.isfinite(rh).all()
+            if flush:
+                lh = np.where(np.abs(lh) < np.float16(2.0 ** -14), np.float16(0), lh)
+                rh = np.where(np.abs(rh) < np.float16(2.0 ** -14), np.float16(0), rh)
+            dot = (lh.astype(f32) @ rh.astype(f32).T).astype(f32)                     # exact products, float32 accumulation
+            s = (nl[:, None].astype(np.float64) + (f32(-2.0) / (sc * sc)) * dot.astype(np.float64) + nr[None, :]).astype(f32)
+            E = (f32(0.00197) * np.sqrt(nl) * rmax + f32(2e-7) * M * (np.sqrt(nl) + rmax) + f32(4e-5) * (nl + rmax2)).astype(np.float64)
+            ratio = float((np.abs(s.astype(np.float64) - d) / E[:, None]).max())
+            worst = max(worst, ratio)
+            assert ratio < 1.0, (name, flush, ratio)
+    print("matcher prefilter: worst |s - d| / E_l = %.3f" % worst)
