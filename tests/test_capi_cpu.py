@@ -156,6 +156,21 @@ def test_cpp_host_library_api(tmp_path):
     assert "ALL OK" in out.stdout
 
 
+def test_cpp_host_pools(tmp_path):
+    """Compile and run tests/cpp/test_host_pool.cpp (internal header host_pool.h) against libpopsift.so: the size-ordered
+    free list returns the smallest adequate buffer, bounds how oversized a reused buffer may be, survives 8 threads, and the
+    NUMA helper leaves the affinity alone for devices it cannot resolve (no GPU involved: pageable pool only)."""
+    _host_lib()
+    exe = str(tmp_path / "test_host_pool")
+    libdir = os.path.join(ROOT, "popsift_amd", "lib")
+    cmd = ["g++", "-std=c++14", "-O1", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_host_pool.cpp"), "-o", exe,
+           "-I", os.path.join(ROOT, "popsift_amd", "csrc", "host"), "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "popsift_amd", "csrc", "include"), "-L", libdir, "-lpopsift", "-lpopsift_hip", "-Wl,-rpath," + libdir]
+    subprocess.check_call(cmd)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout
+
+
 def test_bench_algorithmic_bytes_match_the_survey():
     """bench.py's roofline numerators: separable-Gaussian stage 44 N0 + 48 sum N_o + input, whole image
     pipe 68 N0 + 72 sum N_o + input, for the 1080p workload (octave 0 = 3840 x 2160, 5 octaves)."""
