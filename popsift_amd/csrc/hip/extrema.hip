@@ -415,27 +415,35 @@ __global__ __launch_bounds__(NT) void k_extrema(const PsxParams* __restrict__ P,
 #endif
 }
 
-// Refinement of the queued candidates of ALL octaves in one launch: one wave per (octave, sub-list), one
-// candidate per lane, DoG values read from the Gaussian planes (L2 resident: the tile kernels have just
-// streamed them).  Survivors are compacted with a 64-bit wave ballot and one atomicAdd per wave
-// (wave64 re-design of extrema_count, s_extrema.cu:22-44).
-constexpr int REFINE_SPLIT = 2;       // waves per (octave, sub-list): 1, 2, 4, 8, 16 measured, extrema stage 0.112 / 0.106 / 0.109 / 0.128 / 0.133 ms
+// Refinement of the queued candidates of ALL octaves in one launch: one workgroup per (octave, sub-list), one
+// candidate per lane, DoG values read from the Gaussian planes.  Survivors are compacted with 64-bit wave ballots,
+// a prefix over the workgroup's waves and one atomicAdd per workgroup and round (wave64 re-design of extrema_count,
+// s_extrema.cu:22-44).
+// REFINE_NT threads per (octave, sub-list).  What this kernel costs is a chain -- list entry -> DoG values -> up to five Newton
+// steps of 19 dependent gathers each -> the slot in the octave's extremum array -- and the slot comes from ONE counter per
+// octave: same-address atomics serialise in the L2 (~100 ns each), so one atomic per wave and round (190 for the bench
+// frame's octave 0) set a floor however the candidates were spread: 1 / 2 / 4 / 8 / 16 one-wave blocks per list measured
+// 0.094 / 0.090 / 0.085 / 0.108 / 0.117 ms for the extrema stage.  Eight waves per list cover a list of the bench frame in
+// one round and take ONE slot range per workgroup and round: 64 / 128 / 256 / 512 / 1024 threads measured 0.087 / 0.088 /
+// 0.081 / 0.082 / 0.085 ms, the kernel 21.6 -> 17.2 us (profiles/r05_refine_ab.txt).  What is left is the chain itself.
+constexpr int REFINE_NT = 512;
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_refine(const PsxParams* __restrict__ P, PsxCounters* cnt)
+__global__ __launch_bounds__(REFINE_NT) void k_refine(const PsxParams* __restrict__ P, PsxCounters* cnt)
 {
-    // REFINE_SPLIT waves per (octave, sub-list); blockIdx.x = (octave * PSX_CAND_SUB + sub) * REFINE_SPLIT + part
-    const int lane = threadIdx.x;
-    const int list_id = blockIdx.x / REFINE_SPLIT, part = blockIdx.x % REFINE_SPLIT;
+    constexpr int NW = REFINE_NT / PSX_WAVE;
+    __shared__ int s_cnt[NW], s_base;
+    const int t = threadIdx.x, lane = t & (PSX_WAVE - 1), wave = t >> 6;
+    const int list_id = blockIdx.x;
     const int o = list_id / PSX_CAND_SUB, sub = list_id % PSX_CAND_SUB;
     const int NL = P->L - 1;
     const int n = min(P->cand_ct[list_id * 32], P->cand_capacity);
-    if (n <= part * PSX_WAVE) return;
+    if (n <= 0) return;
     const PsxOctave oc = P->oct[o];
     const unsigned long long* list = P->cand[o] + (size_t)sub * P->cand_capacity;
     const DogView dv{oc, nullptr, NL, -(1 << 30), -(1 << 30)};      // never "in tile": global reads
-    for (int e0 = part * PSX_WAVE; e0 < n; e0 += PSX_WAVE * REFINE_SPLIT) {
-        const int e = e0 + lane;
+    for (int e0 = 0; e0 < n; e0 += REFINE_NT) {
+        const int e = e0 + t;
         bool ok = false;
         psx_iext ec;
         if (e < n) {
@@ -445,19 +453,23 @@ __global__ __launch_bounds__(64) void k_refine(const PsxParams* __restrict__ P, 
             ok = refine<MODE>(P, dv, o, x, y, z, v, ec);
         }
         const unsigned long long mask = __ballot(ok);
-        if (mask != 0ull) {
-            const int leader = __ffsll((long long)mask) - 1;
-            int wbase = 0;
-            if (lane == leader) wbase = atomicAdd(&cnt->ext_ct[o], __popcll(mask));
-            wbase = __shfl(wbase, leader);
-            if (ok) {
-                const int idx = wbase + __popcll(mask & ((1ull << lane) - 1ull));
-                if (idx < P->max_extrema) {
-                    P->iext[o][idx] = ec;
-                    P->iext_off[o][idx] = idx;
-                }
+        if (lane == 0) s_cnt[wave] = __popcll(mask);
+        __syncthreads();
+        if (t == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) { const int c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
+            s_base = tot > 0 ? atomicAdd(&cnt->ext_ct[o], tot) : 0;
+        }
+        __syncthreads();
+        if (ok) {
+            const int idx = s_base + s_cnt[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+            if (idx < P->max_extrema) {
+                P->iext[o][idx] = ec;
+                P->iext_off[o][idx] = idx;
             }
         }
+        __syncthreads();                                   // the next round rewrites s_cnt / s_base
     }
 }
 
@@ -520,7 +532,7 @@ int psx_extrema_tiles(const PsxParams& hp, int octave)
 hipError_t psx_launch_refine(const PsxParams* d_params, const PsxParams& hp, PsxCounters* d_cnt, hipStream_t s)
 {
     if (hp.L - 3 < 1) return hipSuccess;
-    const dim3 grid(hp.num_octaves * PSX_CAND_SUB * REFINE_SPLIT), block(PSX_WAVE);
+    const dim3 grid(hp.num_octaves * PSX_CAND_SUB), block(REFINE_NT);
     switch (hp.sift_mode) {
     case PSX_MODE_VLFEAT: hipLaunchKernelGGL(k_refine<PSX_MODE_VLFEAT>, grid, block, 0, s, d_params, d_cnt); break;
     case PSX_MODE_OPENCV: hipLaunchKernelGGL(k_refine<PSX_MODE_OPENCV>, grid, block, 0, s, d_params, d_cnt); break;
