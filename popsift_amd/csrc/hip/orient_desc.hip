@@ -916,18 +916,242 @@ constexpr int ALT_BINS = 9;
 // one contribution into the lane's private bins (column `lane` of a [9][64] block)
 __device__ __forceinline__ void alt_add(float* bins, int lane, int b, float v) { bins[b * PSX_WAVE + lane] += v; }
 
-template <int MODE>
-__global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
+// The plane as these modes read it.  AltPlane: the clamped plane in HBM.  AltWindow: the part of it the workgroup staged in
+// LDS, addressed with UNCLAMPED coordinates -- entry (cx, cy) of the window holds plane[clamp(cy)][clamp(cx)], so the texel
+// pairs (i, i + 1) / (j, j + 1) of a bilinear fetch are neighbours in the window whatever the clamp did to them.
+struct AltPlane {
+    const float* p; int W, H, pitch;
+    __device__ __forceinline__ float at(int x, int y) const { return p[(size_t)psx_clampi(y, 0, H - 1) * pitch + psx_clampi(x, 0, W - 1)]; }
+    __device__ __forceinline__ void quad(int i, int j, float& p00, float& p01, float& p10, float& p11) const
+    {
+        const int i0 = psx_clampi(i, 0, W - 1), i1 = psx_clampi(i + 1, 0, W - 1);
+        const int j0 = psx_clampi(j, 0, H - 1), j1 = psx_clampi(j + 1, 0, H - 1);
+        p00 = p[(size_t)j0 * pitch + i0]; p01 = p[(size_t)j0 * pitch + i1];
+        p10 = p[(size_t)j1 * pitch + i0]; p11 = p[(size_t)j1 * pitch + i1];
+    }
+};
+struct AltWindow {
+    const float LDS_AS* w; int bx0, by0, bw;
+    __device__ __forceinline__ float at(int x, int y) const { return w[(y - by0) * bw + (x - bx0)]; }
+    __device__ __forceinline__ void quad(int i, int j, float& p00, float& p01, float& p10, float& p11) const
+    {
+        const float LDS_AS* q = w + ((j - by0) * bw + (i - bx0));
+        p00 = q[0]; p01 = q[1]; p10 = q[bw]; p11 = q[bw + 1];        // two ds_read2_b32
+    }
+};
+// the linear-filtered layered texture at (x, y) (1.8 fixed-point weights), as d_plane_linear
+template <class V>
+__device__ __forceinline__ float alt_linear(const V& v, float x, float y)
 {
+    const float xs = x + 0.5f, ys = y + 0.5f;
+    const float xb = xs - 0.5f, yb = ys - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    const float a = rintf((xb - fx) * 256.0f) * (1.0f / 256.0f);
+    const float b = rintf((yb - fy) * 256.0f) * (1.0f / 256.0f);
+    float p00, p01, p10, p11;
+    v.quad((int)fx, (int)fy, p00, p01, p10, p11);
+    return d_lerp(d_lerp(p00, p01, a), d_lerp(p10, p11, a), b);
+}
+// get_gradiant with the rotated stencil on the linear texture (s_gradiant.h:72-88); magnitude and angle as d_gradiant_rot
+template <class V>
+__device__ __forceinline__ void alt_gradiant_rot(const V& v, float& grad, float& theta, float x, float y, float cos_t, float sin_t)
+{
+    const float dx = alt_linear(v, x + cos_t, y + sin_t) - alt_linear(v, x - cos_t, y - sin_t);
+    const float dy = alt_linear(v, x - sin_t, y + cos_t) - alt_linear(v, x + sin_t, y - cos_t);
+    grad = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+    theta = fast_atan2(dy, dx);
+}
+// get_gradiant on the point texture at integer coordinates (s_gradiant.h:56-69)
+template <class V>
+__device__ __forceinline__ void alt_gradiant_pt(const V& v, float& grad, float& theta, int x, int y)
+{
+    const float dx = v.at(x + 1, y) - v.at(x - 1, y);
+    const float dy = v.at(x, y + 1) - v.at(x, y - 1);
+    grad = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+    theta = fast_atan2(dy, dx);
+}
+
+// Window staged per descriptor: every coordinate these modes read lies within E = 2.5 sqrt(2) SBP + 2.51 of the keypoint
+// (samples: the rotated square |step| <= 2.5 in units of SBP; + 1 for the gradient stencil; `grid` snaps a sample to a pixel,
+// + 0.5, through an (int) conversion, + 1; the bilinear fetch takes floor and floor + 1), i.e. integer coordinates
+// floor(x) - ceil(E) .. floor(x) + ceil(E) + 1.  84 x 84 texels hold SBP <= 10.8 = sigma <= 3.6, the largest a keypoint of a
+// three-level octave gets (sigma0 2^(3.5/3)); larger windows (more levels, larger sigma0) are read from the plane in HBM.
+constexpr int ALT_WIN_MAX = 84;
+constexpr int ALT_WIN_CAP = ALT_WIN_MAX * ALT_WIN_MAX;
+
+// The tiles of one wave.  The reference's 32- / 16- / 8-lane groups (one tile each) sit side by side in the wave: 2, 4 or 8
+// tiles per pass; the four waves of the workgroup split the passes (iloop: two each; grid / igrid: one each; notile: its two
+// passes x the two halves of the per-lane sample loop, the halves summed in the epilogue).
+template <int MODE, class V>
+__device__ __forceinline__ void alt_tiles(const V& v, float* bins, float* out, int lane, int wave,
+                                          float x, float y, float ang, float SBP, float cos_t, float sin_t)
+{
+    const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
+    if (MODE == PSX_DESC_ILOOP) {
+        // 32 lanes per tile, lane = j of the 32 x 32 sample grid, 2 tiles per pass
+        const int sub = lane & 31, half = lane >> 5;
+        for (int pass = wave * 2; pass < wave * 2 + 2; pass++) {
+            const int tz = pass * 2 + half;
+            const int ix = tz & 3, iy = tz >> 2;
+            const float offx = ix - 1.5f, offy = iy - 1.5f;
+            const float ptx = fmaf(csbp, offx, -ssbp * offy);
+            const float pty = fmaf(csbp, offy,  ssbp * offx);
+            const float bsz = fabsf(cos_t) + fabsf(sin_t);
+#pragma unroll
+            for (int b = 0; b < ALT_BINS; b++) bins[b * PSX_WAVE + lane] = 0.0f;
+            for (int i = 0; i < 32; i++) {
+                const float dx = (-bsz + sub * bsz / 16.0f);
+                const float dy = (-bsz + i * bsz / 16.0f);
+                const float nx = fmaf(cos_t, dx,  sin_t * dy);
+                const float ny = fmaf(cos_t, dy, -sin_t * dx);
+                const float nnx = fabsf(nx), nny = fabsf(ny);
+                if (nnx < 1.0f && nny < 1.0f) {
+                    const float jj = x + ptx + dx * SBP;
+                    const float ii = y + pty + dy * SBP;
+                    float mod, th;
+                    alt_gradiant_rot(v, mod, th, jj, ii, cos_t, sin_t);
+                    const float dnx = nx + offx, dny = ny + offy;
+                    const float ww = __builtin_amdgcn_exp2f((dnx * dnx + dny * dny) * (-0.125f * 1.4426950408889634f));
+                    const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod;
+                    th += (th <  0.0f  ? PI2_F : 0.0f);
+                    th -= (th >= PI2_F ? PI2_F : 0.0f);
+                    const float tth = th * M_4RPI_F;
+                    const int   fo0 = (int)floorf(tth);
+                    const float do0 = tth - fo0;
+                    const int   fo  = fo0 % 8;
+                    alt_add(bins, lane, fo, (1.0f - do0) * wgt);
+                    alt_add(bins, lane, fo + 1, do0 * wgt);
+                }
+            }
+            bins[lane] += bins[8 * PSX_WAVE + lane];                 // dpt[0] += dpt[8]
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                float s = bins[b * PSX_WAVE + lane];
+#pragma unroll
+                for (int d = 16; d >= 1; d >>= 1) s += __shfl_down(s, d, 32);
+                if (sub == 0) out[tz * 8 + b] = s;
+            }
+        }
+    } else if (MODE == PSX_DESC_GRID || MODE == PSX_DESC_IGRID) {
+        // 16 lanes per tile (lane = xd), 4 tiles per pass, 16 samples (yd) per lane
+        const int xd = lane & 15, q = lane >> 4;
+        const int tz = wave * 4 + q;
+        const int ix = tz & 3, iy = tz >> 2;
+        const float offx = ix - 1.5f, offy = iy - 1.5f;
+#pragma unroll
+        for (int b = 0; b < ALT_BINS; b++) bins[b * PSX_WAVE + lane] = 0.0f;
+        if (MODE == PSX_DESC_GRID) {
+            const float ptx = fmaf(csbp, offx, fmaf(-ssbp, offy, x));
+            const float pty = fmaf(csbp, offy, fmaf( ssbp, offx, y));
+            const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t;
+            const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;
+            const float usx = -sin_t / 8.0f, usy = cos_t / 8.0f;
+            for (int yd = 0; yd < 16; yd++) {
+                float pox = fmaf(yd + 0.5f, usx, fmaf(xd + 0.5f, rsx, ldx));
+                float poy = fmaf(yd + 0.5f, usy, fmaf(xd + 0.5f, rsy, ldy));
+                const float pix_x = roundf(fmaf(pox, SBP, ptx)) - ptx;
+                const float pix_y = roundf(fmaf(poy, SBP, pty)) - pty;
+                pox = pix_x / SBP; poy = pix_y / SBP;
+                float mod, th;
+                alt_gradiant_pt(v, mod, th, (int)(ptx + pix_x), (int)(pty + pix_y));
+                const float npx = fmaf(cos_t, pox,  sin_t * poy);
+                const float npy = fmaf(cos_t, poy, -sin_t * pox);
+                const float dnx = npx + offx, dny = npy + offy;
+                const float ww = __builtin_amdgcn_exp2f((dnx * dnx + dny * dny) * (-0.125f * 1.4426950408889634f));
+                const float wx = 1.0f - fabsf(npx), wy = 1.0f - fabsf(npy);
+                if (wx < 0.0f || wy < 0.0f) continue;
+                const float wgt = ww * wx * wy * mod;
+                th -= ang;
+                th += (th <  0.0f  ? PI2_F : 0.0f);
+                th -= (th >= PI2_F ? PI2_F : 0.0f);
+                const float tth = th * M_4RPI_F;
+                const int   fo0 = (int)floorf(tth);
+                const float do0 = tth - fo0;
+                const int   fo  = fo0 % 8;
+                alt_add(bins, lane, fo, (1.0f - do0) * wgt);
+                alt_add(bins, lane, fo + 1, do0 * wgt);
+            }
+            bins[lane] += bins[8 * PSX_WAVE + lane];
+        } else {
+            for (int yd = 0; yd < 16; yd++) {
+                const float stepx = ix - 2.5f + 1.0f / 16.0f + xd / 8.0f;
+                const float stepy = iy - 2.5f + 1.0f / 16.0f + yd / 8.0f;
+                const float ptx = fmaf(cos_t, stepx, -sin_t * stepy);
+                const float pty = fmaf(cos_t, stepy,  sin_t * stepx);
+                float mod, th;
+                alt_gradiant_rot(v, mod, th, fmaf(ptx, SBP, x), fmaf(pty, SBP, y), cos_t, sin_t);
+                th += (th <  0.0f  ? PI2_F : 0.0f);
+                th -= (th >= PI2_F ? PI2_F : 0.0f);
+                const float ww = desc_gauss_entry(iy * 8 + yd, ix * 8 + xd);
+                const float wgt = ww * desc_tile_entry(xd) * desc_tile_entry(yd) * mod;
+                const float tth = th * M_4RPI_F;
+                const int   fo  = (int)floorf(tth);
+                const float do0 = tth - fo;
+                alt_add(bins, lane, (fo + 1) & 7, wgt * do0);
+                alt_add(bins, lane, fo & 7, wgt * (1.0f - do0));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            float s = bins[b * PSX_WAVE + lane];
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) s += __shfl_down(s, d, 16);
+            if (xd == 0) out[tz * 8 + b] = s;
+        }
+    } else {
+        // notile: threads (tx 0..31, ty 0..3) of the reference = 2 passes of a wave64; wave = (pass, half of the xoff loop)
+        const int tx = lane & 31, in_x = tx & 7;
+        const float stepbase = -2.5f + 1.0f / 16.0f;
+        const int pass = wave >> 1, xoff = wave & 1;
+        const int out_y = pass * 2 + (lane >> 5);
+#pragma unroll
+        for (int b = 0; b < 8; b++) bins[b * PSX_WAVE + lane] = 0.0f;
+        const int xd = (xoff << 3) + in_x;
+        const int newx = (xoff << 3) + tx;
+        for (int yd = 0; yd < 16; yd++) {
+            const int newy = (out_y << 3) + yd;
+            const float wgt = desc_tile_entry(xd) * desc_tile_entry(yd);
+            const float stepx = stepbase + ldexpf((float)newx, -3);
+            const float stepy = stepbase + ldexpf((float)newy, -3);
+            const float ptx = fmaf(cos_t, stepx, -sin_t * stepy);
+            const float pty = fmaf(cos_t, stepy,  sin_t * stepx);
+            float mod, th;
+            alt_gradiant_rot(v, mod, th, fmaf(ptx, SBP, x), fmaf(pty, SBP, y), cos_t, sin_t);
+            th += (th < 0.0f ? PI2_F : 0.0f);
+            const float tth = th * M_4RPI_F;
+            const int   fo  = (int)floorf(tth);
+            const float do0 = tth - fo;
+            const int fo0 = fo & 7, fo1 = (fo0 + 1) & 7;
+            const float ww = desc_gauss_entry(newy, newx) * mod;
+            alt_add(bins, lane, fo0, wgt * ((1.0f - do0) * ww));
+            alt_add(bins, lane, fo1, wgt * (do0 * ww));
+        }
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            float s = bins[b * PSX_WAVE + lane];
+#pragma unroll
+            for (int d = 4; d >= 1; d >>= 1) s += __shfl_down(s, d, 8);
+            if (in_x == 0) out[xoff * 128 + out_y * 32 + (tx >> 3) * 8 + b] = s;
+        }
+    }
+}
+
+// One WORKGROUP per descriptor (round 5; before: one wave per descriptor reading the plane in HBM).  These modes take 4096
+// (igrid, notile), ~8000 (iloop) or 4096 (grid) samples per descriptor and every sample is four bilinear fetches = 16 texels
+// (grid: 4): as 64-address gathers on the plane they kept the texture-address path busy for 1.4 ms per 1080p frame.  The
+// workgroup stages the window once (coalesced rows, clamped as the texture clamps), the four waves split the tiles and fetch
+// from LDS (two ds_read2_b32 per bilinear fetch).  Same samples, same order within a wave, same arithmetic.
+template <int MODE>
+__global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X, const int use_window)
+{
+    __shared__ __attribute__((aligned(16))) float s_win[ALT_WIN_CAP];
     __shared__ float s_bins[WPB][ALT_BINS * PSX_WAVE];
-    __shared__ float s_out[WPB][128];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ float s_out[256];                 // [2][128]: notile sums two halves, the others use the first
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     float* bins = s_bins[wave];
-    float* out = s_out[wave];
 
     const int total = cnt->ori_total;
-    const int nwaves = gridDim.x * WPB;
-    for (int jv = blockIdx.x * WPB + wave; jv < total; jv += nwaves) {
+    for (int jv = blockIdx.x; jv < total; jv += gridDim.x) {
         const int j = __builtin_amdgcn_readfirstlane(jv);
         const int ext_idx = P->feat_to_ext[j];
         const psx_extremum ex = P->extrema[ext_idx];
@@ -935,177 +1159,40 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
         const float ang = ori_num == 0 ? ex.orientation[0] : ori_num == 1 ? ex.orientation[1] : ori_num == 2 ? ex.orientation[2] : ex.orientation[3];   // no scratch copy of ex
         const PsxOctave oc = P->oct[ex.octave];
         const int W = oc.w, H = oc.h, pitch = oc.pitch;
-        if (ori_num == 0 && lane == 0) write_feature(P, X, ext_idx, ex, ex.idx_ori, total);
+        if (ori_num == 0 && t == 0) write_feature(P, X, ext_idx, ex, ex.idx_ori, total);
 
         const float x = ex.xpos, y = ex.ypos;
         const float* plane = oc.data + (size_t)psx_clampi(ex.lpos, 0, P->L - 1) * oc.plane;
         const float SBP = fabsf(DESC_MAGNIFY * ex.sigma);
-        for (int i = lane; i < 128; i += PSX_WAVE) out[i] = 0.0f;
-        wave_fence();
+        s_out[t] = 0.0f;
+
+        const int Ei = (int)ceilf(fmaf(3.5356f, SBP, 2.51f));
+        const int bw = 2 * Ei + 2;
+        const int bx0 = (int)floorf(x) - Ei, by0 = (int)floorf(y) - Ei;
+        const bool windowed = use_window != 0 && SBP < 64.0f && bw <= ALT_WIN_MAX;
+        if (windowed && SBP != 0.0f) {
+            for (int r = wave; r < bw; r += WPB) {
+                const float* row = plane + (size_t)psx_clampi(by0 + r, 0, H - 1) * pitch;
+                for (int c = lane; c < bw; c += PSX_WAVE) s_win[r * bw + c] = row[psx_clampi(bx0 + c, 0, W - 1)];
+            }
+        }
+        __syncthreads();
 
         if (SBP != 0.0f) {
             // __sincosf in the reference.  GRID snaps its sample points through (int)(pt + (round(pt + pix) - pt)), which
             // flips on the last bit of sin / cos: that mode evaluates them in double and rounds once, as the oracle does
             const float cos_t = MODE == PSX_DESC_GRID ? (float)cos((double)ang) : cosf(ang);
             const float sin_t = MODE == PSX_DESC_GRID ? (float)sin((double)ang) : sinf(ang);
-            const float csbp = cos_t * SBP, ssbp = sin_t * SBP;
-
-            if (MODE == PSX_DESC_ILOOP) {
-                // 32 lanes per tile, lane = j of the 32 x 32 sample grid, 2 tiles per pass
-                const int sub = lane & 31, half = lane >> 5;
-                for (int pass = 0; pass < 8; pass++) {
-                    const int tz = pass * 2 + half;
-                    const int ix = tz & 3, iy = tz >> 2;
-                    const float offx = ix - 1.5f, offy = iy - 1.5f;
-                    const float ptx = fmaf(csbp, offx, -ssbp * offy);
-                    const float pty = fmaf(csbp, offy,  ssbp * offx);
-                    const float bsz = fabsf(cos_t) + fabsf(sin_t);
-#pragma unroll
-                    for (int b = 0; b < ALT_BINS; b++) bins[b * PSX_WAVE + lane] = 0.0f;
-                    for (int i = 0; i < 32; i++) {
-                        const float dx = (-bsz + sub * bsz / 16.0f);
-                        const float dy = (-bsz + i * bsz / 16.0f);
-                        const float nx = fmaf(cos_t, dx,  sin_t * dy);
-                        const float ny = fmaf(cos_t, dy, -sin_t * dx);
-                        const float nnx = fabsf(nx), nny = fabsf(ny);
-                        if (nnx < 1.0f && nny < 1.0f) {
-                            const float jj = x + ptx + dx * SBP;
-                            const float ii = y + pty + dy * SBP;
-                            float mod, th;
-                            d_gradiant_rot(mod, th, jj, ii, cos_t, sin_t, plane, W, H, pitch);
-                            const float dnx = nx + offx, dny = ny + offy;
-                            const float ww = __builtin_amdgcn_exp2f((dnx * dnx + dny * dny) * (-0.125f * 1.4426950408889634f));
-                            const float wgt = ww * (1.0f - nnx) * (1.0f - nny) * mod;
-                            th += (th <  0.0f  ? PI2_F : 0.0f);
-                            th -= (th >= PI2_F ? PI2_F : 0.0f);
-                            const float tth = th * M_4RPI_F;
-                            const int   fo0 = (int)floorf(tth);
-                            const float do0 = tth - fo0;
-                            const int   fo  = fo0 % 8;
-                            alt_add(bins, lane, fo, (1.0f - do0) * wgt);
-                            alt_add(bins, lane, fo + 1, do0 * wgt);
-                        }
-                    }
-                    bins[lane] += bins[8 * PSX_WAVE + lane];                 // dpt[0] += dpt[8]
-#pragma unroll
-                    for (int b = 0; b < 8; b++) {
-                        float v = bins[b * PSX_WAVE + lane];
-#pragma unroll
-                        for (int d = 16; d >= 1; d >>= 1) v += __shfl_down(v, d, 32);
-                        if (sub == 0) out[tz * 8 + b] = v;
-                    }
-                }
-            } else if (MODE == PSX_DESC_GRID || MODE == PSX_DESC_IGRID) {
-                // 16 lanes per tile (lane = xd), 4 tiles per pass, 16 samples (yd) per lane
-                const int xd = lane & 15, q = lane >> 4;
-                for (int pass = 0; pass < 4; pass++) {
-                    const int tz = pass * 4 + q;
-                    const int ix = tz & 3, iy = tz >> 2;
-                    const float offx = ix - 1.5f, offy = iy - 1.5f;
-#pragma unroll
-                    for (int b = 0; b < ALT_BINS; b++) bins[b * PSX_WAVE + lane] = 0.0f;
-                    if (MODE == PSX_DESC_GRID) {
-                        const float ptx = fmaf(csbp, offx, fmaf(-ssbp, offy, x));
-                        const float pty = fmaf(csbp, offy, fmaf( ssbp, offx, y));
-                        const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t;
-                        const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;
-                        const float usx = -sin_t / 8.0f, usy = cos_t / 8.0f;
-                        for (int yd = 0; yd < 16; yd++) {
-                            float pox = fmaf(yd + 0.5f, usx, fmaf(xd + 0.5f, rsx, ldx));
-                            float poy = fmaf(yd + 0.5f, usy, fmaf(xd + 0.5f, rsy, ldy));
-                            const float pix_x = roundf(fmaf(pox, SBP, ptx)) - ptx;
-                            const float pix_y = roundf(fmaf(poy, SBP, pty)) - pty;
-                            pox = pix_x / SBP; poy = pix_y / SBP;
-                            float mod, th;
-                            d_gradiant_pt(mod, th, (int)(ptx + pix_x), (int)(pty + pix_y), plane, W, H, pitch);
-                            const float npx = fmaf(cos_t, pox,  sin_t * poy);
-                            const float npy = fmaf(cos_t, poy, -sin_t * pox);
-                            const float dnx = npx + offx, dny = npy + offy;
-                            const float ww = __builtin_amdgcn_exp2f((dnx * dnx + dny * dny) * (-0.125f * 1.4426950408889634f));
-                            const float wx = 1.0f - fabsf(npx), wy = 1.0f - fabsf(npy);
-                            if (wx < 0.0f || wy < 0.0f) continue;
-                            const float wgt = ww * wx * wy * mod;
-                            th -= ang;
-                            th += (th <  0.0f  ? PI2_F : 0.0f);
-                            th -= (th >= PI2_F ? PI2_F : 0.0f);
-                            const float tth = th * M_4RPI_F;
-                            const int   fo0 = (int)floorf(tth);
-                            const float do0 = tth - fo0;
-                            const int   fo  = fo0 % 8;
-                            alt_add(bins, lane, fo, (1.0f - do0) * wgt);
-                            alt_add(bins, lane, fo + 1, do0 * wgt);
-                        }
-                        bins[lane] += bins[8 * PSX_WAVE + lane];
-                    } else {
-                        for (int yd = 0; yd < 16; yd++) {
-                            const float stepx = ix - 2.5f + 1.0f / 16.0f + xd / 8.0f;
-                            const float stepy = iy - 2.5f + 1.0f / 16.0f + yd / 8.0f;
-                            const float ptx = fmaf(cos_t, stepx, -sin_t * stepy);
-                            const float pty = fmaf(cos_t, stepy,  sin_t * stepx);
-                            float mod, th;
-                            d_gradiant_rot(mod, th, fmaf(ptx, SBP, x), fmaf(pty, SBP, y), cos_t, sin_t, plane, W, H, pitch);
-                            th += (th <  0.0f  ? PI2_F : 0.0f);
-                            th -= (th >= PI2_F ? PI2_F : 0.0f);
-                            const float ww = desc_gauss_entry(iy * 8 + yd, ix * 8 + xd);
-                            const float wgt = ww * desc_tile_entry(xd) * desc_tile_entry(yd) * mod;
-                            const float tth = th * M_4RPI_F;
-                            const int   fo  = (int)floorf(tth);
-                            const float do0 = tth - fo;
-                            alt_add(bins, lane, (fo + 1) & 7, wgt * do0);
-                            alt_add(bins, lane, fo & 7, wgt * (1.0f - do0));
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; b++) {
-                        float v = bins[b * PSX_WAVE + lane];
-#pragma unroll
-                        for (int d = 8; d >= 1; d >>= 1) v += __shfl_down(v, d, 16);
-                        if (xd == 0) out[tz * 8 + b] = v;
-                    }
-                }
-            } else {
-                // notile: threads (tx 0..31, ty 0..3) of the reference = 2 passes of a wave64
-                const int tx = lane & 31, in_x = tx & 7;
-                const float stepbase = -2.5f + 1.0f / 16.0f;
-                for (int pass = 0; pass < 2; pass++) {
-                    const int out_y = pass * 2 + (lane >> 5);
-#pragma unroll
-                    for (int b = 0; b < 8; b++) bins[b * PSX_WAVE + lane] = 0.0f;
-                    for (int xoff = 0; xoff < 2; xoff++) {
-                        const int xd = (xoff << 3) + in_x;
-                        const int newx = (xoff << 3) + tx;
-                        for (int yd = 0; yd < 16; yd++) {
-                            const int newy = (out_y << 3) + yd;
-                            const float wgt = desc_tile_entry(xd) * desc_tile_entry(yd);
-                            const float stepx = stepbase + ldexpf((float)newx, -3);
-                            const float stepy = stepbase + ldexpf((float)newy, -3);
-                            const float ptx = fmaf(cos_t, stepx, -sin_t * stepy);
-                            const float pty = fmaf(cos_t, stepy,  sin_t * stepx);
-                            float mod, th;
-                            d_gradiant_rot(mod, th, fmaf(ptx, SBP, x), fmaf(pty, SBP, y), cos_t, sin_t, plane, W, H, pitch);
-                            th += (th < 0.0f ? PI2_F : 0.0f);
-                            const float tth = th * M_4RPI_F;
-                            const int   fo  = (int)floorf(tth);
-                            const float do0 = tth - fo;
-                            const int fo0 = fo & 7, fo1 = (fo0 + 1) & 7;
-                            const float ww = desc_gauss_entry(newy, newx) * mod;
-                            alt_add(bins, lane, fo0, wgt * ((1.0f - do0) * ww));
-                            alt_add(bins, lane, fo1, wgt * (do0 * ww));
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < 8; b++) {
-                        float v = bins[b * PSX_WAVE + lane];
-#pragma unroll
-                        for (int d = 4; d >= 1; d >>= 1) v += __shfl_down(v, d, 8);
-                        if (in_x == 0) out[out_y * 32 + (tx >> 3) * 8 + b] = v;
-                    }
-                }
-            }
+            if (windowed) alt_tiles<MODE>(AltWindow{(const float LDS_AS*)s_win, bx0, by0, bw}, bins, s_out, lane, wave, x, y, ang, SBP, cos_t, sin_t);
+            else          alt_tiles<MODE>(AltPlane{plane, W, H, pitch}, bins, s_out, lane, wave, x, y, ang, SBP, cos_t, sin_t);
         }
-        wave_fence();
-        normalize_store(P, X, j, lane, out[2 * lane], out[2 * lane + 1]);
-        wave_fence();
+        __syncthreads();
+        if (wave == 0) {
+            float a = s_out[2 * lane], b = s_out[2 * lane + 1];
+            if (MODE == PSX_DESC_NOTILE) { a += s_out[128 + 2 * lane]; b += s_out[128 + 2 * lane + 1]; }
+            normalize_store(P, X, j, lane, a, b);
+        }
+        __syncthreads();                                   // s_out and the window are rewritten for the next descriptor
     }
 }
 
@@ -1125,12 +1212,16 @@ hipError_t psx_launch_scan(const PsxParams* d_params, PsxCounters* d_cnt, const 
 
 hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounters* d_cnt, int desc_mode, const PsxExport& x, int cus, hipStream_t s)
 {
-    const dim3 grid(cus > 0 ? 8 * cus : 2048), block(NT);
+    // 4 workgroups (38 KB of LDS each) are resident per CU; the workgroups loop over the descriptors
+    static const int per_cu = [] { const char* e = getenv("POPSIFT_ALT_WGS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 8; }();
+    // POPSIFT_ALT_WINDOW=0: measurement / test switch, every texel from the plane in HBM (what large-sigma keypoints do anyway)
+    static const int win = [] { const char* e = getenv("POPSIFT_ALT_WINDOW"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
+    const dim3 grid((cus > 0 ? cus : 256) * per_cu), block(NT);
     switch (desc_mode) {
-    case PSX_DESC_ILOOP:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_ILOOP>, grid, block, 0, s, d_params, d_cnt, x); break;
-    case PSX_DESC_GRID:   hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_GRID>, grid, block, 0, s, d_params, d_cnt, x); break;
-    case PSX_DESC_IGRID:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_IGRID>, grid, block, 0, s, d_params, d_cnt, x); break;
-    case PSX_DESC_NOTILE: hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_NOTILE>, grid, block, 0, s, d_params, d_cnt, x); break;
+    case PSX_DESC_ILOOP:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_ILOOP>, grid, block, 0, s, d_params, d_cnt, x, win); break;
+    case PSX_DESC_GRID:   hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_GRID>, grid, block, 0, s, d_params, d_cnt, x, win); break;
+    case PSX_DESC_IGRID:  hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_IGRID>, grid, block, 0, s, d_params, d_cnt, x, win); break;
+    case PSX_DESC_NOTILE: hipLaunchKernelGGL(k_descriptors_alt<PSX_DESC_NOTILE>, grid, block, 0, s, d_params, d_cnt, x, win); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

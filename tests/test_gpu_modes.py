@@ -125,3 +125,20 @@ def test_alternative_modes_match_reference_golden(capi, name):
     else:
         assert_parity(m, what=name, **budget(len(fa)))
     ctx.close()
+
+
+def test_alt_descriptor_window_equals_plane():
+    """k_descriptors_alt reads a window of the plane it staged in LDS; keypoints whose window exceeds 84 x 84 texels read the
+    plane in HBM.  Both must give the same bits: every mode, windows over the image border, a configuration whose large
+    keypoints take the plane path (the digest is over the sorted descriptor rows: the order of the features is not fixed)."""
+    import json, os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for win in ("1", "0"):
+        p = subprocess.run([sys.executable, os.path.join(here, "alt_window_worker.py")], capture_output=True, text=True,
+                           env=dict(os.environ, POPSIFT_ALT_WINDOW=win), timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[win] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(res["1"]) == 12 and all(r["n"] > 50 for r in res["1"])
+    for a, b in zip(res["1"], res["0"]):
+        assert a == b, (a, b)
