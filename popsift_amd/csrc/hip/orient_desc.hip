@@ -876,42 +876,6 @@ __device__ __forceinline__ float desc_tile_entry(int i)
 // model of the linear-filtered layered texture (1.8 fixed-point weights), as in pyramid_alt.hip.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float d_lerp(float p, float q, float a) { return fmaf(a, q, (1.0f - a) * p); }
-__device__ __forceinline__ float d_plane_linear(const float* p, int W, int H, int pitch, float x, float y)
-{
-    const float xs = x + 0.5f, ys = y + 0.5f;
-    const float xb = xs - 0.5f, yb = ys - 0.5f;
-    const float fx = floorf(xb), fy = floorf(yb);
-    const float a = rintf((xb - fx) * 256.0f) * (1.0f / 256.0f);
-    const float b = rintf((yb - fy) * 256.0f) * (1.0f / 256.0f);
-    const int i = (int)fx, jj = (int)fy;
-    const int i0 = psx_clampi(i, 0, W - 1), i1 = psx_clampi(i + 1, 0, W - 1);
-    const int j0 = psx_clampi(jj, 0, H - 1), j1 = psx_clampi(jj + 1, 0, H - 1);
-    const float r0 = d_lerp(p[(size_t)j0 * pitch + i0], p[(size_t)j0 * pitch + i1], a);
-    const float r1 = d_lerp(p[(size_t)j1 * pitch + i0], p[(size_t)j1 * pitch + i1], a);
-    return d_lerp(r0, r1, b);
-}
-// get_gradiant with the rotated stencil on the linear texture (s_gradiant.h:72-88)
-__device__ __forceinline__ void d_gradiant_rot(float& grad, float& theta, float x, float y, float cos_t, float sin_t,
-                                               const float* plane, int W, int H, int pitch)
-{
-    const float dx = d_plane_linear(plane, W, H, pitch, x + cos_t, y + sin_t) - d_plane_linear(plane, W, H, pitch, x - cos_t, y - sin_t);
-    const float dy = d_plane_linear(plane, W, H, pitch, x - sin_t, y + cos_t) - d_plane_linear(plane, W, H, pitch, x + sin_t, y - cos_t);
-    // magnitude and angle only SCALE / interpolate a contribution (bin weights are continuous in the angle): v_sqrt_f32 and the
-    // degree-13 atan polynomial (3.3e-7 rad) of the default kernel instead of hypotf and a double-precision atan2 (round 5:
-    // the f64 atan2 alone was most of these kernels' instructions)
-    grad = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
-    theta = fast_atan2(dy, dx);
-}
-// get_gradiant on the point texture at integer coordinates (s_gradiant.h:56-69)
-__device__ __forceinline__ void d_gradiant_pt(float& grad, float& theta, int x, int y, const float* plane, int W, int H, int pitch)
-{
-    auto rd = [&](int xx, int yy) { return plane[(size_t)psx_clampi(yy, 0, H - 1) * pitch + psx_clampi(xx, 0, W - 1)]; };
-    const float dx = rd(x + 1, y) - rd(x - 1, y);
-    const float dy = rd(x, y + 1) - rd(x, y - 1);
-    grad = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
-    theta = fast_atan2(dy, dx);
-}
-
 constexpr int ALT_BINS = 9;
 // one contribution into the lane's private bins (column `lane` of a [9][64] block)
 __device__ __forceinline__ void alt_add(float* bins, int lane, int b, float v) { bins[b * PSX_WAVE + lane] += v; }
@@ -922,42 +886,72 @@ __device__ __forceinline__ void alt_add(float* bins, int lane, int b, float v) {
 struct AltPlane {
     const float* p; int W, H, pitch;
     __device__ __forceinline__ float at(int x, int y) const { return p[(size_t)psx_clampi(y, 0, H - 1) * pitch + psx_clampi(x, 0, W - 1)]; }
-    __device__ __forceinline__ void quad(int i, int j, float& p00, float& p01, float& p10, float& p11) const
+    // the 2 x 2 texels at (i, j) = (fx, fy), integers held as floats
+    __device__ __forceinline__ void quad(float fx, float fy, float& p00, float& p01, float& p10, float& p11) const
     {
+        const int i = (int)fx, j = (int)fy;
         const int i0 = psx_clampi(i, 0, W - 1), i1 = psx_clampi(i + 1, 0, W - 1);
         const int j0 = psx_clampi(j, 0, H - 1), j1 = psx_clampi(j + 1, 0, H - 1);
         p00 = p[(size_t)j0 * pitch + i0]; p01 = p[(size_t)j0 * pitch + i1];
         p10 = p[(size_t)j1 * pitch + i0]; p11 = p[(size_t)j1 * pitch + i1];
     }
 };
+// Rows of the window are ALT_WIN_MAX texels apart whatever its size: the texel below is an immediate offset of the same
+// ds_read2_b32.  The byte address of texel (i, j) is formed in FLOAT, 4 i + 336 j + c with c = the window's LDS address
+// - 4 (bx0 + 84 by0): all terms are integers below 2^24 (the kernel checks the plane's height), so two fma and one conversion
+// replace two conversions, two subtractions, a quarter-rate integer multiply, two shifts and an add.
+constexpr int ALT_WIN_MAX = 84;
+constexpr int ALT_WIN_CAP = ALT_WIN_MAX * ALT_WIN_MAX;
 struct AltWindow {
-    const float LDS_AS* w; int bx0, by0, bw;
-    __device__ __forceinline__ float at(int x, int y) const { return w[(y - by0) * bw + (x - bx0)]; }
-    __device__ __forceinline__ void quad(int i, int j, float& p00, float& p01, float& p10, float& p11) const
+    const float LDS_AS* w; int bx0, by0; float c4;
+    __device__ __forceinline__ float at(int x, int y) const { return w[(y - by0) * ALT_WIN_MAX + (x - bx0)]; }
+    __device__ __forceinline__ void quad(float fx, float fy, float& p00, float& p01, float& p10, float& p11) const
     {
-        const float LDS_AS* q = w + ((j - by0) * bw + (i - bx0));
-        p00 = q[0]; p01 = q[1]; p10 = q[bw]; p11 = q[bw + 1];        // two ds_read2_b32
+        const unsigned addr = (unsigned)(int)fmaf(fy, 4.0f * ALT_WIN_MAX, fmaf(fx, 4.0f, c4));
+        const float LDS_AS* q = (const float LDS_AS*)addr;
+        p00 = q[0]; p01 = q[1]; p10 = q[ALT_WIN_MAX]; p11 = q[ALT_WIN_MAX + 1];        // two ds_read2_b32
     }
 };
-// the linear-filtered layered texture at (x, y) (1.8 fixed-point weights), as d_plane_linear
-template <class V>
-__device__ __forceinline__ float alt_linear(const V& v, float x, float y)
+// The linear-filtered layered texture at p = (x, y): texel centres at integer + 0.5, 1.8 fixed-point weights (the software
+// model of pyramid_alt.hip), the two axes side by side in packed f32 instructions.  In two halves, so that a caller can put
+// the texel reads of several fetches in flight before the first interpolation.
+struct AltTap { v2f f, ab; };
+__device__ __forceinline__ AltTap alt_tap(v2f p)
 {
-    const float xs = x + 0.5f, ys = y + 0.5f;
-    const float xb = xs - 0.5f, yb = ys - 0.5f;
-    const float fx = floorf(xb), fy = floorf(yb);
-    const float a = rintf((xb - fx) * 256.0f) * (1.0f / 256.0f);
-    const float b = rintf((yb - fy) * 256.0f) * (1.0f / 256.0f);
-    float p00, p01, p10, p11;
-    v.quad((int)fx, (int)fy, p00, p01, p10, p11);
-    return d_lerp(d_lerp(p00, p01, a), d_lerp(p10, p11, a), b);
+    const v2f ps = p + splat(0.5f);
+    const v2f pb = ps - splat(0.5f);
+    AltTap t;
+    t.f = (v2f){floorf(pb.x), floorf(pb.y)};
+    const v2f fr = (pb - t.f) * splat(256.0f);
+    t.ab = (v2f){rintf(fr.x), rintf(fr.y)} * splat(1.0f / 256.0f);
+    return t;
 }
-// get_gradiant with the rotated stencil on the linear texture (s_gradiant.h:72-88); magnitude and angle as d_gradiant_rot
+// d_lerp(p, q, a) = fma(a, q, (1 - a) * p) on both rows at once, then between the rows
+__device__ __forceinline__ float alt_blend(const AltTap& t, const float (&q)[4])
+{
+    const float na = 1.0f - t.ab.x;
+    const v2f r = pk_fma(splat(t.ab.x), (v2f){q[1], q[3]}, splat(na) * (v2f){q[0], q[2]});
+    return fmaf(t.ab.y, r.y, (1.0f - t.ab.y) * r.x);
+}
+// get_gradiant with the rotated stencil on the linear texture (s_gradiant.h:72-88).  Magnitude and angle only SCALE /
+// interpolate a contribution (bin weights are continuous in the angle): v_sqrt_f32 and the degree-13 atan polynomial of
+// the default kernel instead of hypotf and a double-precision atan2.
 template <class V>
 __device__ __forceinline__ void alt_gradiant_rot(const V& v, float& grad, float& theta, float x, float y, float cos_t, float sin_t)
 {
-    const float dx = alt_linear(v, x + cos_t, y + sin_t) - alt_linear(v, x - cos_t, y - sin_t);
-    const float dy = alt_linear(v, x - sin_t, y + cos_t) - alt_linear(v, x + sin_t, y - cos_t);
+    const v2f p = (v2f){x, y}, cs = (v2f){cos_t, sin_t}, sc = (v2f){-sin_t, cos_t};
+    // (x + cos, y + sin), (x - cos, y - sin), (x - sin, y + cos), (x + sin, y - cos)
+    const AltTap t0 = alt_tap(p + cs), t1 = alt_tap(p - cs), t2 = alt_tap(p + sc), t3 = alt_tap(p - sc);
+    float q0[4], q1[4], q2[4], q3[4];
+    v.quad(t0.f.x, t0.f.y, q0[0], q0[1], q0[2], q0[3]);
+    v.quad(t1.f.x, t1.f.y, q1[0], q1[1], q1[2], q1[3]);
+    v.quad(t2.f.x, t2.f.y, q2[0], q2[1], q2[2], q2[3]);
+    v.quad(t3.f.x, t3.f.y, q3[0], q3[1], q3[2], q3[3]);
+    // all sixteen texels before the first use (otherwise each fetch is waited for on its own: four LDS round trips per sample)
+    asm volatile("" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]));
+    asm volatile("" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]), "+v"(q3[0]), "+v"(q3[1]), "+v"(q3[2]), "+v"(q3[3]));
+    const float dx = alt_blend(t0, q0) - alt_blend(t1, q1);
+    const float dy = alt_blend(t2, q2) - alt_blend(t3, q3);
     grad = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
     theta = fast_atan2(dy, dx);
 }
@@ -976,8 +970,6 @@ __device__ __forceinline__ void alt_gradiant_pt(const V& v, float& grad, float& 
 // + 0.5, through an (int) conversion, + 1; the bilinear fetch takes floor and floor + 1), i.e. integer coordinates
 // floor(x) - ceil(E) .. floor(x) + ceil(E) + 1.  84 x 84 texels hold SBP <= 10.8 = sigma <= 3.6, the largest a keypoint of a
 // three-level octave gets (sigma0 2^(3.5/3)); larger windows (more levels, larger sigma0) are read from the plane in HBM.
-constexpr int ALT_WIN_MAX = 84;
-constexpr int ALT_WIN_CAP = ALT_WIN_MAX * ALT_WIN_MAX;
 
 // The tiles of one wave.  The reference's 32- / 16- / 8-lane groups (one tile each) sit side by side in the wave: 2, 4 or 8
 // tiles per pass; the four waves of the workgroup split the passes (iloop: two each; grid / igrid: one each; notile: its two
@@ -1018,7 +1010,7 @@ __device__ __forceinline__ void alt_tiles(const V& v, float* bins, float* out, i
                     const float tth = th * M_4RPI_F;
                     const int   fo0 = (int)floorf(tth);
                     const float do0 = tth - fo0;
-                    const int   fo  = fo0 % 8;
+                    const int   fo  = fo0 & 7;                  // th in [0, 2 pi): fo0 in 0..8
                     alt_add(bins, lane, fo, (1.0f - do0) * wgt);
                     alt_add(bins, lane, fo + 1, do0 * wgt);
                 }
@@ -1046,12 +1038,13 @@ __device__ __forceinline__ void alt_tiles(const V& v, float* bins, float* out, i
             const float ldx = -cos_t + sin_t, ldy = -cos_t - sin_t;
             const float rsx = cos_t / 8.0f, rsy = sin_t / 8.0f;
             const float usx = -sin_t / 8.0f, usy = cos_t / 8.0f;
+            const float rsbp = __builtin_amdgcn_rcpf(SBP);
             for (int yd = 0; yd < 16; yd++) {
                 float pox = fmaf(yd + 0.5f, usx, fmaf(xd + 0.5f, rsx, ldx));
                 float poy = fmaf(yd + 0.5f, usy, fmaf(xd + 0.5f, rsy, ldy));
                 const float pix_x = roundf(fmaf(pox, SBP, ptx)) - ptx;
                 const float pix_y = roundf(fmaf(poy, SBP, pty)) - pty;
-                pox = pix_x / SBP; poy = pix_y / SBP;
+                pox = pix_x * rsbp; poy = pix_y * rsbp;          // the reference divides; these only weigh the sample (continuous)
                 float mod, th;
                 alt_gradiant_pt(v, mod, th, (int)(ptx + pix_x), (int)(pty + pix_y));
                 const float npx = fmaf(cos_t, pox,  sin_t * poy);
@@ -1067,7 +1060,7 @@ __device__ __forceinline__ void alt_tiles(const V& v, float* bins, float* out, i
                 const float tth = th * M_4RPI_F;
                 const int   fo0 = (int)floorf(tth);
                 const float do0 = tth - fo0;
-                const int   fo  = fo0 % 8;
+                const int   fo  = fo0 & 7;                  // th in [0, 2 pi): fo0 in 0..8
                 alt_add(bins, lane, fo, (1.0f - do0) * wgt);
                 alt_add(bins, lane, fo + 1, do0 * wgt);
             }
@@ -1147,6 +1140,7 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
     __shared__ __attribute__((aligned(16))) float s_win[ALT_WIN_CAP];
     __shared__ float s_bins[WPB][ALT_BINS * PSX_WAVE];
     __shared__ float s_out[256];                 // [2][128]: notile sums two halves, the others use the first
+    __shared__ float s_cs[2];                    // cos, sin of the descriptor's orientation
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     float* bins = s_bins[wave];
 
@@ -1169,21 +1163,27 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
         const int Ei = (int)ceilf(fmaf(3.5356f, SBP, 2.51f));
         const int bw = 2 * Ei + 2;
         const int bx0 = (int)floorf(x) - Ei, by0 = (int)floorf(y) - Ei;
-        const bool windowed = use_window != 0 && SBP < 64.0f && bw <= ALT_WIN_MAX;
+        if (wave == WPB - 1) {
+            // __sincosf in the reference.  GRID snaps its sample points through (int)(pt + (round(pt + pix) - pt)), which
+            // flips on the last bit of sin / cos: that mode evaluates them in double and rounds once, as the oracle does.
+            // One wave does it for the workgroup (the double-precision pair is ~600 instructions).
+            const float c = MODE == PSX_DESC_GRID ? (float)cos((double)ang) : cosf(ang);
+            const float sn = MODE == PSX_DESC_GRID ? (float)sin((double)ang) : sinf(ang);
+            if (lane == 0) { s_cs[0] = c; s_cs[1] = sn; }
+        }
+        const bool windowed = use_window != 0 && SBP < 64.0f && bw <= ALT_WIN_MAX && H <= 32768;      // 4 * 84 * (H + 84) < 2^24
         if (windowed && SBP != 0.0f) {
             for (int r = wave; r < bw; r += WPB) {
                 const float* row = plane + (size_t)psx_clampi(by0 + r, 0, H - 1) * pitch;
-                for (int c = lane; c < bw; c += PSX_WAVE) s_win[r * bw + c] = row[psx_clampi(bx0 + c, 0, W - 1)];
+                for (int c = lane; c < bw; c += PSX_WAVE) s_win[r * ALT_WIN_MAX + c] = row[psx_clampi(bx0 + c, 0, W - 1)];
             }
         }
         __syncthreads();
 
         if (SBP != 0.0f) {
-            // __sincosf in the reference.  GRID snaps its sample points through (int)(pt + (round(pt + pix) - pt)), which
-            // flips on the last bit of sin / cos: that mode evaluates them in double and rounds once, as the oracle does
-            const float cos_t = MODE == PSX_DESC_GRID ? (float)cos((double)ang) : cosf(ang);
-            const float sin_t = MODE == PSX_DESC_GRID ? (float)sin((double)ang) : sinf(ang);
-            if (windowed) alt_tiles<MODE>(AltWindow{(const float LDS_AS*)s_win, bx0, by0, bw}, bins, s_out, lane, wave, x, y, ang, SBP, cos_t, sin_t);
+            const float cos_t = s_cs[0], sin_t = s_cs[1];
+            const float c4 = (float)((int)(unsigned)(uintptr_t)(const float LDS_AS*)s_win - 4 * (bx0 + ALT_WIN_MAX * by0));
+            if (windowed) alt_tiles<MODE>(AltWindow{(const float LDS_AS*)s_win, bx0, by0, c4}, bins, s_out, lane, wave, x, y, ang, SBP, cos_t, sin_t);
             else          alt_tiles<MODE>(AltPlane{plane, W, H, pitch}, bins, s_out, lane, wave, x, y, ang, SBP, cos_t, sin_t);
         }
         __syncthreads();

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_modes.py -x -q 2>&1 | tail -3
+python tools/desc_modes_ms.py 2>&1 | tail -5
