@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_modes.py -x -q 2>&1 | tail -3
-python tools/desc_modes_ms.py 2>&1 | tail -5
+timeout 600 python tools/superframe_ab.py 2>&1 | tail -20
