@@ -377,3 +377,96 @@ def test_matcher_prefilter_margin_holds():
             worst = max(worst, ratio)
             assert ratio < 1.0, (name, flush, ratio)
     print("matcher prefilter: worst |s - d| / E_l = %.3f" % worst)
+
+
+def _alt_window_box(x, y, sbp):
+    """orient_desc.hip k_descriptors_alt: the window of the plane a workgroup stages for one descriptor."""
+    ei = int(np.ceil(_fma(np.asarray([3.5356], f32), np.asarray([sbp], f32), np.asarray([2.51], f32))[0]))
+    return int(np.floor(x)) - ei, int(np.floor(y)) - ei, 2 * ei + 2
+
+
+def _alt_reads_bilinear(px, py, cos_t, sin_t):
+    """Integer texel coordinates alt_gradiant_rot touches for sample points (px, py): the four stencil taps, each the
+    2 x 2 texels at floor((c + 0.5) - 0.5) and + 1.  Returns (min x, max x, min y, max y)."""
+    xs, ys = [], []
+    for dx, dy in ((cos_t, sin_t), (-cos_t, -sin_t), (-sin_t, cos_t), (sin_t, -cos_t)):
+        tx = ((px + f32(dx)).astype(f32) + f32(0.5)).astype(f32) - f32(0.5)
+        ty = ((py + f32(dy)).astype(f32) + f32(0.5)).astype(f32) - f32(0.5)
+        xs.append(np.floor(tx)); ys.append(np.floor(ty))
+    xs, ys = np.concatenate(xs), np.concatenate(ys)
+    return xs.min(), xs.max() + 1, ys.min(), ys.max() + 1
+
+
+def test_alt_descriptor_window_holds_every_texel_the_modes_read():
+    """orient_desc.hip k_descriptors_alt stages texels floor(x) - Ei .. floor(x) + Ei + 1 (Ei = ceil(3.5356 SBP + 2.51)) per
+    axis and its waves read the window WITHOUT a range check.  The sample coordinates of the four modes are re-evaluated
+    here in float32 (the kernel's expressions: s_desc_igrid.cu / s_desc_notile.cu / s_desc_iloop.cu / s_desc_grid.cu as
+    restated in alt_tiles) for random keypoints, sizes and orientations -- also at the plane's corner and for tiny and
+    maximal SBP -- and every texel they touch must lie inside the window."""
+    rng = np.random.default_rng(11)
+    n_checked = 0
+    for trial in range(400):
+        sbp = f32(rng.choice([0.05, 0.7, 3.0, 5.4, 8.1, 10.8, 10.88]) if trial % 3 == 0 else rng.uniform(0.3, 10.88))
+        ang = f32(rng.uniform(-np.pi, np.pi) if trial % 5 else rng.choice([0.0, np.pi / 4, np.pi / 2, -np.pi / 4, np.pi]))
+        x = f32(rng.uniform(-0.5, 4000.0) if trial % 4 else rng.choice([0.0, 0.999, 1.0, 3839.5]))
+        y = f32(rng.uniform(-0.5, 2200.0) if trial % 4 else rng.choice([0.0, 0.001, 2159.0]))
+        cos_t, sin_t = f32(np.cos(np.float64(ang))), f32(np.sin(np.float64(ang)))
+        bx0, by0, bw = _alt_window_box(x, y, sbp)
+        assert bw <= 84, (sbp, bw)                        # SBP <= 10.88 = sigma <= 3.63 fits ALT_WIN_MAX
+
+        def inside(lims, what):
+            x0, x1, y0, y1 = lims
+            assert bx0 <= x0 and x1 <= bx0 + bw - 1 and by0 <= y0 and y1 <= by0 + bw - 1, \
+                (what, float(sbp), float(ang), float(x), float(y), lims, (bx0, by0, bw))
+
+        # igrid / notile: the lattice step = -2.5 + 1/16 + k/8, k = 0..39, rotated, times SBP, around (x, y)
+        k = np.arange(40, dtype=f32)
+        step = (f32(-2.5) + f32(1.0 / 16.0) + k / f32(8.0)).astype(f32)
+        sx, sy = np.meshgrid(step, step)
+        sx, sy = sx.ravel(), sy.ravel()
+        ptx = _fma(np.full(sx.shape, cos_t, f32), sx, (-sin_t * sy).astype(f32))
+        pty = _fma(np.full(sx.shape, cos_t, f32), sy, (sin_t * sx).astype(f32))
+        px = _fma(ptx, np.full(sx.shape, sbp, f32), np.full(sx.shape, x, f32))
+        py = _fma(pty, np.full(sx.shape, sbp, f32), np.full(sx.shape, y, f32))
+        inside(_alt_reads_bilinear(px, py, cos_t, sin_t), "igrid/notile")
+
+        # iloop: tile centres +-0.5, +-1.5 (x SBP, rotated) + the 32 x 32 lattice over [-bsz, bsz)^2 x SBP, inside |n| < 1 only
+        csbp, ssbp = f32(cos_t * sbp), f32(sin_t * sbp)
+        bsz = f32(abs(cos_t) + abs(sin_t))
+        sub = np.arange(32, dtype=f32)
+        d = (-bsz + (sub * bsz).astype(f32) / f32(16.0)).astype(f32)
+        dx, dy = np.meshgrid(d, d)
+        dx, dy = dx.ravel(), dy.ravel()
+        nx = _fma(np.full(dx.shape, cos_t, f32), dx, (sin_t * dy).astype(f32))
+        ny = _fma(np.full(dx.shape, cos_t, f32), dy, (-sin_t * dx).astype(f32))
+        m = (np.abs(nx) < 1) & (np.abs(ny) < 1)
+        for offx in (-1.5, -0.5, 0.5, 1.5):
+            for offy in (-1.5, -0.5, 0.5, 1.5):
+                tpx = _fma(np.asarray([csbp], f32), np.asarray([offx], f32), np.asarray([-ssbp * f32(offy)], f32))[0]
+                tpy = _fma(np.asarray([csbp], f32), np.asarray([offy], f32), np.asarray([ssbp * f32(offx)], f32))[0]
+                jj = ((x + tpx).astype(f32) + (dx[m] * sbp).astype(f32)).astype(f32)
+                ii = ((y + tpy).astype(f32) + (dy[m] * sbp).astype(f32)).astype(f32)
+                inside(_alt_reads_bilinear(jj, ii, cos_t, sin_t), "iloop")
+
+        # grid: 16 x 16 samples per tile snapped to pixels through roundf and an (int) conversion, point reads at +-1
+        xd = np.arange(16, dtype=f32) + f32(0.5)
+        gx, gy = np.meshgrid(xd, xd)
+        gx, gy = gx.ravel(), gy.ravel()
+        ldx, ldy = f32(-cos_t + sin_t), f32(-cos_t - sin_t)
+        rsx, rsy, usx, usy = f32(cos_t / f32(8)), f32(sin_t / f32(8)), f32(-sin_t / f32(8)), f32(cos_t / f32(8))
+        one = np.ones(gx.shape, f32)
+        pox = _fma(gy, one * usx, _fma(gx, one * rsx, one * ldx))
+        poy = _fma(gy, one * usy, _fma(gx, one * rsy, one * ldy))
+        for offx in (-1.5, -0.5, 0.5, 1.5):
+            for offy in (-1.5, -0.5, 0.5, 1.5):
+                tpx = _fma(np.asarray([csbp], f32), np.asarray([offx], f32), _fma(np.asarray([-ssbp], f32), np.asarray([offy], f32), np.asarray([x], f32)))[0]
+                tpy = _fma(np.asarray([csbp], f32), np.asarray([offy], f32), _fma(np.asarray([ssbp], f32), np.asarray([offx], f32), np.asarray([y], f32)))[0]
+                rx = _fma(pox, one * sbp, one * tpx)
+                ry = _fma(poy, one * sbp, one * tpy)
+                rnd = lambda v: (np.sign(v) * np.floor(np.abs(v) + f32(0.5))).astype(f32)          # roundf: half away from zero
+                pix_x, pix_y = (rnd(rx) - tpx).astype(f32), (rnd(ry) - tpy).astype(f32)
+                ix = np.trunc((tpx + pix_x).astype(f32))
+                iy = np.trunc((tpy + pix_y).astype(f32))
+                inside((ix.min() - 1, ix.max() + 1, iy.min() - 1, iy.max() + 1), "grid")
+        n_checked += 1
+    assert n_checked == 400

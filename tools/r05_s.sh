@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python tools/superframe_ab.py 2>&1 | tail -20
+mkdir -p gpurun_out/r05_sweep
+timeout 2400 python tools/parity_counts.py 300 gpurun_out/r05_sweep/parity_counts.json 2>&1 | tail -5
