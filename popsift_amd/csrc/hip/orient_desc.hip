@@ -886,14 +886,14 @@ __device__ __forceinline__ void alt_add(float* bins, int lane, int b, float v) {
 struct AltPlane {
     const float* p; int W, H, pitch;
     __device__ __forceinline__ float at(int x, int y) const { return p[(size_t)psx_clampi(y, 0, H - 1) * pitch + psx_clampi(x, 0, W - 1)]; }
-    // the 2 x 2 texels at (i, j) = (fx, fy), integers held as floats
-    __device__ __forceinline__ void quad(float fx, float fy, float& p00, float& p01, float& p10, float& p11) const
+    // the 2 x 2 texels at (i, j) = (fx, fy), integers held as floats: top = row j, columns (i, i + 1); bot = row j + 1
+    __device__ __forceinline__ void quad(float fx, float fy, v2f& top, v2f& bot) const
     {
         const int i = (int)fx, j = (int)fy;
         const int i0 = psx_clampi(i, 0, W - 1), i1 = psx_clampi(i + 1, 0, W - 1);
         const int j0 = psx_clampi(j, 0, H - 1), j1 = psx_clampi(j + 1, 0, H - 1);
-        p00 = p[(size_t)j0 * pitch + i0]; p01 = p[(size_t)j0 * pitch + i1];
-        p10 = p[(size_t)j1 * pitch + i0]; p11 = p[(size_t)j1 * pitch + i1];
+        top = (v2f){p[(size_t)j0 * pitch + i0], p[(size_t)j0 * pitch + i1]};
+        bot = (v2f){p[(size_t)j1 * pitch + i0], p[(size_t)j1 * pitch + i1]};
     }
 };
 // Rows of the window are ALT_WIN_MAX texels apart whatever its size: the texel below is an immediate offset of the same
@@ -905,11 +905,11 @@ constexpr int ALT_WIN_CAP = ALT_WIN_MAX * ALT_WIN_MAX;
 struct AltWindow {
     const float LDS_AS* w; int bx0, by0; float c4;
     __device__ __forceinline__ float at(int x, int y) const { return w[(y - by0) * ALT_WIN_MAX + (x - bx0)]; }
-    __device__ __forceinline__ void quad(float fx, float fy, float& p00, float& p01, float& p10, float& p11) const
+    __device__ __forceinline__ void quad(float fx, float fy, v2f& top, v2f& bot) const
     {
         const unsigned addr = (unsigned)(int)fmaf(fy, 4.0f * ALT_WIN_MAX, fmaf(fx, 4.0f, c4));
         const float LDS_AS* q = (const float LDS_AS*)addr;
-        p00 = q[0]; p01 = q[1]; p10 = q[ALT_WIN_MAX]; p11 = q[ALT_WIN_MAX + 1];        // two ds_read2_b32
+        top = (v2f){q[0], q[1]}; bot = (v2f){q[ALT_WIN_MAX], q[ALT_WIN_MAX + 1]};        // two ds_read2_b32
     }
 };
 // The linear-filtered layered texture at p = (x, y): texel centres at integer + 0.5, 1.8 fixed-point weights (the software
@@ -926,12 +926,14 @@ __device__ __forceinline__ AltTap alt_tap(v2f p)
     t.ab = (v2f){rintf(fr.x), rintf(fr.y)} * splat(1.0f / 256.0f);
     return t;
 }
-// d_lerp(p, q, a) = fma(a, q, (1 - a) * p) on both rows at once, then between the rows
-__device__ __forceinline__ float alt_blend(const AltTap& t, const float (&q)[4])
+// d_lerp(p, q, w) = fma(w, q, (1 - w) * p): between the two rows first, both columns at once -- top and bot are
+// the register pairs the two ds_read2_b32 deliver, so the packed operands need no moves -- then between
+// the columns.  (The oracle's model blends the columns first; the two orders differ by an ulp of the texel difference.)
+__device__ __forceinline__ float alt_blend(const AltTap& t, v2f top, v2f bot)
 {
-    const float na = 1.0f - t.ab.x;
-    const v2f r = pk_fma(splat(t.ab.x), (v2f){q[1], q[3]}, splat(na) * (v2f){q[0], q[2]});
-    return fmaf(t.ab.y, r.y, (1.0f - t.ab.y) * r.x);
+    const float nb = 1.0f - t.ab.y;
+    const v2f r = pk_fma(splat(t.ab.y), bot, splat(nb) * top);
+    return fmaf(t.ab.x, r.y, (1.0f - t.ab.x) * r.x);
 }
 // get_gradiant with the rotated stencil on the linear texture (s_gradiant.h:72-88).  Magnitude and angle only SCALE /
 // interpolate a contribution (bin weights are continuous in the angle): v_sqrt_f32 and the degree-13 atan polynomial of
@@ -942,16 +944,15 @@ __device__ __forceinline__ void alt_gradiant_rot(const V& v, float& grad, float&
     const v2f p = (v2f){x, y}, cs = (v2f){cos_t, sin_t}, sc = (v2f){-sin_t, cos_t};
     // (x + cos, y + sin), (x - cos, y - sin), (x - sin, y + cos), (x + sin, y - cos)
     const AltTap t0 = alt_tap(p + cs), t1 = alt_tap(p - cs), t2 = alt_tap(p + sc), t3 = alt_tap(p - sc);
-    float q0[4], q1[4], q2[4], q3[4];
-    v.quad(t0.f.x, t0.f.y, q0[0], q0[1], q0[2], q0[3]);
-    v.quad(t1.f.x, t1.f.y, q1[0], q1[1], q1[2], q1[3]);
-    v.quad(t2.f.x, t2.f.y, q2[0], q2[1], q2[2], q2[3]);
-    v.quad(t3.f.x, t3.f.y, q3[0], q3[1], q3[2], q3[3]);
+    v2f a0, b0, a1, b1, a2, b2, a3, b3;
+    v.quad(t0.f.x, t0.f.y, a0, b0);
+    v.quad(t1.f.x, t1.f.y, a1, b1);
+    v.quad(t2.f.x, t2.f.y, a2, b2);
+    v.quad(t3.f.x, t3.f.y, a3, b3);
     // all sixteen texels before the first use (otherwise each fetch is waited for on its own: four LDS round trips per sample)
-    asm volatile("" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3]));
-    asm volatile("" : "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]), "+v"(q3[0]), "+v"(q3[1]), "+v"(q3[2]), "+v"(q3[3]));
-    const float dx = alt_blend(t0, q0) - alt_blend(t1, q1);
-    const float dy = alt_blend(t2, q2) - alt_blend(t3, q3);
+    asm volatile("" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
+    const float dx = alt_blend(t0, a0, b0) - alt_blend(t1, a1, b1);
+    const float dy = alt_blend(t2, a2, b2) - alt_blend(t3, a3, b3);
     grad = __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
     theta = fast_atan2(dy, dx);
 }

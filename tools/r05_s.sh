@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-bash tools/env_ab.sh '' 'GPU_MAX_HW_QUEUES=8' 'GPU_MAX_HW_QUEUES=6' '' 'GPU_MAX_HW_QUEUES=3' 'POPSIFT_BENCH_CTX=24' 'POPSIFT_BENCH_CTX=8' 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_modes.py -x -q 2>&1 | tail -3
+python tools/desc_modes_ms.py 2>&1 | tail -5
