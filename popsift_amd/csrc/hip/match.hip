@@ -400,8 +400,11 @@ __device__ __forceinline__ void top2_insert_lex(Top2& t, float d, int i)
 // lane 0 ends with ((((p0 + p16) + (p8 + p24)) + ...)), the tree of l2_tree above.  `left` / `right` in ORIGINAL layout.
 __global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ left, int l_len, const float* __restrict__ right, int r_len,
                                                      const int* __restrict__ cand_ct, const int* __restrict__ cand,
-                                                     int* __restrict__ out, float* __restrict__ dist)
+                                                     int* __restrict__ out, float* __restrict__ dist, const int* __restrict__ flag)
 {
+    // launched behind the prefilter without waiting for its verdict: a raised flag (a candidate segment overflowed, norms the
+    // margin cannot bound) means the host will run the exact scan of every pair instead
+    if (*flag != 0) return;
     const int lane = threadIdx.x & 63, tl = lane & 31, half = lane >> 5;
     const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (li >= l_len) return;
@@ -545,6 +548,8 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
     // candidates (identical results by construction; used from 2048 right / 256 left descriptors on)
     static const bool use_mfma = [] { const char* e = getenv("POPSIFT_MATCH_MFMA"); return !(e != nullptr && e[0] == '0'); }();
     bool exact_scan = true;
+    int* d_flag_used = nullptr;
+    int* d_cct_used = nullptr;
     if (use_mfma && r_len >= 2 * MF_SEED && l_len >= 256) {
         if (!sc.need(4, sizeof(unsigned short) * 128 * (size_t)l_len) || !sc.need(5, sizeof(unsigned short) * 128 * (size_t)r_len) ||
             !sc.need(6, sizeof(float) * (1 + 2 * MF_SEEDCH) * (size_t)l_len) || !sc.need(7, sizeof(float) * (size_t)r_len + 1024) ||
@@ -584,28 +589,40 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         hipLaunchKernelGGL((k_match_mfma<false>), dim3(lblocks, mchunks), dim3(256), 0, st, d_lf16, d_ln2, l_len, d_rf16, d_rn2, r_len, mlen,
                            d_par, d_seed, d_cct, d_cand);
         hipLaunchKernelGGL(k_match_overflow, dim3((l_len * MF_SEGS + 255) / 256), dim3(256), 0, st, d_cct, l_len, d_flag);
-        if (!sc.need_pinned(64)) return PSX_ERR_NOMEM;
-        int* h_flagp = static_cast<int*>(sc.hpin);
-        if (hipGetLastError() != hipSuccess ||
-            hipMemcpyAsync(h_flagp, d_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) return PSX_ERR_HIP;
+        // the exact evaluation of the candidates goes out at once; the flag comes back with the results (one synchronisation
+        // per call instead of two)
+        hipLaunchKernelGGL(k_match_exact, dim3((l_len + 3) / 4), dim3(256), 0, st, d_left, l_len, d_right, r_len, d_cct, d_cand,
+                           d_out, d_dist, d_flag);
+        exact_scan = false;
+        d_flag_used = d_flag; d_cct_used = d_cct;
+    }
+    const size_t mb = sizeof(int) * 3 * (size_t)l_len, db = sizeof(float) * 2 * (size_t)l_len;
+    if (!sc.need_pinned(mb + db + 64)) return PSX_ERR_NOMEM;
+    char* hp = static_cast<char*>(sc.hpin);
+    int* h_flagp = reinterpret_cast<int*>(hp + mb + db);
+    *h_flagp = 0;
+    auto fetch = [&]() -> bool {
+        return hipGetLastError() == hipSuccess &&
+               hipMemcpyAsync(hp, d_out, mb, hipMemcpyDeviceToHost, st) == hipSuccess &&
+               (!host_dist || hipMemcpyAsync(hp + mb, d_dist, db, hipMemcpyDeviceToHost, st) == hipSuccess) &&
+               (!d_flag_used || hipMemcpyAsync(h_flagp, d_flag_used, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess) &&
+               hipStreamSynchronize(st) == hipSuccess;
+    };
+    if (!exact_scan) {
+        if (!fetch()) return PSX_ERR_HIP;
         const int h_flag = *h_flagp;
         static const bool stats = getenv("POPSIFT_MATCH_STATS") != nullptr;       // measurement: candidates per left descriptor
         if (stats) {
             std::vector<int> h((size_t)l_len * MF_SEGS);
-            if (hipMemcpy(h.data(), d_cct, sizeof(int) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (hipMemcpy(h.data(), d_cct_used, sizeof(int) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
                 long long sum = 0; int mx = 0, mxl = 0;
                 for (int i = 0; i < l_len; i++) { int t = 0; for (int q = 0; q < MF_SEGS; q++) { const int v = h[(size_t)i * MF_SEGS + q]; t += v; if (v > mx) mx = v; } sum += t; if (t > mxl) mxl = t; }
                 fprintf(stderr, "psx_match prefilter: %d x %d, candidates per left descriptor: mean %.1f, max %d; fullest segment %d of %d%s\n", l_len, r_len,
                         (double)sum / l_len, mxl, mx, MF_SEGCAP, h_flag ? " -> exact scan of every pair" : "");
             }
         }
-        if (h_flag == 0) {
-            hipLaunchKernelGGL(k_match_exact, dim3((l_len + 3) / 4), dim3(256), 0, st, d_left, l_len, d_right, r_len, d_cct, d_cand,
-                               d_out, d_dist);
-            exact_scan = false;
-        }
-        // else: some list overflowed (thousands of near-equal neighbours): the exact scan of every pair below
+        // a list overflowed (thousands of near-equal neighbours) or the norms are out of the margin's reach: the exact scan below
+        if (h_flag != 0) { exact_scan = true; d_flag_used = nullptr; }
     }
     if (exact_scan) {
     if (r_len > 0)
@@ -614,15 +631,8 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
                        chunk_len, d_partial);
     hipLaunchKernelGGL(k_match_merge, dim3((l_len + 255) / 256), dim3(256), 0, st, d_partial, l_len, nchunks,
                        r_len, d_out, d_dist);
+    if (!fetch()) return PSX_ERR_HIP;
     }
-    const size_t mb = sizeof(int) * 3 * (size_t)l_len, db = sizeof(float) * 2 * (size_t)l_len;
-    if (!sc.need_pinned(mb + db)) return PSX_ERR_NOMEM;
-    char* hp = static_cast<char*>(sc.hpin);
-    if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(hp, d_out, mb, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        (host_dist && hipMemcpyAsync(hp + mb, d_dist, db, hipMemcpyDeviceToHost, st) != hipSuccess) ||
-        hipStreamSynchronize(st) != hipSuccess)
-        return PSX_ERR_HIP;
     memcpy(host_match, hp, mb);
     if (host_dist) memcpy(host_dist, hp + mb, db);
     return PSX_OK;
