@@ -287,36 +287,30 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
     // ---- staging of a right tile: 32 descriptors x 256 bytes = 512 16-byte pieces, two per thread; norms by 32 threads.
     // Two steps, so that the global loads of tile k + 2 are in flight while tile k is computed: issue() = loads into
     // registers; commit() = registers into the LDS buffer of tile k + 1 (free since the barrier that ended iteration k - 1) ----
-    uint4 pre[2];
+    // (two named registers sets and macros, not an array captured by lambdas: the array stayed in scratch memory, and the
+    // scratch store behind each global load waited for it -- the loads were not in flight at all)
+    uint4 pre0 = make_uint4(0u, 0u, 0u, 0u), pre1 = make_uint4(0u, 0u, 0u, 0u);
     float pre_n = INFINITY;
-    auto issue = [&](int tile) {
-        const int base = r0 + tile * MF_TILE;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int piece = t + j * 256;
-            const int row = piece >> 4, c16 = piece & 15;
-            const int ri = min(base + row, r_len - 1);
-            pre[j] = *reinterpret_cast<const uint4*>(rh + (size_t)ri * 128 + c16 * 8);
-        }
-        if (t < MF_TILE) pre_n = (base + t < r1) ? rn2[min(base + t, r_len - 1)] : INFINITY;     // rows beyond the chunk never win
-    };
-    auto commit = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int piece = t + j * 256;
-            const int row = piece >> 4, c16 = piece & 15;
-            *reinterpret_cast<uint4*>(&s_r[buf][row * MF_ROW + c16 * 16]) = pre[j];
-        }
-        if (t < MF_TILE) s_n[buf][t] = pre_n;
-    };
+    const int st_row0 = t >> 4, st_row1 = (t + 256) >> 4, st_c16 = t & 15;
+#define MF_ISSUE(tile_) do { \
+        const int base_ = r0 + (tile_) * MF_TILE; \
+        pre0 = *reinterpret_cast<const uint4*>(rh + (size_t)min(base_ + st_row0, r_len - 1) * 128 + st_c16 * 8); \
+        pre1 = *reinterpret_cast<const uint4*>(rh + (size_t)min(base_ + st_row1, r_len - 1) * 128 + st_c16 * 8); \
+        if (t < MF_TILE) pre_n = (base_ + t < r1) ? rn2[min(base_ + t, r_len - 1)] : INFINITY;     /* rows beyond the chunk never win */ \
+    } while (0)
+#define MF_COMMIT(buf_) do { \
+        *reinterpret_cast<uint4*>(&s_r[buf_][st_row0 * MF_ROW + st_c16 * 16]) = pre0; \
+        *reinterpret_cast<uint4*>(&s_r[buf_][st_row1 * MF_ROW + st_c16 * 16]) = pre1; \
+        if (t < MF_TILE) s_n[buf_][t] = pre_n; \
+    } while (0)
 
-    if (ntiles > 0) { issue(0); commit(0); }
-    if (ntiles > 1) issue(1);
+    if (ntiles > 0) { MF_ISSUE(0); MF_COMMIT(0); }
+    if (ntiles > 1) MF_ISSUE(1);
     __syncthreads();
     for (int tile = 0; tile < ntiles; tile++) {
         const int buf = tile & 1;
-        if (tile + 1 < ntiles) commit(buf ^ 1);          // loaded during the previous iteration
-        if (tile + 2 < ntiles) issue(tile + 2);
+        if (tile + 1 < ntiles) MF_COMMIT(buf ^ 1);       // loaded during the previous iteration
+        if (tile + 2 < ntiles) MF_ISSUE(tile + 2);
         f32x16 acc[2];
 #pragma unroll
         for (int c = 0; c < 2; c++)
@@ -335,7 +329,8 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
             // first the whole tile's values against the threshold the column had BEFORE this tile (a superset test), in
             // one wave-wide decision: the common case "nobody has a candidate" costs a compare per element and one branch
             // (forming the values again in the candidate path instead of keeping them: 162 VGPRs = three waves per SIMD,
-            // measured 261 us against 238 with two)
+            // measured 261 us against 238 with two; keeping the 16 verdicts as wave masks and branching on each: 230 us
+            // against 190 -- profiles/r05_match_prefilter.txt)
             float sp[16];
             float thr = m2[c] + twoE[c];
             bool any = false;
@@ -346,8 +341,9 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
                 for (int e = 0; e < 4; e++) {
                     sp[4 * g + e] = fmaf(fneg2, acc[c][4 * g + e], nr[e]);
                     any |= sp[4 * g + e] <= thr;
-                    m2[c] = fminf(m2[c], fmaxf(m1[c], sp[4 * g + e]));
-                    m1[c] = fminf(m1[c], sp[4 * g + e]);
+                    // m1 <= m2: the second smallest of {m1, m2, s} is their median (one v_med3_f32 for min(m2, max(m1, s)))
+                    m2[c] = __builtin_amdgcn_fmed3f(m1[c], m2[c], sp[4 * g + e]);
+                    m1[c] = __builtin_amdgcn_fmed3f(m1[c], sp[4 * g + e], -3.0e38f);      // = min: every s is far above -3e38
                 }
             }
             if (!SEED && __ballot(any && lidx[c] < l_len) != 0ull) {
@@ -383,6 +379,9 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
         }
     }
 }
+
+#undef MF_ISSUE
+#undef MF_COMMIT
 
 // (distance, index) lexicographic order: what the reference's sequential scan with strict '<' yields
 __device__ __forceinline__ bool lex_less(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
