@@ -180,9 +180,17 @@ __device__ __forceinline__ unsigned short to_f16(float f)
 }
 
 // squared norm of every descriptor and the largest one (bits of a non-negative float, 64 slots: same-address atomics serialise)
-__global__ void k_match_norms(const float* __restrict__ src, int n, float* __restrict__ norm2, unsigned* __restrict__ maxbits)
+// (both sides in one launch: blocks [0, blocks_a) take the first set, the others the second)
+__global__ void k_match_norms(const float* __restrict__ src_a, int n_a, float* __restrict__ norm2_a, unsigned* __restrict__ maxbits_a, int blocks_a,
+                              const float* __restrict__ src_b, int n_b, float* __restrict__ norm2_b, unsigned* __restrict__ maxbits_b)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 elements, 32 threads per descriptor
+    const bool second = (int)blockIdx.x >= blocks_a;
+    const float* src = second ? src_b : src_a;
+    const int n = second ? n_b : n_a;
+    float* norm2 = second ? norm2_b : norm2_a;
+    unsigned* maxbits = second ? maxbits_b : maxbits_a;
+    const int bid = second ? (int)blockIdx.x - blocks_a : (int)blockIdx.x;
+    const int g = bid * blockDim.x + threadIdx.x;                  // one thread per 4 elements, 32 threads per descriptor
     const int d = g >> 5, q = g & 31;
     float ss = 0.0f;
     if (d < n) {
@@ -197,7 +205,7 @@ __global__ void k_match_norms(const float* __restrict__ src, int n, float* __res
     // a NaN norm has the bit pattern of a huge unsigned: it wins the maximum and switches the prefilter off (k_match_scale)
     if (d < n && q == 0) atomicMax(&s_max, __float_as_uint(ss < 0.0f ? 0.0f : ss));
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&maxbits[blockIdx.x & (MF_MAXSLOTS - 1)], s_max);
+    if (threadIdx.x == 0) atomicMax(&maxbits[bid & (MF_MAXSLOTS - 1)], s_max);
 }
 
 // par[0] = 2^k, par[1] = -2 / 4^k, par[2] = Rmax^2, par[3] = M; *flag = 1 when the prefilter cannot be used
@@ -218,10 +226,15 @@ __global__ void k_match_scale(const unsigned* __restrict__ lmax, const unsigned*
     par[3] = M;
 }
 
-// f16 copy of every descriptor, scaled by par[0] = 2^k
-__global__ void k_match_cvt(const float* __restrict__ src, int n, unsigned short* __restrict__ dst, const float* __restrict__ par)
+// f16 copy of every descriptor of both sides, scaled by par[0] = 2^k (blocks [0, blocks_a): the first set)
+__global__ void k_match_cvt(const float* __restrict__ src_a, int n_a, unsigned short* __restrict__ dst_a, int blocks_a,
+                            const float* __restrict__ src_b, int n_b, unsigned short* __restrict__ dst_b, const float* __restrict__ par)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 4 elements
+    const bool second = (int)blockIdx.x >= blocks_a;
+    const float* src = second ? src_b : src_a;
+    unsigned short* dst = second ? dst_b : dst_a;
+    const int n = second ? n_b : n_a;
+    const int g = ((int)blockIdx.x - (second ? blocks_a : 0)) * blockDim.x + threadIdx.x;          // one thread per 4 elements
     if (g >= n * 32) return;
     const float sc = par[0];
     const float4 v = reinterpret_cast<const float4*>(src)[g];
@@ -568,11 +581,10 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         int* d_cand = static_cast<int*>(sc.buf[9]);
         if (hipMemsetAsync(d_cct, 0, sizeof(int) * (size_t)MF_SEGS * l_len, st) != hipSuccess ||
             hipMemsetAsync(d_rmax, 0, sizeof(unsigned) * (2 * MF_MAXSLOTS + 1), st) != hipSuccess) return PSX_ERR_HIP;
-        hipLaunchKernelGGL(k_match_norms, dim3((r_len * 32 + 255) / 256), dim3(256), 0, st, d_right, r_len, d_rn2, d_rmax);
-        hipLaunchKernelGGL(k_match_norms, dim3((l_len * 32 + 255) / 256), dim3(256), 0, st, d_left, l_len, d_ln2, d_lmax);
+        const int rblk = (r_len * 32 + 255) / 256, lblk = (l_len * 32 + 255) / 256;
+        hipLaunchKernelGGL(k_match_norms, dim3(rblk + lblk), dim3(256), 0, st, d_right, r_len, d_rn2, d_rmax, rblk, d_left, l_len, d_ln2, d_lmax);
         hipLaunchKernelGGL(k_match_scale, dim3(1), dim3(64), 0, st, d_lmax, d_rmax, d_par, d_flag);
-        hipLaunchKernelGGL(k_match_cvt, dim3((r_len * 32 + 255) / 256), dim3(256), 0, st, d_right, r_len, d_rf16, d_par);
-        hipLaunchKernelGGL(k_match_cvt, dim3((l_len * 32 + 255) / 256), dim3(256), 0, st, d_left, l_len, d_lf16, d_par);
+        hipLaunchKernelGGL(k_match_cvt, dim3(rblk + lblk), dim3(256), 0, st, d_right, r_len, d_rf16, rblk, d_left, l_len, d_lf16, d_par);
         const int lblocks = (l_len + 255) / 256;
         // seeding pass over the first MF_SEED right descriptors, then every chunk of the right side: enough workgroups for
         // a round or two of the chip, whole tiles per chunk
