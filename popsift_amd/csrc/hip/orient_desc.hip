@@ -869,11 +869,12 @@ __device__ __forceinline__ float desc_tile_entry(int i)
 // Alternative descriptor modes: iloop, grid, igrid, notile (s_desc_iloop.cu, s_desc_grid.cu, s_desc_igrid.cu,
 // s_desc_notile.cu).  Each samples the window differently and therefore yields a DIFFERENT descriptor than
 // "loop"; they exist for API completeness of Config::setDescMode and follow the CPU restatement
-// (oracle/sift_oracle.c descriptor_iloop / _grid / _igrid / _notile) operation by operation.  One wave64 per
-// descriptor; the reference's 32- / 16- / 8-lane groups (one tile each) sit side by side in the wave: 2, 4 or
-// 8 tiles per pass.  Every lane accumulates into its own 8 (+1 wrap) bins -- a private LDS column, no atomics
-// -- and the groups are then reduced with the reference's shuffle trees.  Gradients come from a software
-// model of the linear-filtered layered texture (1.8 fixed-point weights), as in pyramid_alt.hip.
+// (oracle/sift_oracle.c descriptor_iloop / _grid / _igrid / _notile) sample by sample.  One workgroup per
+// descriptor; the reference's 32- / 16- / 8-lane groups (one tile each) sit side by side in a wave: 2, 4 or
+// 8 tiles per pass, the passes spread over the four waves.  Every lane accumulates into its own 8 (+1 wrap)
+// bins -- a private LDS column, no atomics -- and the groups are then reduced with the reference's shuffle
+// trees.  Gradients come from a software model of the linear-filtered layered texture (1.8 fixed-point
+// weights), as in pyramid_alt.hip, read from a window of the plane staged in LDS.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float d_lerp(float p, float q, float a) { return fmaf(a, q, (1.0f - a) * p); }
 constexpr int ALT_BINS = 9;
