@@ -200,3 +200,36 @@ def test_demo_runs_the_reference_test_script(oracle, tmp_path, mode, desc_mode):
     allowed = int(0.06 * len(got)) if mode == "grid" else max(1, len(got) // 2000)
     assert bad <= allowed, "%d of %d descriptor rows differ" % (bad, len(got))
     assert os.path.isdir(str(tmp_path / "dir-octave")) and os.path.isdir(str(tmp_path / "dir-desc"))
+
+
+def test_demo_runs_the_oxford_regression_command_line(oracle, tmp_path):
+    """testScripts/testOxfordDataset.sh.in:48 of the reference: popsift-demo --log --gauss-mode vlfeat --desc-mode loop
+    --popsift-mode --root-sift --downsampling -1 on a colour PPM (the Oxford images are PPMs); the script byte-compares the
+    quantised Gaussian planes and the sorted feature files with stored ones.  Same command line on a synthetic PPM: the
+    plane files from the oracle's planes (bit-identical pyramid), the feature rows against the oracle's."""
+    g = synth(400, 320, 31)
+    rgb = np.stack([g, np.roll(g, 3, axis=1), np.roll(g, 5, axis=0)], axis=2).astype(np.uint8)
+    with open(str(tmp_path / "img1.ppm"), "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]) + rgb.tobytes())
+    r, gg, b = (rgb[:, :, k].astype(np.int64) for k in range(3))
+    gray = ((4899 * r + 9617 * gg + 1868 * b) >> 14).astype(np.uint8)          # pgmread.cpp: the reference's integer luma
+    p = _run([DEMO, "--log", "--gauss-mode", "vlfeat", "--desc-mode", "loop", "--popsift-mode", "--root-sift",
+              "--downsampling", "-1", "-i", "img1.ppm"], tmp_path)
+    ref = oracle.run(oracle.default_config(gauss_mode=0, desc_mode=0, sift_mode=0, norm_mode=0, upscale_factor=1.0), gray)
+    assert "Number of feature points: %d number of feature descriptors: %d" % (ref.ext_total, ref.ori_total) in p.stderr
+    for o in range(ref.num_octaves):
+        for l in range(ref.num_levels):
+            assert np.array_equal(_read_p2(str(tmp_path / "dir-octave" / ("pyramid-o-%d-l-%d.pgm" % (o, l)))),
+                                  ref.gauss(o, l).astype(np.int64)), (o, l)
+    got = np.loadtxt(str(tmp_path / "output-features.txt"), ndmin=2)
+    exp = _expected_rows(ref)
+    assert got.shape == exp.shape == (ref.ori_total, 5 + 128) and ref.ori_total > 500
+    used = np.zeros(len(exp), bool)
+    for row in got:
+        c = np.flatnonzero((np.abs(exp[:, 0] - row[0]) <= 2e-3) & (np.abs(exp[:, 1] - row[1]) <= 2e-3) &
+                           (np.abs(exp[:, 2] - row[2]) <= 2e-5 * row[2] + 1e-9) & ~used)
+        assert len(c) > 0, row[:5]
+        dd = np.abs(exp[c, 5:] - row[5:]).max(axis=1)
+        assert dd.min() <= 1e-3 + 0.6e-3, dd.min()                 # descriptors within 1e-3, 3 significant digits of values below 1
+        used[c[dd.argmin()]] = True
+    assert used.all()
