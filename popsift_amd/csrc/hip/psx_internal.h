@@ -166,6 +166,25 @@ struct PsxAltArgs {
     void* user;
 };
 hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s);
+// GaussMode Fixed9 / Fixed15: every derived level of an octave in one launch (pyramid_fixed.hip)
+struct PsxFixedOctaveArgs {
+    const void* src;            // level 0 of the octave (from_input == 0) or the input image
+    int src_w, src_h, is_float; // image size / type (from_input != 0)
+    int from_input;             // octave 0: levels 0..5 from the image (x2 upsampling only: psx_fixed_octave0_ok)
+    int shift;                  // 4 (Fixed9) or 7 (Fixed15)
+    int nlev;                   // levels written: 6 from the image, 5 from a plane
+    float* dst;                 // plane of the first level written
+    size_t plane;               // floats between two levels
+    float* half_dst;            // level 0 of the next octave (every second row / column of level L - 3), or nullptr
+    int half_pitch, half_level; // half_level: index of that level among the levels written
+    int W, H, pitch;
+    float scale;
+    const float* taps;          // host table: nlev rows of PSX_GAUSS_ALIGN floats
+    hipEvent_t ev0, ev1;        // begin / end timestamps of the dispatch, or nullptr
+};
+bool psx_fixed_octave0_ok(int w, int h, int W, int H);
+bool psx_fixed_octave_enabled();
+hipError_t psx_launch_fixed_octave(const PsxFixedOctaveArgs& a, hipStream_t s);
 hipError_t psx_launch_dog(const float* a, const float* b, float* d, int W, int H, int pitch, hipStream_t s);
 // k_extrema scans the tiles of up to PSX_EXT_BATCH octaves in one launch
 #define PSX_EXT_BATCH 4

@@ -256,6 +256,7 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
     auto taps = [](const float* row) { PsxTaps t; for (int i = 0; i < PSX_GAUSS_ALIGN; i++) t.g[i] = row[i]; return t; };
     auto inc = [&](int l) { return taps(a.inc_filter + l * PSX_GAUSS_ALIGN); };
     auto inci = [&](int l) { return taps(a.inc_ifilter + l * PSX_GAUSS_ALIGN); };
+    bool next_l0_done = false;          // level 0 of this octave was written by the previous octave's fused launch
     for (int o = 0; o < P.num_octaves; o++) {
         const PsxOctave& oc = P.oct[o];
         const int W = oc.w, H = oc.h, pitch = oc.pitch;
@@ -298,13 +299,35 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
             }
         };
         if (fixed) {
-            if (o == 0) fixed_levels(0, true);
-            else {
+            // one launch per octave (pyramid_fixed.hip: level 0 read once, every derived level and the next octave's level 0
+            // written from LDS) wherever that kernel applies; the per-level kernels above otherwise
+            const bool fused = psx_fixed_octave_enabled();
+            PsxFixedOctaveArgs fo;
+            fo.src_w = a.w; fo.src_h = a.h; fo.is_float = a.is_float;
+            fo.shift = SHIFT; fo.plane = oc.plane; fo.W = W; fo.H = H; fo.pitch = pitch;
+            fo.half_dst = nullptr; fo.half_pitch = 0;
+            if (!direct && o + 1 < P.num_octaves) { fo.half_dst = P.oct[o + 1].data; fo.half_pitch = P.oct[o + 1].pitch; }
+            fo.ev0 = fo.ev1 = nullptr;
+            if (o == 0) {
+                if (fused && psx_fixed_octave0_ok(a.w, a.h, W, H) && a.upscale_factor == 1.0f) {
+                    fo.src = a.img; fo.from_input = 1; fo.nlev = 6; fo.dst = plane(0); fo.half_level = P.L - 3;
+                    fo.scale = 255.0f; fo.taps = a.abs0_filter;
+                    const hipError_t e2 = psx_launch_fixed_octave(fo, s);
+                    if (e2 != hipSuccess) return e2;
+                    next_l0_done = fo.half_dst != nullptr;
+                } else { fixed_levels(0, true); next_l0_done = false; }
+            } else {
                 if (direct) {
                     hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, taps(a.dd_filter + o * PSX_GAUSS_ALIGN), a.dd_span[o], shift);
                     hipLaunchKernelGGL(k_alt_v_plain, g, b, 0, s, a.intm, plane(0), W, H, pitch, inc(0), a.inc_span[0]);
-                } else downscale();
-                fixed_levels(1, false);
+                } else if (!next_l0_done) downscale();
+                if (fused) {
+                    fo.src = plane(0); fo.from_input = 0; fo.nlev = 5; fo.dst = plane(1); fo.half_level = P.L - 3 - 1;
+                    fo.scale = 1.0f; fo.taps = a.absN_filter + PSX_GAUSS_ALIGN;
+                    const hipError_t e2 = psx_launch_fixed_octave(fo, s);
+                    if (e2 != hipSuccess) return e2;
+                    next_l0_done = fo.half_dst != nullptr;
+                } else { fixed_levels(1, false); next_l0_done = false; }
             }
         } else if (direct) {
             const bool interp = (gm == PSX_GAUSS_VLFEAT_RELATIVE);
