@@ -25,7 +25,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 
-HIP_SOURCES = ["pyramid.hip", "pyramid_tile.hip", "pyramid_alt.hip", "pyramid_fixed.hip", "extrema.hip", "orient_desc.hip", "gridfilter.hip", "match.hip", "util.hip", "api.hip"]
+HIP_SOURCES = ["pyramid.hip", "pyramid_tile.hip", "pyramid_alt.hip", "pyramid_fixed.hip", "pyramid_interp.hip", "extrema.hip", "orient_desc.hip", "gridfilter.hip", "match.hip", "util.hip", "api.hip"]
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # no implicit fused multiply-add: the arithmetic order is part of the parity contract

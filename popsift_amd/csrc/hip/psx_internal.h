@@ -94,7 +94,11 @@ struct PsxLevel0Args {
     float shift;
     PsxTaps taps_h; int span_h;   // dd table, octave 0
     PsxTaps taps_v; int span_v;   // inc table, level 0
+    // GaussMode VLFeat_Relative: the interpolated table of level 0 (i_filter row, its odd span) -- the vertical pass is
+    // absoluteSourceInterpolated::vert instead of absoluteSource::vert; nullptr otherwise
+    const float* v_ifilter = nullptr; int v_ispan = 0;
 };
+bool psx_level0_interp_ok(const PsxLevel0Args& a);
 
 hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s);
 // per-tap texture coordinates exactly as the reference forms them (pyramid_alt.hip): what psx_launch_level0 runs when
@@ -182,6 +186,18 @@ struct PsxFixedOctaveArgs {
     const float* taps;          // host table: nlev rows of PSX_GAUSS_ALIGN floats
     hipEvent_t ev0, ev1;        // begin / end timestamps of the dispatch, or nullptr
 };
+// GaussMode VLFeat_Relative: one fused H + V launch per level (pyramid_interp.hip); fi / ispan: the level's row of the
+// interpolated table; psx_blur_interp_ok: the pair count the kernel is instantiated for
+bool psx_blur_interp_ok(int ispan);
+struct PsxInterpJob {
+    const float* src; float* dst; float* half_dst;     // half_dst: level 0 of the next octave (level L - 3 only), or nullptr
+    int W, H, pitch, half_pitch;
+    const float* fi; int ispan;                         // the level's row of the interpolated table (host), its odd span
+};
+hipError_t psx_launch_blur_interp(const PsxInterpJob& j, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t psx_launch_blur_interp2(const PsxInterpJob& a, const PsxInterpJob& b, hipStream_t s);
+int psx_blur_interp_grid(int W, int H, int ispan);
+bool psx_blur_interp_pair_ok(int W1, int H1, int ispan1, int W2, int H2, int ispan2);
 bool psx_fixed_octave0_ok(int w, int h, int W, int H);
 bool psx_fixed_octave_enabled();
 hipError_t psx_launch_fixed_octave(const PsxFixedOctaveArgs& a, hipStream_t s);

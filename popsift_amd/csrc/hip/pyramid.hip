@@ -23,6 +23,7 @@
 //   level 0 H (s_pyramid_build_ra.cu:17-55): pairs outermost-in, then centre, then *255
 #include "psx_internal.h"
 #include "blur_arith.h"
+#include "blur_interp.h"
 
 #include <hip/hip_ext.h>
 
@@ -910,6 +911,8 @@ struct L0Args {
     int nstrips, chunk_rows;
     PsxTaps taps;      // dd horizontal
     PsxTaps taps_v;    // inc[0] vertical
+    // GaussMode VLFeat_Relative (k_level0_x2<.., VNP > 0>): the vertical pass is the interpolated one (blur_interp.h)
+    float vg0, vmul[4], voff[4];
 };
 
 template <int R>
@@ -1139,7 +1142,10 @@ __global__ __launch_bounds__(NT, 4) void k_level0_fused(L0Args a)
 // T[i0] either way), so the plane is bit-identical (the GPU suite runs through it in every SiftMode).
 // Rows outside the plane (first / last chunk) replicate U(0) / U(H-1): patched in LDS on those steps only.
 // ---------------------------------------------------------------------------------------------
-template <int R, bool ISFLOAT, bool SHIFT1>
+// VNP > 0 (GaussMode VLFeat_Relative, level 0 of octave 0: normalizedSource::horiz + absoluteSourceInterpolated::vert,
+// s_pyramid_build.cu:505-512): the same staging and "dd" H pass, the vertical pass with VNP interpolated tap pairs
+// (psx_vinterp2x4, blur_interp.h); R >= 2 VNP, the H taps beyond their span are zero.
+template <int R, bool ISFLOAT, bool SHIFT1, int VNP = 0>
 __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
 {
     using G = Geom2<R>;
@@ -1147,8 +1153,12 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
     constexpr int NRW = SHIFT1 ? 3 : 4;                  // texel rows / columns a 4 x 4 block of outputs needs
     constexpr int NGRP = BR / 4 + 1;                     // aligned row groups that intersect a step of BR rows
     static_assert(NGRP * SW4 <= NT, "one block per thread");
+    static_assert(2 * VNP <= R, "the interpolated vertical pass reaches 2 VNP rows");
     __shared__ __attribute__((aligned(16))) float s_u[BR * SWA];
     __shared__ __attribute__((aligned(16))) float s_ring[(RING + MIRROR) * RS];
+    __shared__ __attribute__((aligned(16))) v4f s_vtab[VNP > 0 ? VNP : 1];   // VNP > 0: the V pass's weight table (blur_interp.h)
+    __shared__ __attribute__((aligned(16))) v4f s_htab[VNP > 0 ? VNP : 1];   //          (the survey's unused column half)
+    __shared__ unsigned s_vmask[2];
 
     const int lid   = xcd_remap(blockIdx.x, gridDim.x);
     const int t     = threadIdx.x;
@@ -1261,6 +1271,18 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
     };
 
     issue(0);
+    unsigned vmask = 0u;
+    if constexpr (VNP > 0) {
+        if (t < 2) s_vmask[t] = 0u;
+        if (t == 0) {
+#pragma unroll
+            for (int p = 0; p < VNP; p++) { s_vtab[p] = (v4f){0.0f, 0.0f, a.vmul[p], a.voff[p]}; s_htab[p] = (v4f){0.0f, 0.0f, a.vmul[p], a.voff[p]}; }
+        }
+        __syncthreads();
+        psx_interp_survey(VNP, t, NT, x0, 0, Y0, Y1 - Y0, (LDS_AS v4f*)s_htab, (LDS_AS v4f*)s_vtab, s_vmask);
+        __syncthreads();
+        vmask = __builtin_amdgcn_readfirstlane(s_vmask[1]);
+    }
     for (int k = 0; k < nsteps; k++) {
         commit(k);
         flush(k - 1);
@@ -1309,11 +1331,14 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
             const int r_out0 = Y0 + rel0;
             if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
                 const LDS_AS float* vp = (const LDS_AS float*)&s_ring[(rel0 & (RING - 1)) * RS + 2 * v_pp];
-                v2f v[VWIN];
-#pragma unroll
-                for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
                 v2f o[4];
-                vfilter2x4_km<R>(v, a.taps_v, o);
+                if constexpr (VNP > 0) psx_vinterp2x4<VNP, RS>(vp + (R - 2 * VNP) * RS, (const LDS_AS v4f*)s_vtab, vmask, a.vg0, r_out0, o);
+                else {
+                    v2f v[VWIN];
+#pragma unroll
+                    for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
+                    vfilter2x4_km<R>(v, a.taps_v, o);
+                }
                 asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
 #pragma unroll
                 for (int i = 0; i < 4; i++) pend[i] = o[i];
@@ -1501,6 +1526,29 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
             const dim3 grid(f.nstrips * nchunks), block(NT);
             // POPSIFT_LEVEL0_X2=0: round 3's k_level0_fused (general weights) instead of the x2-specialised kernel
             static const bool x2 = [] { const char* e = getenv("POPSIFT_LEVEL0_X2"); return !(e != nullptr && e[0] == '0'); }();
+            if constexpr (R == 8) {
+                if (h.v_ifilter != nullptr) {
+                    // VLFeat_Relative: the interpolated vertical pass; np pairs run on the next instantiation (zero-weight pairs)
+                    const int np = (h.v_ispan - 1) / 2;
+                    f.vg0 = h.v_ifilter[0];
+                    for (int p = 0; p < 4; p++) {
+                        const int offset = 2 * p + 1;
+                        const float u = p < np ? h.v_ifilter[offset] : 0.0f;
+                        f.vmul[p] = p < np ? h.v_ifilter[offset + 1] : 0.0f;
+                        f.voff[p] = offset + (1.0f - u);
+                    }
+                    const bool s1 = h.shift == 1.0f;
+                    if (np <= 3) {
+                        if (h.is_float) { if (s1) hipLaunchKernelGGL((k_level0_x2<R, true, true, 3>), grid, block, 0, s, f);  else hipLaunchKernelGGL((k_level0_x2<R, true, false, 3>), grid, block, 0, s, f); }
+                        else            { if (s1) hipLaunchKernelGGL((k_level0_x2<R, false, true, 3>), grid, block, 0, s, f); else hipLaunchKernelGGL((k_level0_x2<R, false, false, 3>), grid, block, 0, s, f); }
+                    } else {
+                        if (h.is_float) { if (s1) hipLaunchKernelGGL((k_level0_x2<R, true, true, 4>), grid, block, 0, s, f);  else hipLaunchKernelGGL((k_level0_x2<R, true, false, 4>), grid, block, 0, s, f); }
+                        else            { if (s1) hipLaunchKernelGGL((k_level0_x2<R, false, true, 4>), grid, block, 0, s, f); else hipLaunchKernelGGL((k_level0_x2<R, false, false, 4>), grid, block, 0, s, f); }
+                    }
+                    return hipGetLastError();
+                }
+            }
+            if (h.v_ifilter != nullptr) return hipErrorNotSupported;
             if (x2) {
                 const bool s1 = h.shift == 1.0f;
                 if (h.is_float) { if (s1) hipLaunchKernelGGL((k_level0_x2<R, true, true>), grid, block, 0, s, f);  else hipLaunchKernelGGL((k_level0_x2<R, true, false>), grid, block, 0, s, f); }
@@ -1512,6 +1560,7 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
             return hipGetLastError();
         }
     }
+    if (h.v_ifilter != nullptr) return hipErrorNotSupported;     // the interpolated vertical pass exists in the x2 kernel only
     const int pad = PSX_LEVEL0_PAD;
     const int wr = ((h.W + TW - 1) / TW) * TW;           // every strip reads full-width source rows
     UpArgs u;
@@ -1912,8 +1961,18 @@ bool psx_level0_exact(int w, int h, int W, int H)
     return (W >= w ? pow2_ratio(W, w) : pow2_ratio(w, W)) && (H >= h ? pow2_ratio(H, h) : pow2_ratio(h, H));
 }
 
+// level 0 with the interpolated vertical pass of GaussMode VLFeat_Relative (a.v_ifilter / a.v_ispan): covered by the x2 kernel for
+// up to 4 tap pairs and a "dd" radius up to 8
+bool psx_level0_interp_ok(const PsxLevel0Args& a)
+{
+    static const bool off = [] { const char* e = getenv("POPSIFT_INTERP_FUSED"); return e != nullptr && e[0] == '0'; }();
+    return !off && level0_fused_enabled() && a.W == 2 * a.w && a.H == 2 * a.h && a.w >= 4 && (a.shift == 1.0f || a.shift == 0.5f) &&
+           (a.v_ispan - 1) / 2 <= 4 && a.span_h - 1 <= 8 && psx_level0_exact(a.w, a.h, a.W, a.H);
+}
+
 hipError_t psx_launch_level0(const PsxLevel0Args& a, hipStream_t s)
 {
+    if (a.v_ifilter != nullptr) return psx_level0_interp_ok(a) ? launch_level0_r<8>(a, s) : hipErrorNotSupported;
     if (!psx_level0_exact(a.w, a.h, a.W, a.H)) return psx_launch_level0_literal(a, s);
     const int R = (a.span_h > a.span_v ? a.span_h : a.span_v) - 1;
     if (R <= 5)  return launch_level0_r<5>(a, s);

@@ -241,6 +241,53 @@ hipError_t psx_launch_level0_literal(const PsxLevel0Args& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// GaussMode VLFeat_Relative with the default scaling, every level on the fused kernels (pyramid_interp.hip): the diagonal
+// schedule of the default pyramid (psx_build_pyramid).  Level l of octave o needs level l - 1 of its octave, and level 0 of octave
+// o + 1 is written by the launch of level D = L - 3 of octave o; so (o, l) runs in launch slot l + D o, and the jobs of a slot -- two
+// for the default 3 levels per octave -- share ONE launch when both grids fit one round of resident workgroups.  The small
+// octaves, chains of ~8 us launches on their own, ride along with the octave above: 17 launches instead of 25 at 5 octaves.
+static hipError_t relative_diagonal(const PsxAltArgs& a, hipStream_t s)
+{
+    const PsxParams& P = *a.hp;
+    const int L = P.L, D = L - 3, noct = P.num_octaves;
+    auto job = [&](int o, int l) {
+        const PsxOctave& oc = P.oct[o];
+        PsxInterpJob j;
+        j.src = oc.data + (size_t)(l - 1) * oc.plane; j.dst = oc.data + (size_t)l * oc.plane;
+        const bool feeds = l == D && o + 1 < noct;
+        j.half_dst = feeds ? P.oct[o + 1].data : nullptr; j.half_pitch = feeds ? P.oct[o + 1].pitch : 0;
+        j.W = oc.w; j.H = oc.h; j.pitch = oc.pitch;
+        j.fi = a.inc_ifilter + l * PSX_GAUSS_ALIGN; j.ispan = a.inc_ispan[l];
+        return j;
+    };
+    for (int t = 1; t <= (L - 1) + D * (noct - 1); t++) {
+        int os[PSX_MAX_OCTAVES], n = 0;
+        for (int o = noct - 1; o >= 0; o--) {           // the deeper octave (the head of the dependency chain) first
+            const int l = t - D * o;
+            if (l >= 1 && l <= L - 1) os[n++] = o;
+        }
+        for (int i = 0; i < n;) {
+            const int o1 = os[i], l1 = t - D * o1;
+            hipError_t e;
+            if (i + 1 < n) {
+                const int o2 = os[i + 1], l2 = t - D * o2;
+                if (psx_blur_interp_pair_ok(P.oct[o1].w, P.oct[o1].h, a.inc_ispan[l1], P.oct[o2].w, P.oct[o2].h, a.inc_ispan[l2])) {
+                    e = psx_launch_blur_interp2(job(o1, l1), job(o2, l2), s);
+                    if (e != hipSuccess) return e;
+                    i += 2;
+                    continue;
+                }
+            }
+            e = psx_launch_blur_interp(job(o1, l1), s);
+            if (e != hipSuccess) return e;
+            i++;
+        }
+        for (int i = 0; i < n; i++)
+            if (t - D * os[i] == L - 1 && a.after_octave) { const hipError_t e = a.after_octave(a.user, os[i]); if (e != hipSuccess) return e; }
+    }
+    return hipSuccess;
+}
+
 // Pyramid::build_pyramid for every mode combination outside the default branch; mirrors build_pyramid() of
 // oracle/sift_oracle.c statement by statement.  Returns hipErrorInvalidValue for Fixed9 / Fixed15 with levels != 3
 // (the reference: POP_FATAL "Unsupported number of levels for making all octaves at once").
@@ -345,12 +392,42 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
                 hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(level), W, H, pitch, inci(level), a.inc_ispan[level]);
             }
         } else if (gm == PSX_GAUSS_VLFEAT_RELATIVE) {
+            bool all_fused = P.L >= 4;
+            for (int level = 1; level < P.L; level++) all_fused = all_fused && psx_blur_interp_ok(a.inc_ispan[level]);
+            static const bool diag = [] { const char* e = getenv("POPSIFT_INTERP_DIAGONAL"); return !(e != nullptr && e[0] == '0'); }();
             for (int level = 0; level < P.L; level++) {
+                if (level == 1 && o == 0 && all_fused && diag) {
+                    // every remaining level of the frame (and the extrema scans behind the octaves' last levels): diagonal schedule
+                    return relative_diagonal(a, s);
+                }
                 if (level == 0) {
                     if (o == 0) {
-                        hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, taps(a.dd_filter), a.dd_span[0], shift);
-                        hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(0), W, H, pitch, inci(0), a.inc_ispan[0]);
-                    } else downscale();
+                        // the x2 level-0 kernel of pyramid.hip with the interpolated vertical pass where it applies
+                        PsxLevel0Args l0;
+                        l0.img = a.img; l0.w = a.w; l0.h = a.h; l0.is_float = a.is_float;
+                        l0.dst = plane(0); l0.W = W; l0.H = H; l0.pitch = pitch;
+                        l0.tmp = a.up; l0.tmp_pitch = a.up_pitch; l0.shift = shift;
+                        l0.taps_h = taps(a.dd_filter); l0.span_h = a.dd_span[0]; l0.taps_v = inc(0); l0.span_v = a.inc_span[0];
+                        l0.v_ifilter = a.inc_ifilter; l0.v_ispan = a.inc_ispan[0];
+                        if (psx_level0_interp_ok(l0)) {
+                            const hipError_t e2 = psx_launch_level0(l0, s);
+                            if (e2 != hipSuccess) return e2;
+                        } else {
+                            hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, taps(a.dd_filter), a.dd_span[0], shift);
+                            hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(0), W, H, pitch, inci(0), a.inc_ispan[0]);
+                        }
+                    } else if (!next_l0_done) downscale();
+                    next_l0_done = false;
+                } else if (psx_blur_interp_ok(a.inc_ispan[level])) {
+                    // one fused launch per level (pyramid_interp.hip); level L - 3 also writes level 0 of the next octave
+                    const bool feeds = level == P.L - 3 && o + 1 < P.num_octaves;
+                    PsxInterpJob ij;
+                    ij.src = plane(level - 1); ij.dst = plane(level); ij.W = W; ij.H = H; ij.pitch = pitch;
+                    ij.half_dst = feeds ? P.oct[o + 1].data : nullptr; ij.half_pitch = feeds ? P.oct[o + 1].pitch : 0;
+                    ij.fi = a.inc_ifilter + level * PSX_GAUSS_ALIGN; ij.ispan = a.inc_ispan[level];
+                    const hipError_t e2 = psx_launch_blur_interp(ij, s);
+                    if (e2 != hipSuccess) return e2;
+                    if (feeds) next_l0_done = true;
                 } else {
                     hipLaunchKernelGGL(k_alt_interp<false>, g, b, 0, s, plane(level - 1), a.intm, W, H, pitch, inci(level), a.inc_ispan[level]);
                     hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(level), W, H, pitch, inci(level), a.inc_ispan[level]);

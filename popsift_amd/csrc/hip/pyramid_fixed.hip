@@ -10,7 +10,7 @@
 // (an image / octave-0 ratio other than x2).
 //
 // Shape: the marching strip of pyramid.hip.  One 256-thread workgroup owns a 64-column strip and marches down a chunk of
-// rows in steps of BR rows (28 at 9 taps, 30 at 15).  Per step:
+// rows in steps of BR rows (28 at 9 taps, 24 at 15).  Per step:
 //   * stage BR source rows (64 + 2 HALO columns, row-coalesced 16-byte loads issued a step ahead) into an LDS ring of 64
 //     rows -- level 0 of the octave is read from HBM exactly once and serves every derived level;
 //   * V pass: a thread owns (2 adjacent columns, VR rows): it reads its VR + 2 SHIFT ring rows ONCE (ds_read_b64),
@@ -58,25 +58,29 @@ struct GeomF {
     static constexpr int SW   = TW + 2 * HALO;            // staged columns: 72 / 80
     static constexpr int SW4  = SW / 4;
     static constexpr int NP   = SW / 2;                   // column pairs of the V pass: 36 / 40
-    static constexpr int VR   = S <= 4 ? 4 : 5;           // rows per V thread
+    static constexpr int VR   = 4;                        // rows per V thread (two row pairs)
     static constexpr int NRG  = NT / NP;                  // row groups: 7 / 6
-    static constexpr int BR   = VR * NRG;                 // rows per step: 28 / 30
+    static constexpr int BR   = VR * NRG;                 // rows per step: 28 / 24
     static constexpr int RING = 64;
     static constexpr int VWIN = VR + 2 * S;               // ring rows a V thread reads
     static constexpr int MIRROR = VWIN - 1;               // slots < MIRROR are duplicated at slot + RING
     static constexpr int RSS  = SW + 4;                   // ring row stride (floats), 16-byte aligned rows
-    // V-result rows: 80 floats apart.  The H pass reads 16-byte windows with lanes = (row, quad 0..15); a ds_read_b128
-    // lane group is {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31}, i.e. quads {0-3, 12-15} of one row + quads {4-11} of the row
-    // that lanes 16-31 work on: conflict free when the two rows are a multiple of 64 floats apart -- rows 4 apart at stride 80
-    static constexpr int VS   = 80;
-    static constexpr int NWIN = (4 + 2 * HALO) / 4;       // 16-byte chunks of an H window: 3 / 5
+    // V results in LDS: [row pair][column][row of the pair] -- the H pass is packed over two ROWS, so that every tap pair
+    // (column c - i, column c + i) of both rows is an aligned register pair whatever the parity of i (packing adjacent
+    // columns needs a register move for every odd tap).  A row pair is VS2 floats long; the H pass reads 16-byte chunks
+    // (2 columns x 2 rows) with lanes = (row pair, column quad 0..15): a lane's chunks are 32 bytes apart, and a
+    // ds_read_b128 lane group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) takes quads {0-3, 12-15} of one row pair and
+    // quads {4-11} of the next: conflict free when consecutive row pairs are an odd number of 16-byte chunks apart
+    static constexpr int VS2  = 2 * SW + 4;               // 148 / 164 floats
+    static constexpr int NRP  = BR / 2;                   // row pairs per step: 14 / 12
+    static constexpr int NWIN = (4 + 2 * HALO) / 2;       // 16-byte chunks of an H window: 6 / 10
     static constexpr int NLD  = (BR * SW4 + NT - 1) / NT; // staging slots per thread (plane source)
     static constexpr int NGRP = (BR + 3) / 4 + 1;         // aligned 4-row groups of U a step can touch (image source)
-    static constexpr int LDS_BYTES = ((RING + MIRROR) * RSS + 2 * BR * VS) * 4;
+    static constexpr int LDS_BYTES = ((RING + MIRROR) * RSS + 2 * NRP * VS2) * 4;
     static constexpr int WGPC = (160 * 1024) / LDS_BYTES > 4 ? 4 : (160 * 1024) / LDS_BYTES;
     static_assert(BR + 2 * S <= RING, "ring too small");
     static_assert(NGRP * SW4 <= NT, "one 4 x 4 block of U per thread");
-    static_assert(SW <= VS, "V-result rows too short");
+    static_assert((VS2 / 4) % 2 == 1 && NRP * 16 <= NT, "H pass layout");
 };
 
 template <int S, int NLEV>
@@ -104,10 +108,10 @@ __global__ __launch_bounds__(NT, GeomF<S>::WGPC) void k_fixed_octave(FixedArgs<S
 {
     using G = GeomF<S>;
     constexpr int HALO = G::HALO, SW4 = G::SW4, NP = G::NP, VR = G::VR, NRG = G::NRG, BR = G::BR, RING = G::RING;
-    constexpr int VWIN = G::VWIN, MIRROR = G::MIRROR, RSS = G::RSS, VS = G::VS, NWIN = G::NWIN, NLD = G::NLD, NGRP = G::NGRP;
+    constexpr int VWIN = G::VWIN, MIRROR = G::MIRROR, RSS = G::RSS, VS2 = G::VS2, NRP = G::NRP, NWIN = G::NWIN, NLD = G::NLD, NGRP = G::NGRP;
     constexpr bool ISFLOAT = SRC == SRC_F32X2;
     __shared__ __attribute__((aligned(16))) float s_ring[(RING + MIRROR) * RSS];
-    __shared__ __attribute__((aligned(16))) float s_v[2 * BR * VS];      // rows BR .. 31 of the second buffer (idle lanes of the H pass) read past the end: LDS returns 0, nothing is stored
+    __shared__ __attribute__((aligned(16))) float s_v[2 * NRP * VS2];
 
     const int t     = threadIdx.x;
     const int lid   = psx_xcd_remap(blockIdx.x, gridDim.x);
@@ -129,9 +133,9 @@ __global__ __launch_bounds__(NT, GeomF<S>::WGPC) void k_fixed_octave(FixedArgs<S
     // ---- V pass geometry: thread = (column pair, VR rows) ----
     const int v_p = t % NP, v_rg = t / NP;
     const bool v_on = v_rg < NRG;
-    // ---- H pass geometry: thread = (row, column quad); lanes 0-15 / 16-31 of a wave work on rows 4 apart ----
-    const int h_quad = t & 15;
-    const int h_row0 = (t >> 6) + 4 * ((t >> 4) & 1) + 8 * ((t >> 5) & 1);
+    // ---- H pass geometry: thread = (row pair, column quad): 4 columns of 2 rows ----
+    const int h_quad = t & 15, h_rp = t >> 4;
+    const bool h_on = h_rp < NRP;
     const int h_x = x0 + 4 * h_quad;
     GLOBAL_AS float* const gdst = (GLOBAL_AS float*)a.dst;
     GLOBAL_AS float* const ghalf = (GLOBAL_AS float*)a.half_dst;
@@ -164,61 +168,61 @@ __global__ __launch_bounds__(NT, GeomF<S>::WGPC) void k_fixed_octave(FixedArgs<S
     };
     auto vwrite = [&](const int l, const int buf) __attribute__((always_inline)) {
         if (!v_on) return;
-        float* bp = &s_v[buf * BR * VS + (v_rg * VR) * VS + 2 * v_p];
+        float* bp = &s_v[buf * NRP * VS2 + (v_rg * (VR / 2)) * VS2 + 4 * v_p];
 #pragma unroll
-        for (int i = 0; i < VR; i++) *reinterpret_cast<v2f*>(bp + i * VS) = vo[l][i];
+        for (int i = 0; i < VR; i += 2)     // (row i, row i+1) of column 2 v_p, then of column 2 v_p + 1: a 2 x 2 transpose in registers
+            *reinterpret_cast<v4f*>(bp + (i / 2) * VS2) = (v4f){vo[l][i].x, vo[l][i + 1].x, vo[l][i].y, vo[l][i + 1].y};
     };
     // FAST (workgroup uniform): every row of the step lies inside the chunk and the strip is a full one -- all but the first
-    // step of a chunk, its last one and the plane's last strip: the only per-lane condition left is the idle quarter of the
-    // second round (rows >= BR), which still computes (on rows of the LDS buffer nobody stores) and skips the store
+    // step of a chunk, its last one and the plane's last strip
     auto hpass = [&](const int k, const int l, const int buf, auto fast_c) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_c)::value;
-        float win[2][4 + 2 * HALO];
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int row = h_row0 + 16 * rnd;
-            const LDS_AS float* hp = (const LDS_AS float*)&s_v[buf * BR * VS + row * VS + 4 * h_quad];
+        if (!h_on) return;
+        v2f win[4 + 2 * HALO];                                           // (row 0, row 1) of the window's columns
+        {
+            const LDS_AS float* hp = (const LDS_AS float*)&s_v[buf * NRP * VS2 + h_rp * VS2 + 8 * h_quad];
 #pragma unroll
             for (int q = 0; q < NWIN; q++) {
                 const v4f w4 = ((const volatile LDS_AS v4f*)hp)[q];
-                win[rnd][4 * q + 0] = w4.x; win[rnd][4 * q + 1] = w4.y; win[rnd][4 * q + 2] = w4.z; win[rnd][4 * q + 3] = w4.w;
+                win[2 * q] = (v2f){w4.x, w4.y}; win[2 * q + 1] = (v2f){w4.z, w4.w};
             }
         }
+        v2f out[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = win[HALO + e] * (v2f){a.g[l][0], a.g[l][0]};
+#pragma unroll
+        for (int i = 1; i <= S; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) out[e] = pk_fma(win[HALO + e - i] + win[HALO + e + i], a.g[l][i], out[e]);
+        if (SRC != SRC_PLANE) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) out[e] = out[e] * (v2f){a.scale, a.scale};
+        }
+        const int r = Y0 + k * BR - 2 * S + 2 * h_rp;                    // rows r, r + 1
+        GLOBAL_AS float* dp = gdst + (size_t)l * a.plane + (size_t)r * a.pitch + h_x;
         const bool halve = l == a.half_level && ghalf != nullptr;         // uniform
+        // get_by_2_pick_every_second: rows and columns 0, 2, 4, .. of level L - 3 are level 0 of the next octave; which of
+        // the pair's rows is the even one is workgroup uniform (Y0 + k BR - 2 S is)
+        const int re = (r & 1) ? r + 1 : r;
+        const v2f hv = (r & 1) ? (v2f){out[0].y, out[2].y} : (v2f){out[0].x, out[2].x};
+        GLOBAL_AS float* hd = ghalf + (size_t)(re >> 1) * a.half_pitch + (h_x >> 1);
+        if constexpr (FAST) {
+            *reinterpret_cast<GLOBAL_AS v4f*>(dp) = (v4f){out[0].x, out[1].x, out[2].x, out[3].x};
+            *reinterpret_cast<GLOBAL_AS v4f*>(dp + a.pitch) = (v4f){out[0].y, out[1].y, out[2].y, out[3].y};
+            if (halve) *reinterpret_cast<GLOBAL_AS v2f*>(hd) = hv;
+        } else {
+            if (h_x < a.W) {
 #pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int row = h_row0 + 16 * rnd;
-            float out[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) out[e] = win[rnd][HALO + e] * a.g[l][0];
-#pragma unroll
-            for (int i = 1; i <= S; i++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) out[e] = fmaf(win[rnd][HALO + e - i] + win[rnd][HALO + e + i], a.g[l][i], out[e]);
-            if (SRC != SRC_PLANE) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) out[e] = out[e] * a.scale;
-            }
-            const int r = Y0 + k * BR - 2 * S + row;
-            GLOBAL_AS float* dp = gdst + (size_t)l * a.plane + (size_t)r * a.pitch + h_x;
-            GLOBAL_AS float* hd = ghalf + (size_t)(r >> 1) * a.half_pitch + (h_x >> 1);
-            if constexpr (FAST) {
-                if (rnd == 0 || row < BR) {
-                    *reinterpret_cast<GLOBAL_AS v4f*>(dp) = (v4f){out[0], out[1], out[2], out[3]};
-                    // get_by_2_pick_every_second: rows and columns 0, 2, 4, .. of level L - 3 are level 0 of the next octave
-                    if (halve && (r & 1) == 0) *reinterpret_cast<GLOBAL_AS v2f*>(hd) = (v2f){out[0], out[2]};
+                for (int j = 0; j < 2; j++) {
+                    if (r + j < Y0 || r + j >= Y1) continue;
+                    GLOBAL_AS float* dj = dp + (size_t)j * a.pitch;
+                    const v4f o = j ? (v4f){out[0].y, out[1].y, out[2].y, out[3].y} : (v4f){out[0].x, out[1].x, out[2].x, out[3].x};
+                    if (h_x + 3 < a.W) *reinterpret_cast<GLOBAL_AS v4f*>(dj) = o;
+                    else { dj[0] = o.x; if (h_x + 1 < a.W) dj[1] = o.y; if (h_x + 2 < a.W) dj[2] = o.z; }
                 }
-            } else {
-                if (row < BR && r >= Y0 && r < Y1 && h_x < a.W) {
-                    if (h_x + 3 < a.W) *reinterpret_cast<GLOBAL_AS v4f*>(dp) = (v4f){out[0], out[1], out[2], out[3]};
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 3; e++) if (h_x + e < a.W) dp[e] = out[e];
-                    }
-                    if (halve && (r & 1) == 0) {
-                        if (h_x + 2 < a.W) *reinterpret_cast<GLOBAL_AS v2f*>(hd) = (v2f){out[0], out[2]};
-                        else hd[0] = out[0];
-                    }
+                if (halve && re >= Y0 && re < Y1) {
+                    if (h_x + 2 < a.W) *reinterpret_cast<GLOBAL_AS v2f*>(hd) = hv;
+                    else hd[0] = hv.x;
                 }
             }
         }
@@ -374,7 +378,9 @@ void fixed_chunking(int W, int H, int& chunk_rows, int& nchunks)
     static const int want = [] { const char* e = getenv("POPSIFT_FIXED_WGS"); return e ? atoi(e) : 0; }();
     const int slots = want > 0 ? want : G::WGPC * device_cus();
     int maxc = slots / nstrips; if (maxc < 1) maxc = 1;
-    const int cr_min = 2 * G::BR - 2 * S;
+    // POPSIFT_FIXED_MINSTEPS: steps per chunk of a plane that does not fill the chip (measurement switch)
+    static const int minsteps = [] { const char* e = getenv("POPSIFT_FIXED_MINSTEPS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 1; }();
+    const int cr_min = minsteps * G::BR - 2 * S;
     int nc = (H + cr_min - 1) / cr_min; if (nc > maxc) nc = maxc; if (nc < 1) nc = 1;
     int cr = (H + nc - 1) / nc;
     // full steps: a chunk of n steps yields n BR - 2 SHIFT rows

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p popsift_amd/lib_phase
-for f in pyramid pyramid_tile pyramid_alt pyramid_fixed extrema orient_desc gridfilter match util api; do
+for f in pyramid pyramid_tile pyramid_alt pyramid_fixed pyramid_interp extrema orient_desc gridfilter match util api; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPSX_PHASE_TIMING \
       -I include -I popsift_amd/csrc/hip -c popsift_amd/csrc/hip/$f.hip -o popsift_amd/lib_phase/$f.o &
 done
