@@ -913,6 +913,7 @@ struct L0Args {
     PsxTaps taps_v;    // inc[0] vertical
     // GaussMode VLFeat_Relative (k_level0_x2<.., VNP > 0>): the vertical pass is the interpolated one (blur_interp.h)
     float vg0, vmul[4], voff[4];
+    int vforce;        // test switch (POPSIFT_INTERP_LITERAL=1): every weight from its coordinate
 };
 
 template <int R>
@@ -1281,7 +1282,7 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
         __syncthreads();
         psx_interp_survey(VNP, t, NT, x0, 0, Y0, Y1 - Y0, (LDS_AS v4f*)s_htab, (LDS_AS v4f*)s_vtab, s_vmask);
         __syncthreads();
-        vmask = __builtin_amdgcn_readfirstlane(s_vmask[1]);
+        vmask = a.vforce ? ~0u : __builtin_amdgcn_readfirstlane(s_vmask[1]);
     }
     for (int k = 0; k < nsteps; k++) {
         commit(k);
@@ -1531,6 +1532,8 @@ hipError_t launch_level0_r(const PsxLevel0Args& h, hipStream_t s)
                     // VLFeat_Relative: the interpolated vertical pass; np pairs run on the next instantiation (zero-weight pairs)
                     const int np = (h.v_ispan - 1) / 2;
                     f.vg0 = h.v_ifilter[0];
+                    static const int force = [] { const char* e = getenv("POPSIFT_INTERP_LITERAL"); return e != nullptr && e[0] == '1' ? 1 : 0; }();
+                    f.vforce = force;
                     for (int p = 0; p < 4; p++) {
                         const int offset = 2 * p + 1;
                         const float u = p < np ? h.v_ifilter[offset] : 0.0f;

@@ -387,6 +387,16 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
                     if (e2 != hipSuccess) return e2;
                     continue;
                 }
+                if (level > 0 && psx_blur_interp_ok(a.inc_ispan[level])) {
+                    // the fused kernel of pyramid_interp.hip (no decimation: ScaleDirect takes level 0 of every octave from the input)
+                    PsxInterpJob ij;
+                    ij.src = plane(level - 1); ij.dst = plane(level); ij.W = W; ij.H = H; ij.pitch = pitch;
+                    ij.half_dst = nullptr; ij.half_pitch = 0;
+                    ij.fi = a.inc_ifilter + level * PSX_GAUSS_ALIGN; ij.ispan = a.inc_ispan[level];
+                    const hipError_t e2 = psx_launch_blur_interp(ij, s);
+                    if (e2 != hipSuccess) return e2;
+                    continue;
+                }
                 if (level == 0) hipLaunchKernelGGL(k_alt_h_input, g, b, 0, s, img, a.intm, W, H, pitch, taps(a.dd_filter + o * PSX_GAUSS_ALIGN), a.dd_span[o], shift);
                 else hipLaunchKernelGGL(k_alt_interp<false>, g, b, 0, s, plane(level - 1), a.intm, W, H, pitch, inci(level), a.inc_ispan[level]);
                 hipLaunchKernelGGL(k_alt_interp<true>, g, b, 0, s, a.intm, plane(level), W, H, pitch, inci(level), a.inc_ispan[level]);

@@ -3,7 +3,7 @@
 // kernel per level.  The reference reads, for every pair of taps (offset, offset + 1), ONE texel of a linear-filtering
 // texture at distance off = offset + (1 - u) on either side, u = a / (a + b) for the pair's weights a, b, and multiplies the sum by
 // (a + b) (GaussTable::transformBlurTable).  The texture unit's linear filter has 1.8 fixed-point weights, so the result is
-// not the plain blur: this mode is its own numerical result with its own oracle branch.  pyramid_alt.hip holds the
+// not the plain blur: this mode is its own numerical result (its own branch in oracle/sift_oracle.c).  pyramid_alt.hip holds the
 // one-thread-per-pixel kernels (k_alt_interp, two launches per level through an intermediate plane) that this file replaces
 // for pair counts up to 8 (sigma up to ~4); they remain the path beyond.
 //
@@ -73,6 +73,7 @@ struct InterpArgs {
     float*       half_dst;          // next octave level 0 (pick every second), or nullptr
     int W, H, pitch, half_pitch;
     int nstrips, chunk_rows;
+    int force_literal;              // test switch (POPSIFT_INTERP_LITERAL=1): every weight from its coordinate, as if none were uniform
     float g0;                       // centre weight
     float mul[NP];                  // a + b of pair p
     float off[NP];                  // offset + (1 - u) of pair p, offset = 2p + 1
@@ -187,8 +188,8 @@ __device__ __forceinline__ void interp_body(const InterpArgs<NP>& a, const int l
     issue(0);                                  // the first rows are on their way while the weights are surveyed
     psx_interp_survey(NP, t, NT, x0, min(TW, a.W - x0), Y0, Y1 - Y0, (LDS_AS v4f*)s_tab[0], (LDS_AS v4f*)s_tab[1], s_mask);
     __syncthreads();
-    const unsigned hmask = __builtin_amdgcn_readfirstlane(s_mask[0]);
-    const unsigned vmask = __builtin_amdgcn_readfirstlane(s_mask[1]);
+    const unsigned hmask = a.force_literal ? ~0u : __builtin_amdgcn_readfirstlane(s_mask[0]);
+    const unsigned vmask = a.force_literal ? ~0u : __builtin_amdgcn_readfirstlane(s_mask[1]);
     for (int k = 0; k < nsteps; k++) {
         commit();
         flush(k - 1);
@@ -292,6 +293,8 @@ int fill_interp(InterpArgs<NP>& a, const PsxInterpJob& j)
     int nchunks;
     interp_chunking(j.W, j.H, GeomI<NP>::RI, a.chunk_rows, nchunks);
     const int npairs = (j.ispan - 1) / 2;
+    static const int force = [] { const char* e = getenv("POPSIFT_INTERP_LITERAL"); return e != nullptr && e[0] == '1' ? 1 : 0; }();
+    a.force_literal = force;
     a.g0 = j.fi[0];
     for (int p = 0; p < NP; p++) {
         const int offset = 2 * p + 1;

@@ -142,3 +142,24 @@ def test_alt_descriptor_window_equals_plane():
     assert len(res["1"]) == 12 and all(r["n"] > 50 for r in res["1"])
     for a, b in zip(res["1"], res["0"]):
         assert a == b, (a, b)
+
+
+def test_fused_mode_kernels_equal_per_level_kernels():
+    """Round 6: Fixed9 / Fixed15 run one kernel per octave (pyramid_fixed.hip) and VLFeat_Relative one fused kernel per level
+    (pyramid_interp.hip, blur_interp.h).  Both must give the bits of the per-level kernels of pyramid_alt.hip, which the tests
+    above hold to the oracle and the reference fixtures at small sizes: here at 1080p and at sizes whose upsampled planes cross
+    2048 / 4096 columns (where the relative mode's fixed-point weights change with the coordinate's binade), byte and float
+    input, every scaling variant.  POPSIFT_INTERP_LITERAL=1 forces the per-element (literal) weight path everywhere."""
+    import json, os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for tag, env in (("fused", {}), ("per_level", dict(POPSIFT_FIXED_FUSED="0", POPSIFT_INTERP_FUSED="0")),
+                     ("literal", dict(POPSIFT_INTERP_LITERAL="1")), ("no_diagonal", dict(POPSIFT_INTERP_DIAGONAL="0"))):
+        p = subprocess.run([sys.executable, os.path.join(here, "fused_modes_worker.py")], capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tag] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(res["fused"]) >= 12 and sum(r["n"] > 100 for r in res["fused"]) >= 10
+    for tag in ("per_level", "literal", "no_diagonal"):
+        for a, b in zip(res["fused"], res[tag]):
+            assert a == b, (tag, a, b)
