@@ -186,6 +186,7 @@ class GpuBackend:
     """Everything of the bench that touches the GPU (tests/test_distributed_cpu.py swaps in a stub with the same
     interface to run the rank / seed / step / reduce control flow under gloo on CPU)."""
     dist_backend = "nccl"
+    device_override = None      # --ranks-on-device D: every rank uses GPU D (the multi-process path on a one-GPU box)
 
     def __init__(self, rank, local_rank, world):
         import numpy as np
@@ -194,6 +195,8 @@ class GpuBackend:
         from popsift_amd.synth import synth
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+        if self.device_override is not None:
+            local_rank = self.device_override
         torch.cuda.set_device(local_rank)
         pin_process_to_gpu_numa_node(capi, local_rank)
         self.np, self.torch, self.capi = np, torch, capi
@@ -213,7 +216,8 @@ class GpuBackend:
         self.torch.cuda.synchronize()
 
     def reduce_tensor(self, v):
-        return self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        # gloo (--dist-backend gloo) reduces host tensors; RCCL device tensors
+        return self.torch.tensor([v], dtype=self.torch.float64, device="cpu" if self.dist_backend == "gloo" else self.dev)
 
     # ---- leg 1: the public C++ API, host frames in, FeaturesHost out ----
     def e2e_open(self, profile="headline"):
@@ -302,6 +306,10 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if getattr(args, "dist_backend", None):
+        backend_cls.dist_backend = args.dist_backend
+    if getattr(args, "ranks_on_device", None) is not None:
+        backend_cls.device_override = args.ranks_on_device
     if args.gpus > 1 or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -315,7 +323,7 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
     def barrier():
         if dist is not None:
             if backend_cls.dist_backend == "nccl":
-                dist.barrier(device_ids=[local_rank])      # RCCL: name the rank's device explicitly
+                dist.barrier(device_ids=[be.device if hasattr(be, "device") else local_rank])      # RCCL: name the rank's device explicitly
             else:
                 dist.barrier()
         be.sync()
@@ -394,7 +402,7 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
         d["within_budget"] = bool(d["kp_miss"] <= b["kp"] and d["ori_miss"] <= b["ori"] and d["desc_miss"] <= b["desc"])
         d["ranks_checked"] = world
         d["what"] = ("4 timed frames of every rank re-run through the same PopSift object after the timed region, matched "
-                     "against oracle/ (tolerances 1e-3, budget 0 keypoints, 1 + n/10000 orientations / descriptors)")
+                     "against oracle/ (tolerances 1e-3, budget 0 keypoints, 8 orientations / descriptors per 100 000 keypoints rounded down: tests/parity.py::budget)")
         return d
 
     # ---- leg 1 (headline): the public C++ API, host frames in, FeaturesHost out; config 1's Config (VLFeat mode) ----
@@ -404,10 +412,11 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
     # ---- outside the timed region, same PopSift object: parity of timed frames, sustained run, sparse frame set ----
     parity = sustained = sparse = popsift_leg = caller_leg = None
     extra_legs = hasattr(be, "e2e_parity") and not args.no_extras
+    quick = bool(getattr(args, "quick", False))      # the headline leg, its parity check and the C-ABI legs only
     if extra_legs:
         if not args.no_parity:
             parity = parity_all_ranks()
-        if world == 1 and SUSTAINED_S > 0:
+        if world == 1 and SUSTAINED_S > 0 and not quick:
             wins, clk, n_s, kp_s = [], [], 0, 0
             t_s0 = tw = time.perf_counter()
             while n_s < SUSTAINED_FRAMES or time.perf_counter() - t_s0 < SUSTAINED_S:
@@ -433,18 +442,19 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
                          "sclk_mhz_min": min(clk) if clk else None, "sclk_mhz_max": max(clk) if clk else None,
                          "keypoints_per_s": round(kp_s / dt_s, 1)}
         n_leg = world * per_rank * args.steps
-        be.e2e_select("sparse")
-        e2e["i"] = 0
-        dt_sp, kps_sp, _ = timed(e2e_step, e2e_drain)
-        be.e2e_select("dense")
-        sparse = {"value": round(n_leg * W * H / dt_sp / 1e6, 1), "unit": "Mpix/s",
-                  "keypoints_per_frame": round(kps_sp / n_leg, 1),
-                  "keypoints_per_1000px": round(kps_sp / n_leg / (W * H / 1000.0), 2),
-                  "keypoints_per_s": round(kps_sp / dt_sp, 1),
-                  "what": "the end-to-end leg on frames with ~2 keypoints / 1000 px (popsift_amd/synth.py sparse=True)"}
+        if not quick:
+            be.e2e_select("sparse")
+            e2e["i"] = 0
+            dt_sp, kps_sp, _ = timed(e2e_step, e2e_drain)
+            be.e2e_select("dense")
+            sparse = {"value": round(n_leg * W * H / dt_sp / 1e6, 1), "unit": "Mpix/s",
+                      "keypoints_per_frame": round(kps_sp / n_leg, 1),
+                      "keypoints_per_1000px": round(kps_sp / n_leg / (W * H / 1000.0), 2),
+                      "keypoints_per_s": round(kps_sp / dt_sp, 1),
+                      "what": "the end-to-end leg on frames with ~2 keypoints / 1000 px (popsift_amd/synth.py sparse=True)"}
     be.e2e_close()
 
-    if extra_legs:
+    if extra_legs and not quick:
         # ---- the same leg with setMode(PopSift): the Config rounds 1-3 quoted as `value` ----
         be.e2e_open("popsift")
         e2e["i"] = 0
@@ -549,7 +559,7 @@ def run(args, backend_cls=GpuBackend, out=sys.stdout):
             "frac_device_resident": round(pipe_b * n_frames / dt_dev / 1e9 / HBM_PEAK_GBS / world, 4),
             "what": "A_min of SURVEY.md 8d (68 N0 + 72 sum N_o + input) x frames / time, per GPU fraction of 8 TB/s"}
         t_wall["abi_legs"] = time.perf_counter()
-        if not args.no_extras:
+        if not args.no_extras and not quick:
             result.update(be.extras(args, world))
         t_wall["extras"] = time.perf_counter()
         # where this run's wall time went (the driver allows the default run about a minute)
@@ -578,6 +588,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of 4 timed frames")
     ap.add_argument("--no-extras", action="store_true", help="only the three timed legs")
     ap.add_argument("--no-host-ceiling", action="store_true", help="skip the host_ceiling leg (it starts 9 helper processes)")
+    ap.add_argument("--quick", action="store_true",
+                    help="only the headline leg, the parity check of its frames and the two C-ABI legs (tests of the multi-process path)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default=None,
+                    help="torch.distributed backend of the N > 1 launch (default nccl = RCCL); gloo reduces the two timing scalars on the host")
+    ap.add_argument("--ranks-on-device", type=int, default=None,
+                    help="every rank uses this GPU instead of LOCAL_RANK: runs the real multi-process path (GpuBackend, barriers, NUMA "
+                         "pinning, per-rank parity) on a box with one GPU; the aggregate is then ONE GPU's rate shared by the ranks")
     ap.add_argument("--extras", action="store_true",
                     help="also the slow informational legs (every alternative Gauss / descriptor mode, BASELINE config 3, the full host-ceiling sweep)")
     return ap.parse_args(argv)
@@ -671,7 +688,7 @@ def match_leg(capi, np, device):
         gp = n * n / dt / 1e9
         return {"left": n, "right": n, "seconds": round(dt, 5), "gpairs_per_s": round(gp, 1),
                 "exact_scan_valu_peak_gpairs_per_s": round(256 * 4 * 16 * 2.4e9 / 165 / 1e9, 1),
-                "what": "psx_match on device-resident descriptors (host call to results in host memory): k_match_prep x 2, seeding pass, "
+                "what": "psx_match on device-resident descriptors (host call to results in host memory): k_match_norms / k_match_scale / k_match_cvt of both sides, seeding pass, "
                         "k_match_mfma (v_mfma_f32_32x32x16_f16 + proven error margin), k_match_exact on the candidates; bit-identical to "
                         "the reference's scan (tests/test_gpu_parity.py::test_match_bit_exact, ::test_match_mfma_prefilter_equals_exact_scan); "
                         "POPSIFT_MATCH_MFMA=0 = the exact scan of every pair (rounds 1-4: 63-82 G pairs/s)"}
@@ -734,6 +751,9 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
         "avg_launch_ms": round(avg_ms, 5), "per_level_ms": [round(m, 5) for m in per_level],
+        "timing_method": "begin / end timestamps of each k_blur dispatch (hipExtLaunchKernelGGL events on the context's stream) inside real "
+                         "psx_extract calls, 20 frames averaged; rocprofv3 --kernel-trace of the same kernels: profiles/r06_single_kernel_by_grid.txt "
+                         "(the two agree within 4-9 % per level; the trace run is profiled, this one is not)",
         "bytes_per_launch": by, "traffic": traffic,
         "traffic_stale": traffic_stale,
         "traffic_source": "profiles/pmc_summary.json (%s): a committed rocprofv3 --pmc pass of THIS kernel source (SHA-1 of pyramid.hip + "
@@ -777,6 +797,35 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
                                "what": "algorithmic bytes of the whole pyramid build (SURVEY.md 8d: 44 N0 + 48 sum N_o + input) / "
                                        "pyramid stage time of one frame on one context (HIP events around psx_build_pyramid)"}
 
+    # the same stage the way the headline runs it: pipelined.  psx_build_pyramid only (no extrema scan rides along: the
+    # interleaving is psx_extract's), all contexts in flight round-robin, device-resident frames
+    try:
+        nctx = len(ctxs)
+        for i, c in enumerate(ctxs):
+            c.set_input_tensor(frames[i % len(frames)])
+        best = None
+        n_pipe = 2400
+        for rep in range(2):
+            t1 = time.perf_counter()
+            for i in range(n_pipe):
+                c = ctxs[i % nctx]
+                if i >= nctx:
+                    c.sync()
+                c.build_pyramid()
+            for c in ctxs:
+                c.sync()
+            dtp = time.perf_counter() - t1
+            best = dtp if best is None or dtp < best else best
+        pipe_gbs = stage_b * n_pipe / best / 1e9
+        ex["roofline"]["stage_pipelined"] = {
+            "bytes": stage_b, "frames": n_pipe, "contexts": nctx, "ms_per_frame": round(best / n_pipe * 1e3, 4),
+            "achieved": round(pipe_gbs, 1), "unit": "GB/s", "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
+            "frac_of_measured_copy": round(pipe_gbs / copy_gbs, 4),
+            "what": "the same algorithmic bytes x %d frames / wall time of psx_build_pyramid alone on %d contexts in flight "
+                    "(round-robin, each context waits for ITS previous frame only): the regime the headline runs in" % (n_pipe, nctx)}
+    except Exception as e:
+        ex["roofline"]["stage_pipelined"] = "failed: %s" % e
+
     lap("single_frame")
     # ---- BASELINE config 5 stand-in and the matcher (always on; a few seconds) ----
     ex["config5"] = config5_leg(capi, np, device)
@@ -819,6 +868,29 @@ def extras(args, capi, torch, np, ctxs, frames, frames_np, world, device):
             ca.close()
         alt["default"] = round(single_ms, 4)
         ex["alt_modes_ms"] = alt
+        # GaussMode Fixed9 / Fixed15: the one-kernel octave (pyramid_fixed.hip).  Octave 0 = six planes written from the
+        # input image: 24 B per octave-0 pixel + the image, timed like `roofline` (begin / end timestamps of the dispatch
+        # inside real psx_extract calls)
+        for name, gm in (("fixed9", 4), ("fixed15", 5)):
+            cf = capi.Context(capi.default_config(**dict(HEADLINE_KW, gauss_mode=gm)), device=device)
+            cf.set_input_tensor(frames[0])
+            cf.enable_blur_probe(True)
+            acc, nb = 0.0, 0
+            for it in range(14):
+                cf.extract()
+                msf, byf = cf.blur_probe_times()
+                if it >= 4 and msf:
+                    acc += msf[0]; nb += 1
+            cf.enable_timers(True)
+            cf.extract()
+            stf = cf.stage_times()
+            cf.close()
+            if nb:
+                gbs = byf / (acc / nb * 1e-3) / 1e9
+                ex["roofline"][name] = {"kernel": "k_fixed_octave (octave 0, 3840x2160: levels 0..5 from the u8 image in one launch)",
+                                        "bytes_per_launch": byf, "avg_launch_ms": round(acc / nb, 5), "achieved": round(gbs, 1), "unit": "GB/s",
+                                        "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / copy_gbs, 4),
+                                        "pyramid_stage_ms": round(stf[0], 4)}
     except Exception as e:
         ex["alt_modes_ms"] = str(e) if str(e).startswith("skipped") else "failed: %s" % e
 

@@ -971,7 +971,14 @@ int psx_build_pyramid(psx_ctx* ctx)
             return psx_launch_extrema(cx->d_params, cx->hp, cx->d_cnt, o, cx->stream);
         } : nullptr;
         ctx->ext_launched = false;
+        int probe_hit = 0;
+        if (ctx->blur_probe) { q.probe_ev0 = ctx->ev_blur[0]; q.probe_ev1 = ctx->ev_blur[1]; q.probe_hit = &probe_hit; ctx->blur_probe_n = 0; }
         const hipError_t e = psx_launch_pyramid_alt(q, ctx->stream);
+        if (probe_hit) {
+            // Fixed9 / Fixed15: the one-kernel octave 0 (six planes written from the input image: 24 B per pixel + the image)
+            ctx->blur_probe_n = 1;
+            ctx->blur_probe_bytes = 24.0 * (double)P.oct[0].w * P.oct[0].h + (double)ctx->in_w * ctx->in_h * (ctx->input_is_float ? 4 : 1);
+        }
         if (e == hipErrorInvalidValue) return fail(ctx, PSX_ERR_INVALID, "Unsupported number of levels for making all octaves at once");
         PSX_HIP(e);
         ctx->ext_launched = ctx->interleave;

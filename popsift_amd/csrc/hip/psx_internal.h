@@ -168,6 +168,10 @@ struct PsxAltArgs {
     float* vbuf; int vbuf_pitch; // scratch of the fixed-span modes: pitch + 2*7 columns
     hipError_t (*after_octave)(void* user, int octave);   // e.g. launch the octave's extrema scan
     void* user;
+    // blur probe (psx_enable_blur_probe): begin / end timestamps of the fixed-span modes' octave-0 launch; *probe_hit is set
+    // when that launch was the one-kernel octave of pyramid_fixed.hip
+    hipEvent_t probe_ev0 = nullptr, probe_ev1 = nullptr;
+    int* probe_hit = nullptr;
 };
 hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s);
 // GaussMode Fixed9 / Fixed15: every derived level of an octave in one launch (pyramid_fixed.hip)

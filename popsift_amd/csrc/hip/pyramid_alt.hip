@@ -359,7 +359,10 @@ hipError_t psx_launch_pyramid_alt(const PsxAltArgs& a, hipStream_t s)
                 if (fused && psx_fixed_octave0_ok(a.w, a.h, W, H) && a.upscale_factor == 1.0f) {
                     fo.src = a.img; fo.from_input = 1; fo.nlev = 6; fo.dst = plane(0); fo.half_level = P.L - 3;
                     fo.scale = 255.0f; fo.taps = a.abs0_filter;
+                    fo.ev0 = a.probe_ev0; fo.ev1 = a.probe_ev1;
+                    if (a.probe_hit) *a.probe_hit = 1;
                     const hipError_t e2 = psx_launch_fixed_octave(fo, s);
+                    fo.ev0 = fo.ev1 = nullptr;
                     if (e2 != hipSuccess) return e2;
                     next_l0_done = fo.half_dst != nullptr;
                 } else { fixed_levels(0, true); next_l0_done = false; }

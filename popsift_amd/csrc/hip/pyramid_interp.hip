@@ -277,8 +277,12 @@ inline void interp_chunking(int W, int H, int RI, int& chunk_rows, int& nchunks)
         const int cr = S * BR - 2 * RI;
         if (cr >= BR && nstrips * ((H + cr - 1) / cr) >= minwg) break;
     }
+    // the small octaves are latency chains: where the filter is narrow enough that ONE step still yields >= 12 rows, a plane
+    // that does not fill a quarter of the chip with two-step chunks is cut into one-step chunks (POPSIFT_INTERP_ONESTEP=0: off)
+    static const bool onestep = [] { const char* e = getenv("POPSIFT_INTERP_ONESTEP"); return !(e != nullptr && e[0] == '0'); }();
+    if (onestep && S == 2 && BR - 2 * RI >= 12 && nstrips * ((H + (2 * BR - 2 * RI) - 1) / (2 * BR - 2 * RI)) < 256) S = 1;
     int cr = S * BR - 2 * RI;
-    if (cr < BR / 2) cr = BR / 2;
+    if (cr < 4) cr = 4;
     if (cr > H) cr = H;
     chunk_rows = cr;
     nchunks = (H + cr - 1) / cr;
