@@ -14,6 +14,7 @@
 #include "psx_internal.h"
 #include "blur_tile_core.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -638,7 +639,27 @@ int psx_create(int device, const psx_config* cfg, psx_ctx** out)
             return fail(nullptr, PSX_ERR_HIP, m__);                                             \
         }                                                                                       \
     } while (0)
-    PSX_HIPC(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    {
+        // POPSIFT_CU_PARTITIONS=P (measurement switch, default off): the contexts of a process take turns over P partitions of
+        // the chip, each context's stream masked to its partition.  POPSIFT_CU_PARTITION_MODE: 0 = by XCD (mask bit b belongs to
+        // XCD b % 8: partition = a set of whole XCDs with their own L2s), 1 = a slice of the CUs of every XCD.
+        static const int parts = [] { const char* e = getenv("POPSIFT_CU_PARTITIONS"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 8 ? v : 0; }();
+        static const int pmode = [] { const char* e = getenv("POPSIFT_CU_PARTITION_MODE"); return e ? atoi(e) : 0; }();
+        static std::atomic<int> next_part{0};
+        int cus = 0;
+        if (parts > 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus >= 64) {
+            const int part = next_part.fetch_add(1) % parts;
+            uint32_t mask[16] = {0};
+            const int nbits = cus < 512 ? cus : 512;
+            for (int b = 0; b < nbits; b++) {
+                const int xcd = b % 8, cu = b / 8;
+                const bool mine = pmode == 0 ? (xcd * parts / 8 == part) : (cu % parts == part);
+                if (mine) mask[b / 32] |= 1u << (b % 32);
+            }
+            PSX_HIPC(hipExtStreamCreateWithCUMask(&n->stream, (uint32_t)((nbits + 31) / 32), mask));
+        } else
+            PSX_HIPC(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+    }
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) n->resident_blocks = 4 * cus; }
     PSX_HIPC(hipMalloc(reinterpret_cast<void**>(&n->d_params), sizeof(PsxParams)));
     PSX_HIPC(hipHostMalloc(reinterpret_cast<void**>(&n->h_params_pin), sizeof(PsxParams), hipHostMallocDefault));

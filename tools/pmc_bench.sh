@@ -4,7 +4,7 @@
 # C-ABI legs), counter pass with --kernel-trace only.  NOTE: rocprofv3's counter collection serialises the dispatches of a
 # process (one kernel on the chip at a time): the sums are each kernel's own counters at the headline's workload and launch
 # mix, not the counters of kernels overlapping each other.
-C=$1; OUT=${2:-/dev/stdout}
+C=$1; OUT=${2:-/dev/stdout}; case "$OUT" in /*) ;; *) OUT="$PWD/$OUT";; esac
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcb
