@@ -228,12 +228,23 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
             const float rgt = *(gfloat_p)(plane + off + 8u);          // p[xx+2]
             const v2f  dwn = *(gv2f_p)(plane + (off + pitch4));
             const v2f  upp = *(gv2f_p)(plane + (off - pitch4));
+#ifdef PSX_MODEL_NOGRAD
+            // measurement build only (tools/polar_patch_model.py): what the kernel costs when magnitude and angle of a pixel
+            // pair come out of ONE 8-byte read (a per-keypoint polar-gradient patch would deliver them that way)
+            const v2f gdx = ctr, gdy = (v2f){ctr.y, ctr.x};
+            (void)lft; (void)rgt; (void)dwn; (void)upp;
+#else
             const v2f gdx = (v2f){ctr.y - lft, rgt - ctr.x};
             const v2f gdy = dwn - upp;
+#endif
             // the reference uses hypotf / atan2f here (s_gradiant.h:56-69).  The magnitude only scales a weight
             // (v_sqrt_f32 is enough); the angle picks the histogram bin and must round exactly like the CPU restatement's
             // (oracle/sift_oracle.c) roundf(36 (atan2f + pi) / 2pi) -- see the bin computation below.
+#ifdef PSX_MODEL_NOGRAD
+            const v2f m2 = gdx;
+#else
             const v2f m2 = pk_fma(gdx, gdx, gdy * gdy);
+#endif
             const float dy = yy - y;
             const v2f dxv = (v2f){(float)xx, (float)(xx + 1)} - splat(x);      // each column converted, then - x: as the CPU restatement
             const v2f d2 = dxv * dxv + splat(dy * dy);
@@ -243,6 +254,9 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
             if (on0 || on1) {
                 // fast_atan2 on both pixels (same operations per component)
                 const v2f ax = (v2f){fabsf(gdx.x), fabsf(gdx.y)}, ay = (v2f){fabsf(gdy.x), fabsf(gdy.y)};
+#ifdef PSX_MODEL_NOGRAD
+                const v2f r = gdy * splat(0.03f);
+#else
                 const v2f mx = (v2f){fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)};
                 const v2f mn = (v2f){fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
                 const v2f rc = (v2f){__builtin_amdgcn_rcpf(fmaxf(mx.x, 1e-30f)), __builtin_amdgcn_rcpf(fmaxf(mx.y, 1e-30f))};
@@ -260,6 +274,7 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                 r = pk_fma(r, s2, splat(-0.3331736922264099f * KB));
                 r = pk_fma(r, s2, splat(0.9999961256980896f * KB));
                 r = r * a;
+#endif
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     if (!(e == 0 ? on0 : on1)) continue;
@@ -268,7 +283,11 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
                     if ((e == 0 ? ay.x : ay.y) > (e == 0 ? ax.x : ax.y)) at = 9.0f - at;
                     if (gx < 0.0f) at = 18.0f - at;
                     at = (gy < 0.0f) ? -at : at;
+#ifdef PSX_MODEL_NOGRAD
+                    const float grad = e == 0 ? m2.x : m2.y;
+#else
                     const float grad = __builtin_amdgcn_sqrtf(e == 0 ? m2.x : m2.y);
+#endif
                     const float weight = grad * __builtin_amdgcn_exp2f((float)(e == 0 ? sq0 : sq1) * factor2);
                     // Bin = roundf(36 (atan2f(gdy,gdx) + pi) / 2pi) with the correctly rounded atan2 (evaluated in double,
                     // rounded once: the CPU restatement and the reference shim do the same) and IEEE division: gradients
@@ -745,12 +764,22 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                         // the rows above and below through their own (uniform) bases: one lane offset serves all three loads
                         const v2f  dwn = *(gv2f_p)(plane_dn + off);
                         const v2f  upp = *(gv2f_p)(plane_up + off);
+#ifdef PSX_MODEL_NOGRAD
+                        // measurement build only: magnitude and angle of the pixel pair from one 8-byte read (see k_orientation)
+                        const v2f gdx = ctr, gdy = (v2f){ctr.y, ctr.x};
+                        (void)lft; (void)rgt; (void)dwn; (void)upp;
+                        const v2f mod = ctr;
+#else
                         const v2f gdx = (v2f){ctr.y - lft, rgt - ctr.x};
                         const v2f gdy = dwn - upp;
                         const v2f m2 = pk_fma(gdx, gdx, gdy * gdy);
                         const v2f mod = (v2f){__builtin_amdgcn_sqrtf(m2.x), __builtin_amdgcn_sqrtf(m2.y)};
+#endif
                         // atan2 in bin units: (4/pi) atan(min/max) by the degree-13 odd polynomial, then the octant
                         const v2f ax = (v2f){fabsf(gdx.x), fabsf(gdx.y)}, ay = (v2f){fabsf(gdy.x), fabsf(gdy.y)};
+#ifdef PSX_MODEL_NOGRAD
+                        v2f r = gdy * splat(0.01f);
+#else
                         const v2f mx = (v2f){fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)};
                         const v2f mn = (v2f){fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
                         const v2f rc = (v2f){__builtin_amdgcn_rcpf(fmaxf(mx.x, 1e-30f)), __builtin_amdgcn_rcpf(fmaxf(mx.y, 1e-30f))};
@@ -764,6 +793,7 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
                         r = pk_fma(r, s2, splat(-0.3331736922264099f * M_4RPI_F));
                         r = pk_fma(r, s2, splat(0.9999961256980896f * M_4RPI_F));
                         r = r * a;
+#endif
                         float r0 = r.x, r1 = r.y;
                         r0 = (ay.x > ax.x) ? 2.0f - r0 : r0;   r1 = (ay.y > ax.y) ? 2.0f - r1 : r1;
                         r0 = (gdx.x < 0.0f) ? 4.0f - r0 : r0;  r1 = (gdx.y < 0.0f) ? 4.0f - r1 : r1;
