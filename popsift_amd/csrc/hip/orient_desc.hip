@@ -64,7 +64,12 @@ __device__ __forceinline__ float from_fix(fix64 v) { return __ull2float_rn(v) * 
 // ds_add_u64 without return value on an LDS-address-space pointer (immediate offsets fold into the instruction)
 __device__ __forceinline__ void lds_add(fix64 LDS_AS* p, fix64 v)
 {
+#ifdef PSX_MODEL_NOATOMIC
+    // measurement build only (tools/polar_patch_model.py): the operands are formed, the ds_add_u64 is not issued
+    asm volatile("" :: "v"(p), "v"(v));
+#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 __device__ __forceinline__ void lds_add(unsigned LDS_AS* p, unsigned v)
 {

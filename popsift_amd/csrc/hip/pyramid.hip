@@ -63,6 +63,8 @@ struct BlurArgs {
 #ifdef PSX_PHASE_TIMING
 __device__ long long* g_blur_dbg = nullptr;
 extern "C" void psx_debug_set_blur_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blur_dbg), &d, sizeof(d)); }
+__device__ long long* g_l0_dbg = nullptr;         // the same stamps in k_level0_x2 (tools/level0_phase.py)
+extern "C" void psx_debug_set_level0_buffer(long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_l0_dbg), &d, sizeof(d)); }
 #define BSTAMP(i) do { long long c_ = clock64(); tacc[i] += c_ - tprev; tprev = c_; } while (0)
 #else
 #define BSTAMP(i)
@@ -1271,6 +1273,11 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
         }
     };
 
+#ifdef PSX_PHASE_TIMING
+    long long tacc[5] = {0, 0, 0, 0, 0};
+    long long tprev = clock64();
+    const long long tstart = tprev;
+#endif
     issue(0);
     unsigned vmask = 0u;
     if constexpr (VNP > 0) {
@@ -1302,7 +1309,9 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
                 }
             }
         }
+        BSTAMP(0);
         __syncthreads();
+        BSTAMP(1);
         if (k + 1 < nsteps) issue(k + 1);
 
         // ---- horizontal: the dd taps over one window of U ----
@@ -1324,7 +1333,9 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
                 reinterpret_cast<float4*>(rp + RING * RS)[1] = make_float4(out[4], out[5], out[6], out[7]);
             }
         }
+        BSTAMP(2);
         __syncthreads();
+        BSTAMP(3);
 
         // ---- vertical ----
         {
@@ -1345,8 +1356,15 @@ __global__ __launch_bounds__(NT, 4) void k_level0_x2(L0Args a)
                 for (int i = 0; i < 4; i++) pend[i] = o[i];
             }
         }
+        BSTAMP(4);
     }
     flush(nsteps - 1);
+#ifdef PSX_PHASE_TIMING
+    if (threadIdx.x == 0 && g_l0_dbg) {
+        for (int q = 0; q < 5; q++) g_l0_dbg[blockIdx.x * 8 + q] = tacc[q];
+        g_l0_dbg[blockIdx.x * 8 + 5] = clock64() - tstart; g_l0_dbg[blockIdx.x * 8 + 6] = nsteps;
+    }
+#endif
 }
 
 // make_dog (s_pyramid_build.cu:74-92) for one level pair; debug/dump use only

@@ -31,25 +31,41 @@ if __name__ == "__main__":
         measure()
         sys.exit(0)
     res = {}
-    for name, lib in (("product", None), ("nograd", os.path.join(ROOT, "popsift_amd", "lib_model", "libpopsift_hip.so"))):
+    libs = (("product", None), ("nograd", "lib_model"), ("noatomic", "lib_model_NOATOMIC"), ("nograd_noatomic", "lib_model_BOTH"))
+    for name, sub in libs:
         env = dict(os.environ)
-        if lib:
+        if sub:
+            lib = os.path.join(ROOT, "popsift_amd", sub, "libpopsift_hip.so")
+            if not os.path.exists(lib):
+                continue
             env["POPSIFT_HIP_LIB"] = lib
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], capture_output=True, text=True, env=env)
         res[name] = json.loads(p.stdout.strip().splitlines()[-1])
-    a, b = res["product"]["stage_ms"], res["nograd"]["stage_ms"]
-    n_kp, n_desc = res["product"]["counts"][0], res["product"]["counts"][1]
-    t_ori, t_desc = a[2] - b[2], a[3] - b[3]
-    # the union of a keypoint's windows against what its passes visit today: the descriptor window is a rotated square of side
-    # 12 sigma' (area 144) inside the disc of radius 8.5 sigma' (area 227) that holds it for every orientation; today's kernel
-    # visits 144 / 0.67 (67 % useful lanes); the orientation window (radius 4.5 sigma') lies inside
-    share = (n_kp * 227.0) / (n_desc * 144.0 / 0.67)
-    saved = t_ori + t_desc * max(0.0, 1.0 - share)
-    print("stage ms (pyramid, extrema, orientation + scan, descriptors): product %s   no-gradient build %s" % ([round(v, 4) for v in a], [round(v, 4) for v in b]))
-    print("keypoints %d, descriptors %d (%.2f per keypoint)" % (n_kp, n_desc, n_desc / max(n_kp, 1)))
-    print("T_grad: orientation %.4f ms, descriptors %.4f ms" % (t_ori, t_desc))
-    print("a shared patch pays the descriptor's gradients once per keypoint over the disc that holds every orientation's window: "
-          "%.2f of today's descriptor-side gradient work; upper bound of the saving %.4f ms of a %.4f ms frame = %.1f %%" % (
-              share, saved, sum(a), 100.0 * saved / sum(a)))
-    print("(upper bound: the patch's accurate-angle requirement of the orientation histogram, its LDS traffic and the keypoint-granular "
-          "work distribution are not charged)")
+    prod = res["product"]
+    n_kp, n_desc = prod["counts"]
+    print("1080p bench frame, one context, medians of 40 frames (HIP event timers); the no-gradient builds produce other orientations,")
+    print("hence other descriptor counts: the descriptor stage is compared PER DESCRIPTOR, the orientation stage per keypoint")
+    for name, r in res.items():
+        a = r["stage_ms"]
+        print("  %-16s keypoints %6d descriptors %6d  orientation + scan %.4f ms (%.2f ns / keypoint)  descriptors %.4f ms (%.2f ns / descriptor)" % (
+            name, r["counts"][0], r["counts"][1], a[2], a[2] * 1e6 / r["counts"][0], a[3], a[3] * 1e6 / r["counts"][1]))
+    if "nograd" in res:
+        ng = res["nograd"]
+        t_ori = prod["stage_ms"][2] - ng["stage_ms"][2]
+        t_desc = (prod["stage_ms"][3] / n_desc - ng["stage_ms"][3] / ng["counts"][1]) * n_desc
+        # the union of a keypoint's windows against what its passes visit today: the descriptor window is a rotated square of
+        # side 12 sigma' (area 144) inside the disc of radius 8.5 sigma' (area 227) that holds it for every orientation; today's
+        # kernel visits 144 / 0.67 (67 % useful lanes); the orientation window (radius 4.5 sigma') lies inside
+        share = (n_kp * 227.0) / (n_desc * 144.0 / 0.67)
+        saved = max(t_ori, 0.0) + max(t_desc, 0.0) * max(0.0, 1.0 - share)
+        frame = sum(prod["stage_ms"])
+        print("T_grad (what hypot + atan2 + four of the five loads cost today): orientation %.4f ms, descriptors %.4f ms of a %.4f ms frame" % (t_ori, t_desc, frame))
+        print("a shared patch computes the descriptor-side gradients once per keypoint over the disc that holds every orientation's window = %.2f of "
+              "today's descriptor-side gradient work: upper bound of its saving %.4f ms = %.1f %% of the frame" % (share, saved, 100.0 * saved / frame))
+        print("(upper bound: the accurate angle the orientation histogram needs, the patch's LDS traffic and keypoint-granular work distribution are not charged)")
+    if "nograd_noatomic" in res:
+        b = res["nograd_noatomic"]
+        print("k_descriptors with NEITHER gradients NOR histogram atomics: %.2f ns per descriptor against %.2f -- what remains (window walk, weights, "
+              "bin arithmetic, per-descriptor prologue / normalisation, load latency of the one remaining read) is %.0f %% of the kernel" % (
+                  b["stage_ms"][3] * 1e6 / b["counts"][1], prod["stage_ms"][3] * 1e6 / n_desc,
+                  100.0 * (b["stage_ms"][3] / b["counts"][1]) / (prod["stage_ms"][3] / n_desc)))
