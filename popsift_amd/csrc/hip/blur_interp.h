@@ -72,6 +72,7 @@ __device__ __forceinline__ void psx_hinterp2x4(const PSX_LDS float* win, const P
                 out[e] = pk_fma(psx_lerp2(lc[e], lc[e + 1], wl) + psx_lerp2(rc[e + 1], rc[e + 2], wr), tp.z, out[e]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);      // the next pairs' loads stay behind this pair's arithmetic (register pressure)
         if (p + 1 < NP) {
             lc[5] = lc[3]; lc[4] = lc[2]; lc[3] = lc[1]; lc[2] = lc[0]; lc[0] = (v2f){nl.x, nl.y}; lc[1] = (v2f){nl.z, nl.w};
             rc[0] = rc[2]; rc[1] = rc[3]; rc[2] = rc[4]; rc[3] = rc[5]; rc[4] = (v2f){nr.x, nr.y}; rc[5] = (v2f){nr.z, nr.w};
@@ -116,6 +117,7 @@ __device__ __forceinline__ void psx_vinterp2x4(const PSX_LDS float* col, const P
                 o[i] = pk_fma(psx_lerp2(lr[i], lr[i + 1], wl) + psx_lerp2(rr[i], rr[i + 1], wr), tp.z, o[i]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (p + 1 < NP) {
             lr[4] = lr[2]; lr[3] = lr[1]; lr[2] = lr[0]; lr[0] = n0; lr[1] = n1;
             rr[0] = rr[2]; rr[1] = rr[3]; rr[2] = rr[4]; rr[3] = n2; rr[4] = n3;

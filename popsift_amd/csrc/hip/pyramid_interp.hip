@@ -37,7 +37,7 @@ namespace {
 
 constexpr int TW = 64, BR = 32, NT = 256;
 #ifndef PSX_INTERP_WGPC_BIG
-#define PSX_INTERP_WGPC_BIG 3
+#define PSX_INTERP_WGPC_BIG 4
 #endif
 
 #define LDS_AS __attribute__((address_space(3)))
