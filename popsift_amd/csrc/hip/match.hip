@@ -190,53 +190,67 @@ __global__ void k_match_norms(const float* __restrict__ src_a, int n_a, float* _
     float* norm2 = second ? norm2_b : norm2_a;
     unsigned* maxbits = second ? maxbits_b : maxbits_a;
     const int bid = second ? (int)blockIdx.x - blocks_a : (int)blockIdx.x;
-    const int g = bid * blockDim.x + threadIdx.x;                  // one thread per 4 elements, 32 threads per descriptor
-    const int d = g >> 5, q = g & 31;
-    float ss = 0.0f;
-    if (d < n) {
+    const int nblk = second ? (int)gridDim.x - blocks_a : blocks_a;
+    const int q = threadIdx.x & 31;
+    // 32 threads per descriptor (4 elements each), a block's 8 groups walk the set with the stride of all groups of this side
+    float mx = 0.0f;
+    for (int d = bid * 8 + (threadIdx.x >> 5); d < n; d += nblk * 8) {
         const float4 v = reinterpret_cast<const float4*>(src + (size_t)d * 128)[q];
-        ss = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+        float ss = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+        for (int k = 16; k >= 1; k >>= 1) ss += __shfl_xor(ss, k, 32);
+        if (q == 0) norm2[d] = ss;
+        // a NaN norm has the bit pattern of a huge unsigned: it wins the maximum and switches the prefilter off (k_match_cvt)
+        mx = __uint_as_float(max(__float_as_uint(mx), __float_as_uint(ss < 0.0f ? 0.0f : ss)));
     }
-    for (int k = 16; k >= 1; k >>= 1) ss += __shfl_xor(ss, k, 32);
-    if (d < n && q == 0) norm2[d] = ss;
     __shared__ unsigned s_max;
     if (threadIdx.x == 0) s_max = 0u;
     __syncthreads();
-    // a NaN norm has the bit pattern of a huge unsigned: it wins the maximum and switches the prefilter off (k_match_scale)
-    if (d < n && q == 0) atomicMax(&s_max, __float_as_uint(ss < 0.0f ? 0.0f : ss));
+    if (q == 0) atomicMax(&s_max, __float_as_uint(mx));
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(&maxbits[bid & (MF_MAXSLOTS - 1)], s_max);
 }
 
 // par[0] = 2^k, par[1] = -2 / 4^k, par[2] = Rmax^2, par[3] = M; *flag = 1 when the prefilter cannot be used
-__global__ void k_match_scale(const unsigned* __restrict__ lmax, const unsigned* __restrict__ rmax, float* __restrict__ par, int* __restrict__ flag)
+__device__ __forceinline__ void match_scale(float l2, float r2, float* par, int* bad)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned lb = 0u, rb = 0u;
-    for (int i = 0; i < MF_MAXSLOTS; i++) { lb = max(lb, lmax[i]); rb = max(rb, rmax[i]); }
-    const float l2 = __uint_as_float(lb), r2 = __uint_as_float(rb);
     const float m2 = fmaxf(l2, r2);
     // finite, positive, and far enough from both ends of the float range for the squares below
-    if (!(l2 == l2) || !(r2 == r2) || !(m2 > 1e-30f) || !(m2 < 1e30f)) { *flag = 1; par[0] = 1.0f; par[1] = -2.0f; par[2] = 0.0f; par[3] = 0.0f; return; }
+    if (!(l2 == l2) || !(r2 == r2) || !(m2 > 1e-30f) || !(m2 < 1e30f)) { *bad = 1; par[0] = 1.0f; par[1] = -2.0f; par[2] = 0.0f; par[3] = 0.0f; return; }
     const float M = sqrtf(m2);
     const int k = (int)floorf(log2f(16384.0f / M));
+    *bad = 0;
     par[0] = ldexpf(1.0f, k);
     par[1] = ldexpf(-2.0f, -2 * k);
     par[2] = r2;
     par[3] = M;
 }
 
-// f16 copy of every descriptor of both sides, scaled by par[0] = 2^k (blocks [0, blocks_a): the first set)
+// f16 copy of every descriptor of both sides, scaled by 2^k (blocks [0, blocks_a): the first set).  Every block derives the
+// scale from the 2 x 64 maximum slots itself (a 1-thread kernel in between cost a 5 us launch); block 0 publishes the
+// parameters and the flag for the kernels behind it.  a = right, b = left.
 __global__ void k_match_cvt(const float* __restrict__ src_a, int n_a, unsigned short* __restrict__ dst_a, int blocks_a,
-                            const float* __restrict__ src_b, int n_b, unsigned short* __restrict__ dst_b, const float* __restrict__ par)
+                            const float* __restrict__ src_b, int n_b, unsigned short* __restrict__ dst_b,
+                            const unsigned* __restrict__ lmax, const unsigned* __restrict__ rmax, float* __restrict__ par, int* __restrict__ flag)
 {
+    __shared__ float s_par[4];
+    if (threadIdx.x < 64) {
+        unsigned lb = lmax[threadIdx.x], rb = rmax[threadIdx.x];
+        for (int k = 32; k >= 1; k >>= 1) { lb = max(lb, (unsigned)__shfl_xor((int)lb, k)); rb = max(rb, (unsigned)__shfl_xor((int)rb, k)); }
+        if (threadIdx.x == 0) {
+            float pp[4]; int bad;
+            match_scale(__uint_as_float(lb), __uint_as_float(rb), pp, &bad);
+            s_par[0] = pp[0];
+            if (blockIdx.x == 0) { par[0] = pp[0]; par[1] = pp[1]; par[2] = pp[2]; par[3] = pp[3]; if (bad) *flag = 1; }
+        }
+    }
+    __syncthreads();
     const bool second = (int)blockIdx.x >= blocks_a;
     const float* src = second ? src_b : src_a;
     unsigned short* dst = second ? dst_b : dst_a;
     const int n = second ? n_b : n_a;
     const int g = ((int)blockIdx.x - (second ? blocks_a : 0)) * blockDim.x + threadIdx.x;          // one thread per 4 elements
     if (g >= n * 32) return;
-    const float sc = par[0];
+    const float sc = s_par[0];
     const float4 v = reinterpret_cast<const float4*>(src)[g];
     ushort4 o; o.x = to_f16(v.x * sc); o.y = to_f16(v.y * sc); o.z = to_f16(v.z * sc); o.w = to_f16(v.w * sc);
     reinterpret_cast<ushort4*>(dst)[g] = o;
@@ -412,7 +426,7 @@ __device__ __forceinline__ void top2_insert_lex(Top2& t, float d, int i)
 // lane 0 ends with ((((p0 + p16) + (p8 + p24)) + ...)), the tree of l2_tree above.  `left` / `right` in ORIGINAL layout.
 __global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ left, int l_len, const float* __restrict__ right, int r_len,
                                                      const int* __restrict__ cand_ct, const int* __restrict__ cand,
-                                                     int* __restrict__ out, float* __restrict__ dist, const int* __restrict__ flag)
+                                                     int* __restrict__ out, float* __restrict__ dist, int* __restrict__ flag)
 {
     // launched behind the prefilter without waiting for its verdict: a raised flag (a candidate segment overflowed, norms the
     // margin cannot bound) means the host will run the exact scan of every pair instead
@@ -424,7 +438,11 @@ __global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ l
     // the left descriptor's segments, compacted into one list in LDS: lane s < MF_SEGS owns segment s
     __shared__ int s_list[4][MF_CAP];
     int* cl = s_list[threadIdx.x >> 6];
-    int myct = lane < MF_SEGS ? min(cand_ct[(size_t)li * MF_SEGS + lane], MF_SEGCAP) : 0;      // an overflowed segment never gets here
+    const int rawct = lane < MF_SEGS ? cand_ct[(size_t)li * MF_SEGS + lane] : 0;
+    // a segment that overflowed (the prefilter counted more candidates than it could store): the whole call goes through the
+    // exact scan of every pair -- the host reads the flag with the results (a separate kernel for this test cost a 5 us launch)
+    if (rawct > MF_SEGCAP) *flag = 1;
+    int myct = min(rawct, MF_SEGCAP);
     int off = myct;                                          // inclusive prefix sum over the 64 lanes
 #pragma unroll
     for (int k = 1; k < 64; k <<= 1) { const int o = __shfl_up(off, k); if (lane >= k) off += o; }
@@ -460,13 +478,6 @@ __global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ l
         out[3 * li + 0] = i1; out[3 * li + 1] = i2; out[3 * li + 2] = accept ? 1 : 0;
         if (dist) { dist[2 * li + 0] = t.d1; dist[2 * li + 1] = t.d2; }
     }
-}
-
-// any left descriptor whose candidate list overflowed? (then psx_match runs the exact scan of every pair)
-__global__ void k_match_overflow(const int* __restrict__ cand_ct, int l_len, int* __restrict__ flag)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < l_len * MF_SEGS && cand_ct[i] > MF_SEGCAP) *flag = 1;
 }
 
 } // namespace
@@ -557,16 +568,16 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
     float* d_dist = static_cast<float*>(sc.buf[3]);
     hipStream_t st = sc.stream;
     // POPSIFT_MATCH_MFMA=0: the exact scan of every pair (rounds 1-4); default: MFMA prefilter + exact evaluation of the
-    // candidates (identical results by construction; used from 2048 right / 256 left descriptors on)
+    // candidates (identical results by construction; used from 2 * MF_SEED = 4096 right / 256 left descriptors on)
     static const bool use_mfma = [] { const char* e = getenv("POPSIFT_MATCH_MFMA"); return !(e != nullptr && e[0] == '0'); }();
     bool exact_scan = true;
     int* d_flag_used = nullptr;
     int* d_cct_used = nullptr;
-    if (use_mfma && r_len >= 2 * MF_SEED && l_len >= 256) {
-        if (!sc.need(4, sizeof(unsigned short) * 128 * (size_t)l_len) || !sc.need(5, sizeof(unsigned short) * 128 * (size_t)r_len) ||
-            !sc.need(6, sizeof(float) * (1 + 2 * MF_SEEDCH) * (size_t)l_len) || !sc.need(7, sizeof(float) * (size_t)r_len + 1024) ||
-            !sc.need(8, sizeof(int) * (size_t)MF_SEGS * l_len) || !sc.need(9, sizeof(int) * (size_t)MF_CAP * l_len))
-            return PSX_ERR_NOMEM;
+    // (a failed allocation of the prefilter's scratch -- 4 KB of candidate slots per left descriptor -- leaves the exact scan)
+    if (use_mfma && r_len >= 2 * MF_SEED && l_len >= 256 &&
+        sc.need(4, sizeof(unsigned short) * 128 * (size_t)l_len) && sc.need(5, sizeof(unsigned short) * 128 * (size_t)r_len) &&
+        sc.need(6, sizeof(float) * (1 + 2 * MF_SEEDCH) * (size_t)l_len) && sc.need(7, sizeof(float) * (size_t)r_len + 1024) &&
+        sc.need(8, sizeof(int) * (size_t)MF_SEGS * l_len) && sc.need(9, sizeof(int) * (size_t)MF_CAP * l_len)) {
         unsigned short* d_lf16 = static_cast<unsigned short*>(sc.buf[4]);
         unsigned short* d_rf16 = static_cast<unsigned short*>(sc.buf[5]);
         float* d_ln2 = static_cast<float*>(sc.buf[6]);
@@ -579,18 +590,40 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         float* d_par = reinterpret_cast<float*>(d_flag + 1);
         int* d_cct = static_cast<int*>(sc.buf[8]);
         int* d_cand = static_cast<int*>(sc.buf[9]);
-        if (hipMemsetAsync(d_cct, 0, sizeof(int) * (size_t)MF_SEGS * l_len, st) != hipSuccess ||
-            hipMemsetAsync(d_rmax, 0, sizeof(unsigned) * (2 * MF_MAXSLOTS + 1), st) != hipSuccess) return PSX_ERR_HIP;
-        const int rblk = (r_len * 32 + 255) / 256, lblk = (l_len * 32 + 255) / 256;
-        hipLaunchKernelGGL(k_match_norms, dim3(rblk + lblk), dim3(256), 0, st, d_right, r_len, d_rn2, d_rmax, rblk, d_left, l_len, d_ln2, d_lmax);
-        hipLaunchKernelGGL(k_match_scale, dim3(1), dim3(64), 0, st, d_lmax, d_rmax, d_par, d_flag);
-        hipLaunchKernelGGL(k_match_cvt, dim3(rblk + lblk), dim3(256), 0, st, d_right, r_len, d_rf16, rblk, d_left, l_len, d_lf16, d_par);
+        // workgroups the prefilter kernel keeps resident (the occupancy the runtime computes from its registers and LDS: 3 per CU)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        static const int per_cu = [] {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_match_mfma<false>, 256, 0) != hipSuccess || n < 1) n = 2;
+            if (const char* e = getenv("POPSIFT_MATCH_WGS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) n = v; }
+            return n;
+        }();
+        const int resident = per_cu * cus;
         const int lblocks = (l_len + 255) / 256;
-        // seeding pass over the first MF_SEED right descriptors, then every chunk of the right side: enough workgroups for
-        // a round or two of the chip, whole tiles per chunk
-        hipLaunchKernelGGL((k_match_mfma<true>), dim3(lblocks, MF_SEEDCH), dim3(256), 0, st, d_lf16, d_ln2, l_len, d_rf16, d_rn2, r_len,
-                           MF_SEED / MF_SEEDCH, d_par, d_seed, d_cct, d_cand);
-        int mchunks = (1024 + lblocks - 1) / lblocks;
+        // seeding pass: the first ~MF_SEED right descriptors in at most MF_SEEDCH chunks, ONE round of resident workgroups
+        // (8 chunks x 72 left blocks were 576 workgroups on 512 slots: a second, nearly empty round); the slots of the
+        // chunks that do not run hold +inf
+        int nseed = resident / lblocks;
+        if (nseed > MF_SEEDCH) nseed = MF_SEEDCH;
+        if (nseed < 1) nseed = 1;
+        const int seedlen = (((MF_SEED + nseed - 1) / nseed + MF_TILE - 1) / MF_TILE) * MF_TILE;
+        if (hipMemsetAsync(d_cct, 0, sizeof(int) * (size_t)MF_SEGS * l_len, st) != hipSuccess ||
+            hipMemsetAsync(d_rmax, 0, sizeof(unsigned) * (2 * MF_MAXSLOTS + 1), st) != hipSuccess ||
+            (nseed < MF_SEEDCH && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_seed), 0x7f800000, 2 * (size_t)MF_SEEDCH * l_len, st) != hipSuccess))
+            return PSX_ERR_HIP;
+        const int rblk = (r_len * 32 + 255) / 256, lblk = (l_len * 32 + 255) / 256;
+        // norms: a few descriptors per 32-thread group (one per group made 9 216 workgroups of one load each: 18 us for 19 MB)
+        const int rnb = rblk < 4 * cus ? rblk : 4 * cus, lnb = lblk < 4 * cus ? lblk : 4 * cus;
+        hipLaunchKernelGGL(k_match_norms, dim3(rnb + lnb), dim3(256), 0, st, d_right, r_len, d_rn2, d_rmax, rnb, d_left, l_len, d_ln2, d_lmax);
+        hipLaunchKernelGGL(k_match_cvt, dim3(rblk + lblk), dim3(256), 0, st, d_right, r_len, d_rf16, rblk, d_left, l_len, d_lf16, d_lmax, d_rmax, d_par, d_flag);
+        hipLaunchKernelGGL((k_match_mfma<true>), dim3(lblocks, nseed), dim3(256), 0, st, d_lf16, d_ln2, l_len, d_rf16, d_rn2, r_len,
+                           seedlen, d_par, d_seed, d_cct, d_cand);
+        // every chunk of the right side: FULL rounds of resident workgroups (15 chunks x 72 left blocks = 1080 workgroups on 768 slots
+        // ran 1.4 rounds, i.e. the time of two), whole tiles per chunk
+        // POPSIFT_MATCH_ROUNDS: rounds of resident workgroups the chunking aims at (measurement switch)
+        static const int rounds = [] { const char* e = getenv("POPSIFT_MATCH_ROUNDS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? v : 1; }();
+        int mchunks = (rounds * resident) / lblocks;
         if (mchunks > (r_len + 8 * MF_TILE - 1) / (8 * MF_TILE)) mchunks = (r_len + 8 * MF_TILE - 1) / (8 * MF_TILE);
         if (mchunks > MF_SEGS / 2) mchunks = MF_SEGS / 2;          // one candidate segment per (chunk, half wave)
         if (mchunks < 1) mchunks = 1;
@@ -599,9 +632,8 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         mchunks = (r_len + mlen - 1) / mlen;
         hipLaunchKernelGGL((k_match_mfma<false>), dim3(lblocks, mchunks), dim3(256), 0, st, d_lf16, d_ln2, l_len, d_rf16, d_rn2, r_len, mlen,
                            d_par, d_seed, d_cct, d_cand);
-        hipLaunchKernelGGL(k_match_overflow, dim3((l_len * MF_SEGS + 255) / 256), dim3(256), 0, st, d_cct, l_len, d_flag);
-        // the exact evaluation of the candidates goes out at once; the flag comes back with the results (one synchronisation
-        // per call instead of two)
+        // the exact evaluation of the candidates goes out at once (it also raises the flag for an overflowed candidate segment); the
+        // flag comes back with the results (one synchronisation per call instead of two)
         hipLaunchKernelGGL(k_match_exact, dim3((l_len + 3) / 4), dim3(256), 0, st, d_left, l_len, d_right, r_len, d_cct, d_cand,
                            d_out, d_dist, d_flag);
         exact_scan = false;

@@ -12,7 +12,8 @@ if not f: print(open("/tmp/pmcc.log").read()[-2000:]); sys.exit(1)
 rows = list(csv.DictReader(open(f[0])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    if sys.argv[1] not in r["Kernel_Name"]: continue
+    import re
+    if not re.search(sys.argv[1].replace("\\|", "|"), r["Kernel_Name"]): continue
     k = (r["Kernel_Name"].replace("(anonymous namespace)::","").replace("void ", "").split("(")[0][:40], int(r["Grid_Size"])//int(r["Workgroup_Size"]))
     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg, key=lambda k:-k[1]):
