@@ -135,6 +135,7 @@ struct psx_ctx {
     unsigned char* d_gf_temp = nullptr;      size_t gf_temp_cap = 0;
     int* d_gf_scratch = nullptr;             size_t gf_scratch_cap = 0;
     bool filtered = false;             // the grid filter ran on the current frame
+    bool null_dl_done = false;         // PSX_NULL_DEVICE_WORK=2: this context's one real download has happened
     bool interleave = false;           // psx_extract: launch an octave's extrema scan right behind its last blur level
     // psx_extract's whole launch chain captured as a hipGraph; valid for one (input pointer, type, size);
     // everything else the kernels read is device resident (PsxParams) or constant per context (taps)
@@ -1423,9 +1424,10 @@ int psx_download(psx_ctx* ctx, psx_feature* features, int feature_capacity, floa
     if (no > 0 && !descriptors) return fail(ctx, PSX_ERR_INVALID, "psx_download: null descriptor buffer");
     const bool feat_exported = (ctx->fx_on && features == ctx->fx_host_feat && ne <= ctx->fx.feat_capacity);
     const bool desc_exported = (ctx->fx_on && descriptors == ctx->fx_host_desc && no <= ctx->fx.desc_capacity);
-    static bool null_dl_done = false;      // PSX_NULL_DEVICE_WORK=2: one real download per process keeps the records well formed
-    if (ctx->null_work == 2 && ctx->null_primed && null_dl_done) return PSX_OK;
-    if (ctx->null_work == 2 && ctx->null_primed) null_dl_done = true;
+    // PSX_NULL_DEVICE_WORK=2: one real download per CONTEXT keeps its host records well formed (a process-wide flag was a
+    // data race between the workers and left every context but the first with uninitialised host buffers)
+    if (ctx->null_work == 2 && ctx->null_primed && ctx->null_dl_done) return PSX_OK;
+    if (ctx->null_work == 2 && ctx->null_primed) ctx->null_dl_done = true;
     if (ne > 0 && !feat_exported)
         PSX_HIP(hipMemcpyAsync(features, ctx->d_features, (size_t)ne * sizeof(psx_feature),
                                hipMemcpyDeviceToHost, ctx->stream));

@@ -1208,7 +1208,8 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
             const float sn = MODE == PSX_DESC_GRID ? (float)sin((double)ang) : sinf(ang);
             if (lane == 0) { s_cs[0] = c; s_cs[1] = sn; }
         }
-        const bool windowed = use_window != 0 && SBP < 64.0f && bw <= ALT_WIN_MAX && H <= 32768;      // 4 * 84 * (H + 84) < 2^24
+        // the window's texel addresses are formed in float: 4 (bx0 + 84 by0) and every 4 i + 336 j must stay below 2^24
+        const bool windowed = use_window != 0 && SBP < 64.0f && bw <= ALT_WIN_MAX && H <= 32768 && 4 * (long long)W + 336ll * (H + 84) < (1ll << 24);
         if (windowed && SBP != 0.0f) {
             for (int r = wave; r < bw; r += WPB) {
                 const float* row = plane + (size_t)psx_clampi(by0 + r, 0, H - 1) * pitch;

@@ -105,8 +105,11 @@ DeviceCpus& device_cpus( int device )
         char line[4096] = { 0 };
         const bool got = fgets( line, sizeof(line), f ) != nullptr;
         fclose( f );
+        // the PROCESS's mask (its main thread's: what a launcher such as taskset / numactl / bench.py's pinning set), not the
+        // calling thread's: the first caller may be a worker that is already bound to another device's socket, and its narrow
+        // mask would truncate -- or empty -- this device's set for the rest of the process
         cpu_set_t allowed;
-        if( !got || sched_getaffinity( 0, sizeof(allowed), &allowed ) != 0 ) return;
+        if( !got || sched_getaffinity( getpid(), sizeof(allowed), &allowed ) != 0 ) return;
         d.valid = parse_cpulist( line, allowed, &d.set ) > 0;
     } );
     return d;

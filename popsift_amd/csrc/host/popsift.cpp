@@ -498,7 +498,8 @@ void PopSift::dispatchLoop( )
             // Results reach the host by DMA after the frame (psx_download into pinned pool buffers that the
             // FeaturesHost then owns).  The alternative, POPSIFT_EXPORT=1, lets the descriptor kernel store them
             // straight into mapped host memory (psx_attach_export_mapped): no second wait, but the PCIe stores slow
-            // the kernel down -- measured 4750 vs 5340 Mpix/s end to end on MI355X, so it is opt-in.
+            // the kernel down -- measured 8 % slower end to end at 18 k descriptors per frame on MI355X (round 5: bench.py's
+            // export leg; round 2 had 4750 against 5340 Mpix/s), so it is opt-in.
             static const bool use_export = []{ const char* e = getenv( "POPSIFT_EXPORT" ); return e != nullptr && e[0] == '1'; }();
             if( _proc_mode == popsift::Config::ExtractingMode && s.xdesc == nullptr && use_export ) {
                 // the previous result took this context's descriptor buffer with it: attach a fresh one

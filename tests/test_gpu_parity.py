@@ -472,7 +472,7 @@ def test_match_bit_exact(oracle, capi, nl, nr, seed):
 
 
 def test_match_mfma_prefilter_equals_exact_scan(oracle, capi):
-    """Round 5: psx_match's default path discards pairs with a bf16-MFMA distance and a proven error margin and evaluates
+    """Round 5: psx_match's default path discards pairs with a f16-MFMA distance and a proven error margin and evaluates
     the survivors with the reference's operation tree (match.hip).  Indices, accept flags and distances must be
     BIT-IDENTICAL to the oracle's sequential scan on: random descriptors, RootSift-like unit-norm descriptors, descriptors
     scaled by 2^9 (setNormalizationMultiplier(9)), exact duplicates and near-duplicates (ties keep the earlier index),
@@ -868,7 +868,7 @@ def test_pyramid_flow_kernel_bit_exact(oracle, capi, monkeypatch, flow, ld, step
             ctx.close()
 
 
-# ---- k_blur_tile: several blur levels of the small octaves per launch on LDS-resident tiles (default; POPSIFT_TILE=0: off) ----
+# ---- k_blur_tile: several blur levels of the small octaves per launch on LDS-resident tiles (opt-in: POPSIFT_TILE=1; the default is the launch-per-level diagonal schedule, which measured faster) ----
 @pytest.mark.parametrize("tile,ty,nt,maxpx", [("1", "64", "512", "3145728"), ("1", "32", "512", "1000000000"),
                                               ("1", "64", "1024", "1000000000"), ("1", "32", "1024", "300000"), ("0", "64", "512", "0")])
 def test_tile_kernel_bit_exact(oracle, capi, monkeypatch, tile, ty, nt, maxpx):
