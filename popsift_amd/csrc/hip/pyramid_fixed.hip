@@ -417,7 +417,9 @@ hipError_t launch_fixed(const PsxFixedOctaveArgs& h, hipStream_t s)
 bool psx_fixed_octave0_ok(int w, int h, int W, int H)
 {
     static const bool off = [] { const char* e = getenv("POPSIFT_FIXED_FUSED"); return e != nullptr && e[0] == '0'; }();
-    return !off && W == 2 * w && H == 2 * h && w >= 4;
+    // up to 4096 texels per side the float coordinates stay within 1e-3 texel of the half-texel grid, far from the 1/512
+    // rounding boundaries of the 1.8 weight (tests/test_numeric_tricks_cpu.py checks every column); larger images: the literal kernels
+    return !off && W == 2 * w && H == 2 * h && w >= 4 && w <= 4096 && h <= 4096;
 }
 bool psx_fixed_octave_enabled()
 {

@@ -470,3 +470,75 @@ def test_alt_descriptor_window_holds_every_texel_the_modes_read():
                 inside((ix.min() - 1, ix.max() + 1, iy.min() - 1, iy.max() + 1), "grid")
         n_checked += 1
     assert n_checked == 400
+
+
+def _tex_axis(tb):
+    """the texture unit on one axis: texel index floor(tb) and the 1.8 fixed-point weight (pyramid_alt.hip a_axis / plane_linear_1d)"""
+    ft = np.floor(tb).astype(f32)
+    w = (np.rint(((tb - ft).astype(f32) * f32(256.0)).astype(f32)) * f32(1.0 / 256.0)).astype(f32)
+    return ft.astype(np.int64), w
+
+
+def test_interpolated_tap_pair_is_a_fixed_texel_pair_with_a_weight():
+    """blur_interp.h psx_lit_weight (GaussMode VLFeat_Relative, s_pyramid_build_ai.cu:17-69): the fetch at c - off / c + off with
+    off = offset + (1 - u) in [offset, offset + 1] reads the FIXED texel pair (c - offset - 1, c - offset) / (c + offset,
+    c + offset + 1); when the float arithmetic lands on the second texel (floor = kstat + 1) its weight is 0, which is the value
+    of weight 1 on the fixed pair.  Every column up to 16384, every pair offset up to 15, u over its range incl. 0 and 1 and
+    values that round c -+ off onto an integer."""
+    rng = np.random.default_rng(11)
+    c = np.arange(0, 16384, dtype=np.int64)
+    cf = c.astype(f32)
+    us = np.concatenate([np.array([0.0, 1.0, 0.5, 1e-7, 1.0 - 6e-8, 0.25, 0.75], dtype=f32), rng.random(40).astype(f32)])
+    changes = 0
+    for offset in range(1, 17, 2):
+        for u in us:
+            off = f32(f32(offset) + (f32(1.0) - u))               # offset + (1.0f - u): int -> float, one addition
+            for right in (False, True):
+                t = (cf + off).astype(f32) if right else (cf - off).astype(f32)
+                ts = (t + f32(0.5)).astype(f32)                    # readTex adds 0.5 ...
+                tb = (ts - f32(0.5)).astype(f32)                   # ... the unit takes it off again
+                k, w = _tex_axis(tb)
+                kstat = c + offset if right else c - offset - 1
+                assert np.all((k == kstat) | (k == kstat + 1)), (offset, float(u), right)
+                assert np.all(w[k == kstat + 1] == 0.0), (offset, float(u), right)
+                assert np.all((w >= 0.0) & (w <= 1.0))
+                wfix = np.where(k == kstat, w, f32(1.0))
+                changes += int(np.count_nonzero(np.diff(wfix)))
+    # the weight on the fixed pair does change with the coordinate (at binade boundaries of c -+ off): rarely, but it happens --
+    # which is why the kernel surveys it per workgroup and keeps a literal per-element path
+    assert 0 < changes < 4000, changes
+
+
+def test_x2_upsampling_puts_the_fixed_span_fetches_on_the_half_texel_grid():
+    """pyramid_fixed.hip, octave 0 of GaussMode Fixed9 / Fixed15 at W = 2w (s_pyramid_fixed.cu:123-140): the fetch of column cx
+    at tap i is tex2D((cx + 1) * (1 / W), fma(i, 1 / H, (y + 1) * (1 / H))) of the normalised, clamped, linear-filtered image.
+    In float these coordinates land on texel t = (n)/2 - ... with a 1.8 weight of exactly 0 or 1/2 -- or, on the knife edge of an
+    integer texel coordinate, on (i0 - 1, weight 1), which is the same texel value -- for every width up to 4096 texels (the bound
+    psx_fixed_octave0_ok enforces).  The kernel's constant-weight form rests on this."""
+    for w in (4, 5, 7, 64, 333, 960, 1171, 1920, 2100, 4095, 4096):
+        W = 2 * w
+        mul = (f32(1.0) / f32(W)).astype(f32) if isinstance(f32(1.0) / f32(W), np.ndarray) else f32(f32(1.0) / f32(W))
+        # columns: xpos = (cx + tshift) * mul_w with tshift = 1.0
+        cx = np.arange(-8, W + 8, dtype=np.int64)
+        xpos = ((cx.astype(f32) + f32(1.0)).astype(f32) * mul).astype(f32)
+        tb = ((xpos * f32(w)).astype(f32) - f32(0.5)).astype(f32)
+        i0, a = _tex_axis(tb)
+        n = cx + 1                                                  # exact texel coordinate = n / 2 - 1/2
+        even = (n % 2) == 0                                         # n even: half-texel position, weight 1/2 on (n/2 - 1, n/2)
+        assert np.all(a[even] == 0.5) and np.all(i0[even] == n[even] // 2 - 1), w
+        odd = ~even                                                 # n odd: integer texel (n - 1) / 2: weight 0 there, or weight 1 one below
+        m = (n[odd] - 1) // 2
+        ok = ((i0[odd] == m) & (a[odd] == 0.0)) | ((i0[odd] == m - 1) & (a[odd] == 1.0))
+        assert np.all(ok), w
+        # rows of tap k: vn = fma(k, mul_h, ypos) -- one rounding; same grid (H = 2h, here h = w)
+        y = np.arange(0, W, 37, dtype=np.int64)
+        ypos = ((y.astype(f32) + f32(1.0)).astype(f32) * mul).astype(f32)
+        for k in range(-7, 8):
+            vn = (np.full(y.shape, k, np.float64) * np.float64(mul) + ypos.astype(np.float64)).astype(f32)
+            tbv = ((vn * f32(w)).astype(f32) - f32(0.5)).astype(f32)
+            j0, b = _tex_axis(tbv)
+            nn = y + k + 1
+            ev = (nn % 2) == 0
+            assert np.all(b[ev] == 0.5) and np.all(j0[ev] == nn[ev] // 2 - 1), (w, k)
+            mm = (nn[~ev] - 1) // 2
+            assert np.all(((j0[~ev] == mm) & (b[~ev] == 0.0)) | ((j0[~ev] == mm - 1) & (b[~ev] == 1.0))), (w, k)
