@@ -616,228 +616,22 @@ __global__ __launch_bounds__(NT, (dma_wg_per_cu<R, NBUF, RINGROWS>())) void k_bl
     blur_body_dma<R, LEVEL0, NBUF, RINGROWS>(a, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-// ---------------------------------------------------------------------------------------------
-// blur_body_hp (round 6): the same marching strip with the horizontal pass packed over a ROW PAIR instead of over adjacent
-// columns of one row.  In blur_body a lane's 8 adjacent outputs share one window, and the packed math pairs outputs (i, i + 1): the
-// operand pair (win[i - k], win[i + 1 - k]) is an aligned register pair for even k only, every odd tap costs moves or runs
-// unpacked (k_blur<5>: 96 VALU in the H phase, 51 of them packed).  Here the staged rows are stored ROW-PAIR INTERLEAVED
-// ([row pair][column][2]) and a lane owns 4 adjacent columns of two rows: every tap's operand (row r, row r + 1) at a column is
-// an aligned register pair whatever the tap's parity (the form pyramid_fixed.hip / blur_interp.h use).  The taps run from
-// the outermost inwards -- the reference's order -- and the window slides with them: a new 16-byte chunk (2 columns x 2 rows)
-// per side at every odd tap, <= 8 chunks live whatever the radius.  Ring, vertical pass, deferred stores: blur_body's.
-// Same operations on the same operands in the same order: planes bit-identical (the whole GPU suite runs through it).
-// ---------------------------------------------------------------------------------------------
-template <int R>
-struct GeomHP {
-    static constexpr int HALO = (R + 3) & ~3;
-    static constexpr int SW   = TW + 2 * HALO;
-    static constexpr int SW4  = SW / 4;
-    static constexpr int SSP  = 2 * SW + 4;              // staged row pair (floats): consecutive pairs an odd number of 16-byte chunks apart
-    static constexpr int NTASK = (BR / 2) * SW4;         // staging tasks (row pair, column quad): two 16-byte loads each
-    static constexpr int NLD  = (NTASK + NT - 1) / NT;
-    static_assert((SSP / 4) % 2 == 1, "row pairs must be an odd number of chunks apart");
-    static_assert((BR / 2) * SSP <= BR * Geom2<R>::SWA, "the interleaved rows fit the stage buffer of blur_body");
-};
-
-template <int R, bool DEFER>
-__device__ __forceinline__ void blur_body_hp(const BlurArgs& a, const int lid, float* const s_stage, float* const s_ring, const int t)
-{
-    using G = Geom2<R>;
-    using GP = GeomHP<R>;
-    constexpr int HALO = GP::HALO, SW = GP::SW, SW4 = GP::SW4, SSP = GP::SSP, NTASK = GP::NTASK, NLD = GP::NLD;
-    constexpr int RING = G::RING, VWIN = G::VWIN, MIRROR = G::MIRROR, RS = G::RS;
-    constexpr bool LAST_PARTIAL = NTASK % NT != 0;
-
-    const GLOBAL_AS float* const gsrc = (const GLOBAL_AS float*)a.src;
-    GLOBAL_AS float* const gdst = (GLOBAL_AS float*)a.dst;
-    GLOBAL_AS float* const ghalf = (GLOBAL_AS float*)a.half_dst;
-    const int strip = lid % a.nstrips;
-    const int chunk = lid / a.nstrips;
-    const int x0    = strip * TW;
-    const int Y0    = chunk * a.chunk_rows;
-    const int Y1    = min(Y0 + a.chunk_rows, a.H);
-    const int nsteps = (Y1 - Y0 + 2 * R + BR - 1) / BR;
-    // workgroup uniform: every staged column exists in the source row (no clamping needed)
-    const bool interior = (x0 - HALO >= 0) && (x0 + TW + HALO <= a.W);
-
-    // ---- staging: task = (row pair, column quad): rows 2 rp, 2 rp + 1 of the step, 4 columns ----
-    int st_lds[NLD], st_row[NLD];
-    unsigned st_off[NLD], st_xb[NLD];
-#pragma unroll
-    for (int j = 0; j < NLD; j++) {
-        const int idx = t + j * NT;
-        const int rp = idx / SW4, c4 = idx - rp * SW4;
-        const int x = x0 - HALO + c4 * 4;
-        // edge strips load the 16-byte slot at the clamped in-row position; their columns outside the plane are patched in LDS
-        const int xc = interior ? x : psx_clampi(x, 0, a.pitch - 4);
-        st_row[j] = 2 * rp;
-        st_lds[j] = rp * SSP + c4 * 8;
-        st_xb[j]  = (unsigned)xc * 4u;
-        st_off[j] = (unsigned)(2 * rp * a.pitch + xc) * 4u;
-    }
-    const bool last_on = !LAST_PARTIAL || (t + (NLD - 1) * NT < NTASK);
-    const unsigned pitchb = (unsigned)a.pitch * 4u;
-    v4f pre[NLD][2];
-    auto issue = [&](const int k) __attribute__((always_inline)) {
-        const int ybase = Y0 - R + k * BR;
-        const bool rows_exist = ybase >= 0 && ybase + BR <= a.H;      // workgroup uniform: all but the first / last chunk of a plane
-        const GLOBAL_AS char* step_base = reinterpret_cast<const GLOBAL_AS char*>(gsrc + (ptrdiff_t)ybase * a.pitch);
-#pragma unroll
-        for (int j = 0; j < NLD; j++) {
-            if (j < NLD - 1 || last_on) {
-                if (rows_exist) {
-                    pre[j][0] = *reinterpret_cast<const GLOBAL_AS v4f*>(step_base + st_off[j]);
-                    pre[j][1] = *reinterpret_cast<const GLOBAL_AS v4f*>(step_base + (st_off[j] + pitchb));
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int y = psx_clampi(ybase + st_row[j] + h, 0, a.H - 1);
-                        pre[j][h] = *reinterpret_cast<const GLOBAL_AS v4f*>(reinterpret_cast<const GLOBAL_AS char*>(gsrc) + ((unsigned)y * pitchb + st_xb[j]));
-                    }
-                }
-            }
-        }
-    };
-    auto commit = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NLD; j++) {
-            if (j < NLD - 1 || last_on) {
-                float* sp = &s_stage[st_lds[j]];
-                *reinterpret_cast<v4f*>(sp)     = (v4f){pre[j][0].x, pre[j][1].x, pre[j][0].y, pre[j][1].y};
-                *reinterpret_cast<v4f*>(sp + 4) = (v4f){pre[j][0].z, pre[j][1].z, pre[j][0].w, pre[j][1].w};
-            }
-        }
-    };
-    // edge strips: staged columns [0, e_l) take the value of column e_l, columns [e_r, SW) that of column e_r - 1 (clamp
-    // addressing): patched in LDS once the step's rows have landed -- one more barrier on the plane's first and last strip only
-    const int e_l = min(max(HALO - x0, 0), SW - 1), e_r = max(min(a.W - (x0 - HALO), SW), 1);
-    auto patch = [&]() __attribute__((always_inline)) {
-        for (int idx = t; idx < (BR / 2) * SW; idx += NT) {
-            const int rp = idx / SW, c = idx - rp * SW;
-            v2f* row = reinterpret_cast<v2f*>(&s_stage[rp * SSP]);
-            if (c < e_l) row[c] = row[e_l];
-            else if (c >= e_r) row[c] = row[e_r - 1];
-        }
-    };
-
-    // ---- horizontal pass geometry: thread = (row pair, column quad) ----
-    const int h_quad = t & 15, h_rp = t >> 4;
-    const LDS_AS float* const h_src = (const LDS_AS float*)&s_stage[h_rp * SSP + 8 * h_quad];
-    // ---- vertical pass geometry: thread = (2 adjacent columns, 4 output rows) ----
-    const int v_pp = t & 31, v_rg = t >> 5;
-    const int v_x  = x0 + 2 * v_pp;
-    const unsigned v_doff = (unsigned)((v_rg * 4) * a.pitch + v_x) * 4u;
-    const bool v_xok = v_x < a.W, v_pair = v_x + 1 < a.W;
-
-    v2f pend[4];
-    auto flush = [&](const int kk) __attribute__((always_inline)) {
-        const int r_out0 = Y0 + kk * BR - 2 * R + v_rg * 4;
-        GLOBAL_AS char* drow = reinterpret_cast<GLOBAL_AS char*>(gdst + (ptrdiff_t)(Y0 - 2 * R + kk * BR) * a.pitch);
-        // fast path (workgroup uniform): every row of step kk inside the chunk, a full strip -- as blur_body
-        if (kk * BR >= 2 * R && Y0 + (kk + 1) * BR - 2 * R <= Y1 && x0 + TW <= a.W) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                GLOBAL_AS char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
-                unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
-                __hip_atomic_store(reinterpret_cast<GLOBAL_AS unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            if (a.half_dst != nullptr) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int r_out = r_out0 + i;
-                    if ((r_out & 1) == 0) ghalf[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int r_out = r_out0 + i;
-            if (r_out >= Y0 && r_out < Y1 && v_xok) {
-                GLOBAL_AS char* di = (drow + (size_t)i * a.pitch * 4) + v_doff;
-                if (v_pair) {
-                    unsigned long long bits; __builtin_memcpy(&bits, &pend[i], 8);
-                    __hip_atomic_store(reinterpret_cast<GLOBAL_AS unsigned long long*>(di), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                } else *reinterpret_cast<GLOBAL_AS float*>(di) = pend[i].x;
-                if (a.half_dst != nullptr && (r_out & 1) == 0) ghalf[(size_t)(r_out >> 1) * a.half_pitch + (v_x >> 1)] = pend[i].x;
-            }
-        }
-    };
-
-    issue(0);
-    for (int k = 0; k < nsteps; k++) {
-        commit();
-        if (DEFER) flush(k - 1);
-        if (!interior) { __syncthreads(); patch(); }
-        __syncthreads();
-        if (k + 1 < nsteps) issue(k + 1);
-
-        // ---- horizontal: 4 columns of 2 rows; centre first, then the taps from the outermost inwards (hfilter8_km's order) ----
-        {
-            auto ld = [&](int q) __attribute__((always_inline)) { return ((const volatile LDS_AS v4f*)h_src)[q]; };
-            auto lo = [](const v4f& c) { return (v2f){c.x, c.y}; };
-            auto hi = [](const v4f& c) { return (v2f){c.z, c.w}; };
-            // the whole window at once (all its LDS reads in flight together: a sliding window, one chunk per tap pair, cost a
-            // chain of LDS round trips per step and measured 17 % SLOWER than blur_body); window column j sits in chunk j / 2,
-            // output e is column HALO + e; only the columns HALO - R .. HALO + R + 3 are read
-            constexpr int C0 = (HALO - R) / 2, C1 = (HALO + R + 3) / 2;        // first / last chunk
-            v2f win[4 + 2 * HALO];
-#pragma unroll
-            for (int q = C0; q <= C1; q++) { const v4f c = ld(q); win[2 * q] = lo(c); win[2 * q + 1] = hi(c); }
-            v2f out[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) out[e] = pk_fma(win[HALO + e], a.taps.g[0], (v2f){0.0f, 0.0f});
-#pragma unroll
-            for (int kk = R; kk >= 1; kk--) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) out[e] = pk_fma(win[HALO + e - kk] + win[HALO + e + kk], a.taps.g[kk], out[e]);
-            }
-            const int slot = (k * BR + 2 * h_rp) & (RING - 1);       // even: slot + 1 is the pair's second row
-            float* rp = &s_ring[slot * RS + 4 * h_quad];
-            const v4f o0 = (v4f){out[0].x, out[1].x, out[2].x, out[3].x}, o1 = (v4f){out[0].y, out[1].y, out[2].y, out[3].y};
-            *reinterpret_cast<v4f*>(rp) = o0;
-            *reinterpret_cast<v4f*>(rp + RS) = o1;
-            if (slot < MIRROR) *reinterpret_cast<v4f*>(rp + RING * RS) = o0;
-            if (slot + 1 < MIRROR) *reinterpret_cast<v4f*>(rp + (RING + 1) * RS) = o1;
-        }
-        __syncthreads();
-
-        // ---- vertical: blur_body's ----
-        {
-            const int rel0 = k * BR - 2 * R + v_rg * 4;
-            const int r_out0 = Y0 + rel0;
-            if (r_out0 + 3 >= Y0 && r_out0 < Y1) {
-                const LDS_AS float* vp = (const LDS_AS float*)&s_ring[(rel0 & (RING - 1)) * RS + 2 * v_pp];
-                v2f v[VWIN];
-#pragma unroll
-                for (int j = 0; j < VWIN; j++) v[j] = *(const volatile LDS_AS v2f*)(vp + j * RS);
-                v2f o[4];
-                vfilter2x4_km<R>(v, a.taps, o);
-                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
-#pragma unroll
-                for (int i = 0; i < 4; i++) pend[i] = o[i];
-            }
-        }
-        if (!DEFER) flush(k);
-    }
-    if (DEFER) flush(nsteps - 1);
-}
-
-// HP: the horizontal pass packed over row pairs (blur_body_hp) instead of over adjacent columns (blur_body)
-template <int R, bool LEVEL0, bool DEFER = true, bool HP = false>
+// (a variant with the horizontal pass packed over row pairs, the form of pyramid_fixed.hip / blur_interp.h, was built here in
+// round 6, bit-exact, and measured 12-17 % SLOWER although its H pass has a third fewer instructions:
+// profiles/r06_blur_rowpair_h_ab.txt; the code is in the history)
+template <int R, bool LEVEL0, bool DEFER = true>
 __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur(BlurArgs a)
 {
     using G = Geom2<R>;
     __shared__ __attribute__((aligned(16))) float s_stage[BR * G::SWA];
     __shared__ __attribute__((aligned(16))) float s_ring[(G::RING + G::MIRROR) * G::RS];
-    if constexpr (HP) blur_body_hp<R, DEFER>(a, xcd_remap(blockIdx.x, gridDim.x), s_stage, s_ring, threadIdx.x);
-    else              blur_body<R, LEVEL0, DEFER>(a, xcd_remap(blockIdx.x, gridDim.x), s_stage, s_ring, threadIdx.x);
+    blur_body<R, LEVEL0, DEFER>(a, xcd_remap(blockIdx.x, gridDim.x), s_stage, s_ring, threadIdx.x);
 }
 
 // Two independent planes in one launch (the diagonal schedule of psx_build_pyramid: level l of octave o
 // together with level l-3 of octave o+1): the first na logical blocks belong to job a, the rest to job b.
 // Small octaves are latency chains of ~5 us launches; riding along with a larger octave's launch hides them.
-template <int R, bool HP = false>
+template <int R>
 __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blur2(BlurArgs a, BlurArgs b, int na)
 {
     using G = Geom2<R>;
@@ -846,13 +640,8 @@ __global__ __launch_bounds__(NT, (R <= 13) ? 4 : ((R <= 22) ? 2 : 1)) void k_blu
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     // two inlined copies: selecting the arguments through a pointer moves the taps out of the preloaded
     // kernel-argument SGPRs (120 bytes of VGPR spills at R = 13)
-    if constexpr (HP) {
-        if (lid < na) blur_body_hp<R, true>(a, lid, s_stage, s_ring, threadIdx.x);
-        else          blur_body_hp<R, true>(b, lid - na, s_stage, s_ring, threadIdx.x);
-    } else {
-        if (lid < na) blur_body<R, false, true>(a, lid, s_stage, s_ring, threadIdx.x);
-        else          blur_body<R, false, true>(b, lid - na, s_stage, s_ring, threadIdx.x);
-    }
+    if (lid < na) blur_body<R, false, true>(a, lid, s_stage, s_ring, threadIdx.x);
+    else          blur_body<R, false, true>(b, lid - na, s_stage, s_ring, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1611,13 +1400,6 @@ inline const BlurTuning& blur_tuning()
     return t;
 }
 
-// POPSIFT_BLUR_HP=1: the horizontal pass packed over row pairs (blur_body_hp; radii up to 16)
-inline bool blur_hp_enabled()
-{
-    static const bool on = [] { const char* e = getenv("POPSIFT_BLUR_HP"); return e != nullptr && e[0] == '1'; }();
-    return on;
-}
-
 inline void chunking(int W, int H, int R, int& chunk_rows, int& nchunks)
 {
     // S marching steps per chunk: the 2R warm-up rows cost ~2R/(S*BR) extra horizontal work, but a
@@ -1672,13 +1454,6 @@ hipError_t launch_blur2_r(const PsxBlurJob& ja, const PsxBlurJob& jb, hipStream_
     BlurArgs a, b;
     const int na = fill_job<R>(a, ja), nb = fill_job<R>(b, jb);
     const dim3 grid(na + nb), block(NT);
-    if constexpr (R <= 16) {
-        if (blur_hp_enabled()) {
-            if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((k_blur2<R, true>), grid, block, 0, s, ev0, ev1, 0, a, b, na);
-            else                                  hipLaunchKernelGGL((k_blur2<R, true>), grid, block, 0, s, a, b, na);
-            return hipGetLastError();
-        }
-    }
     if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((k_blur2<R>), grid, block, 0, s, ev0, ev1, 0, a, b, na);
     else                                  hipLaunchKernelGGL((k_blur2<R>), grid, block, 0, s, a, b, na);
     return hipGetLastError();
@@ -1739,13 +1514,6 @@ hipError_t launch_blur_r(const float* src, float* dst, int W, int H, int pitch, 
         if (dma == 3) { launch_dma<R, false, 3>(a, s, ev0, ev1); return hipGetLastError(); }
     }
     const bool ext = ev0 != nullptr || ev1 != nullptr;       // kernel begin / end timestamps of THIS dispatch (what rocprofv3 --kernel-trace reports)
-    if constexpr (R <= 16) {
-        if (blur_tuning().defer && blur_hp_enabled()) {
-            if (ext) hipExtLaunchKernelGGL((k_blur<R, false, true, true>), grid, block, 0, s, ev0, ev1, 0, a);
-            else     hipLaunchKernelGGL((k_blur<R, false, true, true>), grid, block, 0, s, a);
-            return hipGetLastError();
-        }
-    }
     if (blur_tuning().defer) {
         // POPSIFT_BLUR_LDS_PAD (measurement switch): extra dynamic LDS per workgroup, i.e. fewer resident k_blur
         // workgroups per CU, leaving room for another stream's kernels on the same CUs
