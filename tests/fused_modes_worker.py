@@ -27,12 +27,19 @@ CASES = [
     ("relative_direct", dict(gauss_mode=1, scaling_mode=0), (640, 480), False),
     ("relative_up0", dict(gauss_mode=1, upscale_factor=0.0), (1171, 653), False),
     ("relative_tiny", dict(gauss_mode=1), (70, 50), False),
+    # planes smaller than a strip, a step, a filter: every workgroup is an edge strip / a first-and-last chunk
+    ("fixed9_9x7", dict(gauss_mode=4, octaves=2), (9, 7), False),
+    ("fixed15_130x5", dict(gauss_mode=5, octaves=2), (130, 5), False),
+    ("fixed9_129x65_float", dict(gauss_mode=4, octaves=3), (129, 65), True),
+    ("relative_5x130", dict(gauss_mode=1, octaves=2), (5, 130), False),
+    ("relative_67x33", dict(gauss_mode=1, octaves=3), (67, 33), True),
+    ("relative_4x4", dict(gauss_mode=1, octaves=1), (4, 4), False),
 ]
 
 out = []
 for name, kw, (w, h), is_float in CASES:
     img = synth_float(w, h, 5) if is_float else synth(w, h, 5)
-    ctx = capi.Context(capi.default_config(octaves=5, **kw))
+    ctx = capi.Context(capi.default_config(**dict(dict(octaves=5), **kw)))
     ctx.upload(img)
     ctx.extract()
     sha = hashlib.sha1()

@@ -159,7 +159,7 @@ def test_fused_mode_kernels_equal_per_level_kernels():
                            env=dict(os.environ, **env), timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         res[tag] = json.loads(p.stdout.strip().splitlines()[-1])
-    assert len(res["fused"]) >= 12 and sum(r["n"] > 100 for r in res["fused"]) >= 10
+    assert len(res["fused"]) >= 19 and sum(r["n"] > 100 for r in res["fused"]) >= 10
     for tag in ("per_level", "literal", "no_diagonal"):
         for a, b in zip(res["fused"], res[tag]):
             assert a == b, (tag, a, b)
