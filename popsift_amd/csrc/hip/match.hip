@@ -167,6 +167,7 @@ constexpr int MF_SEGS = 32;                  // candidate segments per left desc
 constexpr int MF_SEGCAP = 32;                // ... of this many slots: private to one lane of one workgroup, so appending needs no atomic
 constexpr int MF_CAP = MF_SEGS * MF_SEGCAP;  // (a returned global atomic per candidate made the scan wait ~1 us per tile and column set)
 constexpr int MF_TILE = 32;                  // right descriptors per MFMA tile
+constexpr int MF_SUB = 2;                    // MFMA tiles per staged block (= per barrier)
 constexpr int MF_ROW = 272;                  // bytes per staged right descriptor: 256 + 16 (rows 4 banks apart: conflict-free b128 reads)
 constexpr int MF_SEED = 2048;                // right descriptors of the seeding pass ...
 constexpr int MF_SEEDCH = 8;                 // ... in this many chunks (workgroups per 256 left descriptors)
@@ -270,14 +271,19 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
                                                        int chunk_len, const float* __restrict__ par, float* __restrict__ seed,
                                                        int* __restrict__ cand_ct, int* __restrict__ cand)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_r[2][MF_TILE * MF_ROW];
-    __shared__ __attribute__((aligned(16))) float s_n[2][MF_TILE];
+    __shared__ __attribute__((aligned(16))) unsigned char s_r[2][MF_SUB * MF_TILE * MF_ROW];
+    __shared__ __attribute__((aligned(16))) float s_n[2][MF_SUB * MF_TILE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int r0 = blockIdx.y * chunk_len, r1 = min(r0 + chunk_len, r_len);
-    const int ntiles = (r1 - r0 + MF_TILE - 1) / MF_TILE;
+    const int ntiles = (r1 - r0 + MF_SUB * MF_TILE - 1) / (MF_SUB * MF_TILE);      // staged blocks of MF_SUB tiles
     const float fneg2 = par[1], rmax2 = par[2], bigM = par[3];
     const float rmax = sqrtf(rmax2);
+    // Round 6: the epilogue works on D = s' / fneg2 = <f16 l, f16 r> + |r|^2 / fneg2 instead of s' = |r|^2 + fneg2 <l, r>.  fneg2 = -2 / 4^k is
+    // a negative power of two times 2: dividing by it is EXACT and reverses the order, so "s' <= threshold" is "D >= threshold /
+    // fneg2" with the same bits on both sides; the norm term enters as the INITIAL VALUE of the MFMA accumulator (the
+    // staged norms are pre-scaled), which removes the fma per pair, and the test of a whole tile column is one maximum.
+    const float inv = 1.0f / fneg2;
 
     // ---- this wave's left descriptors: B operands (8 K-steps x 2 column sets), norms, margins ----
     f16x8 bfrag[2][8];
@@ -293,10 +299,11 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
         for (int kk = 0; kk < 8; kk++) bfrag[c][kk] = *reinterpret_cast<const f16x8*>(lp + kk * 16);
         const float nl = ln2[lq];
         const float E = 0.00197f * sqrtf(nl) * rmax + 2e-7f * bigM * (sqrtf(nl) + rmax) + 4e-5f * (nl + rmax2);
-        twoE[c] = 2.0f * E;
-        // running smallest / second smallest of s' = |r|^2 - 2 <l, r> (|l|^2 is the same for every pair of a column).  The
-        // real pass starts both at the sample's second smallest: "two values <= S exist" is all a threshold needs.
-        if (SEED) m1[c] = m2[c] = INFINITY;
+        twoE[c] = 2.0f * E * -inv;                      // the margin in D units (-inv > 0, a power of two: exact)
+        // running LARGEST / second largest of D (= smallest / second smallest of s' = |r|^2 - 2 <l, r>; |l|^2 is the same for every
+        // pair of a column).  The real pass starts both at the sample's second smallest s': "two values <= S exist" is all a
+        // threshold needs.
+        if (SEED) m1[c] = m2[c] = -INFINITY;
         else {
             // second smallest of the seeding pass' MF_SEEDCH (smallest, second smallest) pairs
             float a1 = INFINITY, a2 = INFINITY;
@@ -305,30 +312,35 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
                 const float v = seed[((size_t)(q >> 1) * l_len + lq) * 2 + (q & 1)];
                 a2 = fminf(a2, fmaxf(a1, v)); a1 = fminf(a1, v);
             }
-            m1[c] = m2[c] = a2;
+            m1[c] = m2[c] = a2 * inv;
         }
     }
     int cnt[2] = {0, 0};                         // candidates of this lane's segment = (left descriptor, chunk, half wave)
     const int seg = blockIdx.y * 2 + half;
 
-    // ---- staging of a right tile: 32 descriptors x 256 bytes = 512 16-byte pieces, two per thread; norms by 32 threads.
-    // Two steps, so that the global loads of tile k + 2 are in flight while tile k is computed: issue() = loads into
-    // registers; commit() = registers into the LDS buffer of tile k + 1 (free since the barrier that ended iteration k - 1) ----
-    // (two named registers sets and macros, not an array captured by lambdas: the array stayed in scratch memory, and the
+    // ---- staging of a block of MF_SUB right tiles: 64 descriptors x 256 bytes = 1024 16-byte pieces, four per thread; norms by 64
+    // threads.  Two steps, so that the global loads of block k + 2 are in flight while block k is computed: issue() = loads into
+    // registers; commit() = registers into the LDS buffer of block k + 1 (free since the barrier that ended iteration k - 1).
+    // One barrier per TWO tiles (round 6: the waves of a workgroup take different times per tile -- half of them run the
+    // candidate path -- and met at a barrier after every 16 MFMAs) ----
+    // (named register sets and macros, not an array captured by lambdas: the array stayed in scratch memory, and the
     // scratch store behind each global load waited for it -- the loads were not in flight at all)
-    uint4 pre0 = make_uint4(0u, 0u, 0u, 0u), pre1 = make_uint4(0u, 0u, 0u, 0u);
+    static_assert(MF_SUB == 2, "four staging loads per thread");
+    uint4 pre0 = make_uint4(0u, 0u, 0u, 0u), pre1 = make_uint4(0u, 0u, 0u, 0u), pre2 = make_uint4(0u, 0u, 0u, 0u), pre3 = make_uint4(0u, 0u, 0u, 0u);
     float pre_n = INFINITY;
-    const int st_row0 = t >> 4, st_row1 = (t + 256) >> 4, st_c16 = t & 15;
+    const int st_row0 = t >> 4, st_c16 = t & 15;             // rows st_row0 + 16 i, i = 0..3
+#define MF_LOAD_(i_) (*reinterpret_cast<const uint4*>(rh + (size_t)min(base_ + st_row0 + 16 * (i_), r_len - 1) * 128 + st_c16 * 8))
 #define MF_ISSUE(tile_) do { \
-        const int base_ = r0 + (tile_) * MF_TILE; \
-        pre0 = *reinterpret_cast<const uint4*>(rh + (size_t)min(base_ + st_row0, r_len - 1) * 128 + st_c16 * 8); \
-        pre1 = *reinterpret_cast<const uint4*>(rh + (size_t)min(base_ + st_row1, r_len - 1) * 128 + st_c16 * 8); \
-        if (t < MF_TILE) pre_n = (base_ + t < r1) ? rn2[min(base_ + t, r_len - 1)] : INFINITY;     /* rows beyond the chunk never win */ \
+        const int base_ = r0 + (tile_) * (MF_SUB * MF_TILE); \
+        pre0 = MF_LOAD_(0); pre1 = MF_LOAD_(1); pre2 = MF_LOAD_(2); pre3 = MF_LOAD_(3); \
+        if (t < MF_SUB * MF_TILE) pre_n = (base_ + t < r1) ? rn2[min(base_ + t, r_len - 1)] : INFINITY;     /* rows beyond the chunk never win */ \
     } while (0)
 #define MF_COMMIT(buf_) do { \
-        *reinterpret_cast<uint4*>(&s_r[buf_][st_row0 * MF_ROW + st_c16 * 16]) = pre0; \
-        *reinterpret_cast<uint4*>(&s_r[buf_][st_row1 * MF_ROW + st_c16 * 16]) = pre1; \
-        if (t < MF_TILE) s_n[buf_][t] = pre_n; \
+        *reinterpret_cast<uint4*>(&s_r[buf_][(st_row0 +  0) * MF_ROW + st_c16 * 16]) = pre0; \
+        *reinterpret_cast<uint4*>(&s_r[buf_][(st_row0 + 16) * MF_ROW + st_c16 * 16]) = pre1; \
+        *reinterpret_cast<uint4*>(&s_r[buf_][(st_row0 + 32) * MF_ROW + st_c16 * 16]) = pre2; \
+        *reinterpret_cast<uint4*>(&s_r[buf_][(st_row0 + 48) * MF_ROW + st_c16 * 16]) = pre3; \
+        if (t < MF_SUB * MF_TILE) s_n[buf_][t] = pre_n * inv;      /* +inf (rows beyond the chunk) becomes -inf: never a maximum */ \
     } while (0)
 
     if (ntiles > 0) { MF_ISSUE(0); MF_COMMIT(0); }
@@ -338,54 +350,67 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
         const int buf = tile & 1;
         if (tile + 1 < ntiles) MF_COMMIT(buf ^ 1);       // loaded during the previous iteration
         if (tile + 2 < ntiles) MF_ISSUE(tile + 2);
+#pragma unroll
+        for (int sub = 0; sub < MF_SUB; sub++) {
+        // accumulators start at |r|^2 / fneg2 of their row (C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
         f32x16 acc[2];
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int g = 0; g < 4; g++) {
+            const f32x4 nr = *reinterpret_cast<const f32x4*>(&s_n[buf][sub * MF_TILE + 8 * g + 4 * half]);
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[c][i] = 0.0f;
-        const unsigned char* rp = &s_r[buf][col * MF_ROW + half * 16];
+            for (int e = 0; e < 4; e++) { acc[0][4 * g + e] = nr[e]; acc[1][4 * g + e] = nr[e]; }
+        }
+        const unsigned char* rp = &s_r[buf][(sub * MF_TILE + col) * MF_ROW + half * 16];
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) {
             const f16x8 a = *reinterpret_cast<const f16x8*>(rp + kk * 32);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfrag[0][kk], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfrag[1][kk], acc[1], 0, 0, 0);
         }
-        const int base = r0 + tile * MF_TILE;
+        const int base = r0 + (tile * MF_SUB + sub) * MF_TILE;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            // first the whole tile's values against the threshold the column had BEFORE this tile (a superset test), in
-            // one wave-wide decision: the common case "nobody has a candidate" costs a compare per element and one branch
-            // (forming the values again in the candidate path instead of keeping them: 162 VGPRs = three waves per SIMD,
-            // measured 261 us against 238 with two; keeping the 16 verdicts as wave masks and branching on each: 230 us
-            // against 190 -- profiles/r05_match_prefilter.txt)
-            float sp[16];
-            float thr = m2[c] + twoE[c];
-            bool any = false;
+            // The whole tile column against the threshold the column had BEFORE this tile (a superset test): one maximum of the
+            // lane's 16 values (v_max3_f32) and one compare -- the running maxima are updated only from values that pass it (a
+            // value below the threshold is below the second largest: it cannot change either of the two).  Rounds 5's form
+            // spent an fma, a compare and two v_med3 on every pair: 212 VALU instructions per 16 MFMAs.
+            if (SEED) {
+                // the seeding pass wants the two largest of everything it sees: no threshold, every value updates them
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 nr = *reinterpret_cast<const f32x4*>(&s_n[buf][8 * g + 4 * half]);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    sp[4 * g + e] = fmaf(fneg2, acc[c][4 * g + e], nr[e]);
-                    any |= sp[4 * g + e] <= thr;
-                    // m1 <= m2: the second smallest of {m1, m2, s} is their median (one v_med3_f32 for min(m2, max(m1, s)))
-                    m2[c] = __builtin_amdgcn_fmed3f(m1[c], m2[c], sp[4 * g + e]);
-                    m1[c] = __builtin_amdgcn_fmed3f(m1[c], sp[4 * g + e], -3.0e38f);      // = min: every s is far above -3e38
+                for (int reg = 0; reg < 16; reg++) {
+                    m2[c] = __builtin_amdgcn_fmed3f(m1[c], m2[c], acc[c][reg]);
+                    m1[c] = fmaxf(m1[c], acc[c][reg]);
                 }
+                continue;
             }
-            if (!SEED && __ballot(any && lidx[c] < l_len) != 0ull) {
-                if (any && lidx[c] < l_len) {
+            const float thr = m2[c] - twoE[c];
+            float mx = fmaxf(fmaxf(acc[c][0], acc[c][1]), acc[c][2]);
+#pragma unroll
+            for (int i = 3; i + 1 < 16; i += 2) mx = fmaxf(fmaxf(mx, acc[c][i]), acc[c][i + 1]);
+            mx = fmaxf(mx, acc[c][15]);
+            const bool any = mx >= thr;
+            if (__ballot(any) != 0ull) {
+                if (any) {
 #pragma unroll
                     for (int reg = 0; reg < 16; reg++) {
-                        const int ridx = base + 8 * (reg >> 2) + 4 * half + (reg & 3);
-                        if (sp[reg] <= thr && ridx < r1) {
-                            if (cnt[c] < MF_SEGCAP) cand[((size_t)lidx[c] * MF_SEGS + seg) * MF_SEGCAP + cnt[c]] = ridx;
-                            cnt[c]++;
+                        const float d = acc[c][reg];
+                        if (d >= thr) {
+                            // m1 >= m2: the second largest of {m1, m2, d} is their median
+                            m2[c] = __builtin_amdgcn_fmed3f(m1[c], m2[c], d);
+                            m1[c] = fmaxf(m1[c], d);
+                            if (!SEED) {
+                                const int ridx = base + 8 * (reg >> 2) + 4 * half + (reg & 3);
+                                if (ridx < r1 && lidx[c] < l_len) {
+                                    if (cnt[c] < MF_SEGCAP) cand[((size_t)lidx[c] * MF_SEGS + seg) * MF_SEGCAP + cnt[c]] = ridx;
+                                    cnt[c]++;
+                                }
+                            }
                         }
                     }
                 }
             }
         }
+        }   // sub
         __syncthreads();
     }
     if (!SEED) {
@@ -398,10 +423,10 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const float o1 = __shfl_xor(m1[c], 32), o2 = __shfl_xor(m2[c], 32);
-            const float s1 = fminf(m1[c], o1), s2 = fminf(fmaxf(m1[c], o1), fminf(m2[c], o2));
+            const float d1 = fmaxf(m1[c], o1), d2 = fmaxf(fminf(m1[c], o1), fmaxf(m2[c], o2));     // largest, second largest D
             if (half == 0 && lidx[c] < l_len) {
                 float* sd = seed + ((size_t)blockIdx.y * l_len + lidx[c]) * 2;
-                sd[0] = s1; sd[1] = s2;
+                sd[0] = d1 * fneg2; sd[1] = d2 * fneg2;                                           // back to s' (exact)
             }
         }
     }
@@ -409,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
 
 #undef MF_ISSUE
 #undef MF_COMMIT
+#undef MF_LOAD_
 
 // (distance, index) lexicographic order: what the reference's sequential scan with strict '<' yields
 __device__ __forceinline__ bool lex_less(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
