@@ -137,7 +137,9 @@ __global__ void k_match_merge(const Top2* __restrict__ partial, int l_len, int n
 //       f16 keeps 11 significant bits (round to nearest even): an element >= 2^-14 in magnitude has relative error <= u = 2^-11,
 //       a smaller one absolute error <= 2^-25, so |<f16 l, f16 r> - <l, r>| <= 2.002 u |l| |r| + 2^-25 sqrt(128) (|l| + |r|)
 //       (Cauchy-Schwarz); the f32 accumulation of 128 exact products, the f32 norms and the rounding of the reference's own
-//       operation tree add <= 2e-5 (|l|^2 + |r|^2).  With Rmax = max |r|:
+//       operation tree add <= 2e-5 (|l|^2 + |r|^2) (round 6: the accumulation STARTS at |r|^2 / fneg2 -- an exact scaling of the
+//       norm -- instead of adding it last: 129 terms instead of 128 in the same f32 chain, (129 / 2^24) (|l| |r| + |r|^2 / 2) <
+//       8e-6 (|l|^2 + |r|^2), inside the same term).  With Rmax = max |r|:
 //       E_l := 0.00197 |l| Rmax + 2e-7 M (|l| + Rmax) + 4e-5 (|l|^2 + Rmax^2)  (bf16, 8 bits, had 0.0157: on random descriptors,
 //       whose distances concentrate, hundreds of neighbours fell inside the margin).
 //       f16's RANGE is taken out of the picture by scaling both sides with a power of two 2^k (exact) before the conversion,
