@@ -391,22 +391,26 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
             for (int i = 3; i + 1 < 16; i += 2) mx = fmaxf(fmaxf(mx, acc[c][i]), acc[c][i + 1]);
             mx = fmaxf(mx, acc[c][15]);
             const bool any = mx >= thr;
+            // The running extrema take only the lane's LARGEST value of the tile: m2 then is the second largest of a subset of
+            // what the column has seen, i.e. <= the true second largest -- a lower threshold, a superset of candidates, still the
+            // proven bound (two values >= m2 exist).  Exact tracking needed a compare-and-branch per value in the candidate path
+            // (16 branches per column set and tile, nearly all taken: what the kernel waited for).
+            m2[c] = __builtin_amdgcn_fmed3f(m1[c], m2[c], mx);
+            m1[c] = fmaxf(m1[c], mx);
             if (__ballot(any) != 0ull) {
-                if (any) {
+                if (any && lidx[c] < l_len) {
+                    // which of the 16 values pass: one bit per value, no branch (bit 15 - reg)
+                    unsigned hits = 0u;
 #pragma unroll
-                    for (int reg = 0; reg < 16; reg++) {
-                        const float d = acc[c][reg];
-                        if (d >= thr) {
-                            // m1 >= m2: the second largest of {m1, m2, d} is their median
-                            m2[c] = __builtin_amdgcn_fmed3f(m1[c], m2[c], d);
-                            m1[c] = fmaxf(m1[c], d);
-                            if (!SEED) {
-                                const int ridx = base + 8 * (reg >> 2) + 4 * half + (reg & 3);
-                                if (ridx < r1 && lidx[c] < l_len) {
-                                    if (cnt[c] < MF_SEGCAP) cand[((size_t)lidx[c] * MF_SEGS + seg) * MF_SEGCAP + cnt[c]] = ridx;
-                                    cnt[c]++;
-                                }
-                            }
+                    for (int reg = 0; reg < 16; reg++) hits = (hits << 1) | (acc[c][reg] >= thr ? 1u : 0u);
+                    while (hits != 0u) {
+                        const int b = 31 - __builtin_clz(hits);
+                        hits &= ~(1u << b);
+                        const int reg = 15 - b;
+                        const int ridx = base + 8 * (reg >> 2) + 4 * half + (reg & 3);
+                        if (ridx < r1) {
+                            if (cnt[c] < MF_SEGCAP) cand[((size_t)lidx[c] * MF_SEGS + seg) * MF_SEGCAP + cnt[c]] = ridx;
+                            cnt[c]++;
                         }
                     }
                 }
