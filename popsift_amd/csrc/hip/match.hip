@@ -386,23 +386,26 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const unsigned short* __r
                 continue;
             }
             const float thr = m2[c] - twoE[c];
-            float mx = fmaxf(fmaxf(acc[c][0], acc[c][1]), acc[c][2]);
+            // maxima of the four register groups (4 values each), then of the lane's 16 values
+            float gm[4];
 #pragma unroll
-            for (int i = 3; i + 1 < 16; i += 2) mx = fmaxf(fmaxf(mx, acc[c][i]), acc[c][i + 1]);
-            mx = fmaxf(mx, acc[c][15]);
+            for (int g = 0; g < 4; g++) gm[g] = fmaxf(fmaxf(fmaxf(acc[c][4 * g], acc[c][4 * g + 1]), acc[c][4 * g + 2]), acc[c][4 * g + 3]);
+            const float mx = fmaxf(fmaxf(fmaxf(gm[0], gm[1]), gm[2]), gm[3]);
             const bool any = mx >= thr;
-            // The running extrema take only the lane's LARGEST value of the tile: m2 then is the second largest of a subset of
-            // what the column has seen, i.e. <= the true second largest -- a lower threshold, a superset of candidates, still the
-            // proven bound (two values >= m2 exist).  Exact tracking needed a compare-and-branch per value in the candidate path
-            // (16 branches per column set and tile, nearly all taken: what the kernel waited for).
             m2[c] = __builtin_amdgcn_fmed3f(m1[c], m2[c], mx);
             m1[c] = fmaxf(m1[c], mx);
             if (__ballot(any) != 0ull) {
                 if (any && lidx[c] < l_len) {
-                    // which of the 16 values pass: one bit per value, no branch (bit 15 - reg)
+                    // which of the 16 values pass: one bit per value (bit 15 - reg); a group of four is looked at only when some lane's
+                    // group maximum passes (one wave-uniform branch per group instead of a compare per value)
                     unsigned hits = 0u;
 #pragma unroll
-                    for (int reg = 0; reg < 16; reg++) hits = (hits << 1) | (acc[c][reg] >= thr ? 1u : 0u);
+                    for (int g = 0; g < 4; g++) {
+                        if (__ballot(gm[g] >= thr) != 0ull) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) hits |= (acc[c][4 * g + e] >= thr ? 1u : 0u) << (15 - (4 * g + e));
+                        }
+                    }
                     while (hits != 0u) {
                         const int b = 31 - __builtin_clz(hits);
                         hits &= ~(1u << b);
