@@ -213,7 +213,7 @@ __global__ void k_match_norms(const float* __restrict__ src_a, int n_a, float* _
     if (threadIdx.x == 0) atomicMax(&maxbits[bid & (MF_MAXSLOTS - 1)], s_max);
 }
 
-// par[0] = 2^k, par[1] = -2 / 4^k, par[2] = Rmax^2, par[3] = M; *flag = 1 when the prefilter cannot be used
+// par[0] = 2^k, par[1] = -2 / 4^k, par[2] = Rmax^2, par[3] = M; *bad = 1 when the prefilter cannot be used
 __device__ __forceinline__ void match_scale(float l2, float r2, float* par, int* bad)
 {
     const float m2 = fmaxf(l2, r2);
@@ -243,7 +243,7 @@ __global__ void k_match_cvt(const float* __restrict__ src_a, int n_a, unsigned s
             float pp[4]; int bad;
             match_scale(__uint_as_float(lb), __uint_as_float(rb), pp, &bad);
             s_par[0] = pp[0];
-            if (blockIdx.x == 0) { par[0] = pp[0]; par[1] = pp[1]; par[2] = pp[2]; par[3] = pp[3]; if (bad) *flag = 1; }
+            if (blockIdx.x == 0) { par[0] = pp[0]; par[1] = pp[1]; par[2] = pp[2]; par[3] = pp[3]; *flag = bad; }   // the call's first write of the flag
         }
     }
     __syncthreads();
@@ -460,9 +460,13 @@ __device__ __forceinline__ void top2_insert_lex(Top2& t, float d, int i)
 //   q = l4 - r4;  p_t = fma(q.w, q.w, fma(q.z, q.z, fma(q.x, q.x, q.y * q.y)));  then v += shfl_down(v, 16 / 8 / 4 / 2 / 1):
 // lane 0 ends with ((((p0 + p16) + (p8 + p24)) + ...)), the tree of l2_tree above.  `left` / `right` in ORIGINAL layout.
 __global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ left, int l_len, const float* __restrict__ right, int r_len,
-                                                     const int* __restrict__ cand_ct, const int* __restrict__ cand,
-                                                     int* __restrict__ out, float* __restrict__ dist, int* __restrict__ flag)
+                                                     int* cand_ct, const int* __restrict__ cand,
+                                                     int* __restrict__ out, float* __restrict__ dist, int* __restrict__ flag,
+                                                     unsigned* __restrict__ maxslots, int tidy)
 {
+    // the last kernel of a call leaves the prefilter's counters as the next call needs them (two memsets per call, one of them
+    // 4.7 MB, were ~10 us of a 0.25 ms call): the 2 x MF_MAXSLOTS maximum slots here, every candidate count below once it is read
+    if (tidy && blockIdx.x == 0 && threadIdx.x < 2 * MF_MAXSLOTS) maxslots[threadIdx.x] = 0u;
     // launched behind the prefilter without waiting for its verdict: a raised flag (a candidate segment overflowed, norms the
     // margin cannot bound) means the host will run the exact scan of every pair instead
     if (*flag != 0) return;
@@ -474,6 +478,7 @@ __global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ l
     __shared__ int s_list[4][MF_CAP];
     int* cl = s_list[threadIdx.x >> 6];
     const int rawct = lane < MF_SEGS ? cand_ct[(size_t)li * MF_SEGS + lane] : 0;
+    if (tidy && lane < MF_SEGS && rawct != 0) cand_ct[(size_t)li * MF_SEGS + lane] = 0;
     // a segment that overflowed (the prefilter counted more candidates than it could store): the whole call goes through the
     // exact scan of every pair -- the host reads the flag with the results (a separate kernel for this test cost a 5 us launch)
     if (rawct > MF_SEGCAP) *flag = 1;
@@ -488,17 +493,27 @@ __global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ l
     __builtin_amdgcn_wave_barrier();
     // the sentinel index is larger than any real one: an empty slot loses every tie
     Top2 t = {INFINITY, INFINITY, 0x7fffffff, 0x7fffffff};
-    for (int c0 = 0; c0 < n; c0 += 2) {
-        const int c = c0 + half;
-        const bool on = c < n;
-        const int ri = on ? cl[c] : 0;
-        const float4 r4 = reinterpret_cast<const float4*>(right + (size_t)ri * 128)[tl];
-        const float qx = l4.x - r4.x, qy = l4.y - r4.y, qz = l4.z - r4.z, qw = l4.w - r4.w;
-        float v = fmaf(qw, qw, fmaf(qz, qz, fmaf(qx, qx, qy * qy)));
-        v += __shfl_down(v, 16, 32); v += __shfl_down(v, 8, 32); v += __shfl_down(v, 4, 32);
-        v += __shfl_down(v, 2, 32);  v += __shfl_down(v, 1, 32);
-        const float d = __shfl(v, 0, 32);                    // the half's distance, in all of its lanes
-        if (on) top2_insert_lex(t, d, ri);
+    // 2 x EX_K candidates per round (EX_K per half wave): all 512-byte reads of a half are in flight before the first reduction
+    // (one at a time, every round waited for its own L2 round trip: 47 us for ~20 candidates per descriptor; two: 37 us)
+    constexpr int EX_K = 2;                                 // 4 measured the same (37 us): past two, the insert chain is the limit
+    for (int c0 = 0; c0 < n; c0 += 2 * EX_K) {
+        int ri[EX_K];
+        float4 r4[EX_K];
+#pragma unroll
+        for (int k = 0; k < EX_K; ++k) {
+            const int c = c0 + 2 * k + half;
+            ri[k] = c < n ? cl[c] : -1;
+            r4[k] = reinterpret_cast<const float4*>(right + (size_t)(ri[k] < 0 ? 0 : ri[k]) * 128)[tl];
+        }
+#pragma unroll
+        for (int k = 0; k < EX_K; ++k) {
+            const float qx = l4.x - r4[k].x, qy = l4.y - r4[k].y, qz = l4.z - r4[k].z, qw = l4.w - r4[k].w;
+            float v = fmaf(qw, qw, fmaf(qz, qz, fmaf(qx, qx, qy * qy)));
+            v += __shfl_down(v, 16, 32); v += __shfl_down(v, 8, 32); v += __shfl_down(v, 4, 32);
+            v += __shfl_down(v, 2, 32);  v += __shfl_down(v, 1, 32);
+            const float d = __shfl(v, 0, 32);                // the half's distance, in all of its lanes
+            if (ri[k] >= 0) top2_insert_lex(t, d, ri[k]);
+        }
     }
     {   // the two halves hold disjoint candidate subsets: merge
         const float od1 = __shfl_xor(t.d1, 32), od2 = __shfl_xor(t.d2, 32);
@@ -527,6 +542,7 @@ struct MatchScratch {
     size_t cap[10] = {};
     void* hpin = nullptr;                // pinned staging of the results: a DMA into pageable caller memory goes through the
     size_t hpin_cap = 0;                 // runtime's own bounce buffers, ~0.5 ms per call on this stack
+    bool tidy = false;                   // the prefilter's counters are zero (left so by the previous call's last kernel)
     void release()
     {
         if (device < 0) return;
@@ -534,6 +550,7 @@ struct MatchScratch {
         if (hipGetDevice(&cur) != hipSuccess) cur = -1;
         (void)hipSetDevice(device);
         for (int i = 0; i < 10; i++) { (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+        tidy = false;
         if (hpin) (void)hipHostFree(hpin);
         hpin = nullptr; hpin_cap = 0;
         if (stream) (void)hipStreamDestroy(stream);
@@ -553,6 +570,7 @@ struct MatchScratch {
     {
         if (bytes <= cap[i] && buf[i]) return true;
         (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0;
+        tidy = false;
         if (hipMalloc(&buf[i], bytes) != hipSuccess) return false;
         cap[i] = bytes;
         return true;
@@ -595,12 +613,14 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
 
     if (!sc.need(0, sizeof(Top2) * (size_t)nchunks * l_len) ||
         !sc.need(1, sizeof(float) * 128 * (size_t)(r_len > 0 ? r_len : 1)) ||
-        !sc.need(2, sizeof(int) * 3 * (size_t)l_len) || !sc.need(3, sizeof(float) * 2 * (size_t)l_len))
+        !sc.need(2, (sizeof(int) * 3 + sizeof(float) * 2) * (size_t)l_len + 64))
         return PSX_ERR_NOMEM;
     Top2* d_partial = static_cast<Top2*>(sc.buf[0]);
     float* d_rperm = static_cast<float*>(sc.buf[1]);
     int* d_out = static_cast<int*>(sc.buf[2]);
-    float* d_dist = static_cast<float*>(sc.buf[3]);
+    // matches, distances and the prefilter's flag in ONE buffer: one copy back per call (three cost ~5 us each)
+    float* d_dist = reinterpret_cast<float*>(d_out + 3 * (size_t)l_len);
+    int* d_flag = reinterpret_cast<int*>(d_dist + 2 * (size_t)l_len);
     hipStream_t st = sc.stream;
     // POPSIFT_MATCH_MFMA=0: the exact scan of every pair (rounds 1-4); default: MFMA prefilter + exact evaluation of the
     // candidates (identical results by construction; used from 2 * MF_SEED = 4096 right / 256 left descriptors on)
@@ -617,12 +637,12 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         unsigned short* d_rf16 = static_cast<unsigned short*>(sc.buf[5]);
         float* d_ln2 = static_cast<float*>(sc.buf[6]);
         float* d_seed = d_ln2 + l_len;
-        float* d_rn2 = static_cast<float*>(sc.buf[7]);
-        // behind the right norms: 2 x MF_MAXSLOTS maximum slots, the overflow flag, 4 parameters
-        unsigned* d_rmax = reinterpret_cast<unsigned*>(d_rn2 + r_len);
+        // in front of the right norms, at an address that does not move with r_len (the slots are zeroed by the previous call):
+        // 2 x MF_MAXSLOTS maximum slots, 4 parameters
+        unsigned* d_rmax = static_cast<unsigned*>(sc.buf[7]);
         unsigned* d_lmax = d_rmax + MF_MAXSLOTS;
-        int* d_flag = reinterpret_cast<int*>(d_lmax + MF_MAXSLOTS);
-        float* d_par = reinterpret_cast<float*>(d_flag + 1);
+        float* d_par = reinterpret_cast<float*>(d_lmax + MF_MAXSLOTS);
+        float* d_rn2 = reinterpret_cast<float*>(d_rmax + 256);
         int* d_cct = static_cast<int*>(sc.buf[8]);
         int* d_cand = static_cast<int*>(sc.buf[9]);
         // workgroups the prefilter kernel keeps resident (the occupancy the runtime computes from its registers and LDS: 3 per CU)
@@ -643,9 +663,14 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         if (nseed > MF_SEEDCH) nseed = MF_SEEDCH;
         if (nseed < 1) nseed = 1;
         const int seedlen = (((MF_SEED + nseed - 1) / nseed + MF_TILE - 1) / MF_TILE) * MF_TILE;
-        if (hipMemsetAsync(d_cct, 0, sizeof(int) * (size_t)MF_SEGS * l_len, st) != hipSuccess ||
-            hipMemsetAsync(d_rmax, 0, sizeof(unsigned) * (2 * MF_MAXSLOTS + 1), st) != hipSuccess ||
-            (nseed < MF_SEEDCH && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_seed), 0x7f800000, 2 * (size_t)MF_SEEDCH * l_len, st) != hipSuccess))
+        static const bool stats = getenv("POPSIFT_MATCH_STATS") != nullptr;       // measurement: candidates per left descriptor
+        // the candidate counts and the maximum slots: zeroed here after an allocation or a call that did not finish the usual
+        // way, otherwise left at zero by the previous call's k_match_exact
+        if (!sc.tidy && (hipMemsetAsync(d_cct, 0, sc.cap[8], st) != hipSuccess ||
+                         hipMemsetAsync(d_rmax, 0, sizeof(unsigned) * 2 * MF_MAXSLOTS, st) != hipSuccess))
+            return PSX_ERR_HIP;
+        sc.tidy = false;                                       // until this call's results are back with the flag down
+        if ((nseed < MF_SEEDCH && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_seed), 0x7f800000, 2 * (size_t)MF_SEEDCH * l_len, st) != hipSuccess))
             return PSX_ERR_HIP;
         const int rblk = (r_len * 32 + 255) / 256, lblk = (l_len * 32 + 255) / 256;
         // norms: a few descriptors per 32-thread group (one per group made 9 216 workgroups of one load each: 18 us for 19 MB)
@@ -670,7 +695,7 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         // the exact evaluation of the candidates goes out at once (it also raises the flag for an overflowed candidate segment); the
         // flag comes back with the results (one synchronisation per call instead of two)
         hipLaunchKernelGGL(k_match_exact, dim3((l_len + 3) / 4), dim3(256), 0, st, d_left, l_len, d_right, r_len, d_cct, d_cand,
-                           d_out, d_dist, d_flag);
+                           d_out, d_dist, d_flag, d_rmax, stats ? 0 : 1);
         exact_scan = false;
         d_flag_used = d_flag; d_cct_used = d_cct;
     }
@@ -681,15 +706,13 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
     *h_flagp = 0;
     auto fetch = [&]() -> bool {
         return hipGetLastError() == hipSuccess &&
-               hipMemcpyAsync(hp, d_out, mb, hipMemcpyDeviceToHost, st) == hipSuccess &&
-               (!host_dist || hipMemcpyAsync(hp + mb, d_dist, db, hipMemcpyDeviceToHost, st) == hipSuccess) &&
-               (!d_flag_used || hipMemcpyAsync(h_flagp, d_flag_used, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess) &&
+               hipMemcpyAsync(hp, d_out, mb + db + (d_flag_used ? sizeof(int) : 0), hipMemcpyDeviceToHost, st) == hipSuccess &&
                hipStreamSynchronize(st) == hipSuccess;
     };
     if (!exact_scan) {
         if (!fetch()) return PSX_ERR_HIP;
         const int h_flag = *h_flagp;
-        static const bool stats = getenv("POPSIFT_MATCH_STATS") != nullptr;       // measurement: candidates per left descriptor
+        static const bool stats = getenv("POPSIFT_MATCH_STATS") != nullptr;
         if (stats) {
             std::vector<int> h((size_t)l_len * MF_SEGS);
             if (hipMemcpy(h.data(), d_cct_used, sizeof(int) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -701,6 +724,7 @@ extern "C" int psx_match(int device, const float* d_left, int l_len, const float
         }
         // a list overflowed (thousands of near-equal neighbours) or the norms are out of the margin's reach: the exact scan below
         if (h_flag != 0) { exact_scan = true; d_flag_used = nullptr; }
+        else if (!stats) sc.tidy = true;
     }
     if (exact_scan) {
     if (r_len > 0)

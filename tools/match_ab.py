@@ -38,7 +38,7 @@ def worker(n):
     for _ in range(5):
         t = time.perf_counter(); mm, dd = dl.match(dr); dt = time.perf_counter() - t
         best = dt if best is None or dt < best else best
-    print(json.dumps({"mfma": os.environ.get("POPSIFT_MATCH_MFMA", "1"), "left": len(l), "right": len(r), "seconds": round(best, 5),
+    print(json.dumps({"mfma": os.environ.get("POPSIFT_MATCH_MFMA", "1"), "left": len(l), "right": len(r), "seconds": round(best, 6),
                       "gpairs_per_s": round(len(l) * len(r) / best / 1e9, 1),
                       "sha1": hashlib.sha1(mm.tobytes() + dd.tobytes()).hexdigest(), "accepted": int((mm[:, 2] == 1).sum())}))
 
