@@ -677,18 +677,19 @@ def match_leg(capi, np, device):
         v = rng.random((2 * n, 128), dtype=np.float32) ** 4
         v = np.sqrt(v / v.sum(1, keepdims=True)).astype(np.float32)           # RootSift-like: non-negative, unit L2 norm
         l, r = capi.DeviceDescriptors(v[:n], device), capi.DeviceDescriptors(v[n:], device)
-        l.match(r)
+        for _ in range(5):                                   # clocks and the thread's scratch buffers settle
+            l.match(r)
         ts = []
-        for _ in range(5):
+        for _ in range(30):
             t1 = time.perf_counter()
             l.match(r)
             ts.append(time.perf_counter() - t1)
         dt = sorted(ts)[len(ts) // 2]
         l.close(); r.close()
         gp = n * n / dt / 1e9
-        return {"left": n, "right": n, "seconds": round(dt, 5), "gpairs_per_s": round(gp, 1),
+        return {"left": n, "right": n, "seconds": round(dt, 6), "gpairs_per_s": round(gp, 1), "calls_timed": len(ts), "statistic": "median",
                 "exact_scan_valu_peak_gpairs_per_s": round(256 * 4 * 16 * 2.4e9 / 165 / 1e9, 1),
-                "what": "psx_match on device-resident descriptors (host call to results in host memory): k_match_norms / k_match_scale / k_match_cvt of both sides, seeding pass, "
+                "what": "psx_match on device-resident descriptors (host call to results in host memory): k_match_norms / k_match_cvt of both sides, seeding pass, "
                         "k_match_mfma (v_mfma_f32_32x32x16_f16 + proven error margin), k_match_exact on the candidates; bit-identical to "
                         "the reference's scan (tests/test_gpu_parity.py::test_match_bit_exact, ::test_match_mfma_prefilter_equals_exact_scan); "
                         "POPSIFT_MATCH_MFMA=0 = the exact scan of every pair (rounds 1-4: 63-82 G pairs/s)"}

@@ -366,7 +366,10 @@ bool psx_blur_interp_pair_ok(int W1, int H1, int ispan1, int W2, int H2, int isp
 {
     const int isp = ispan1 > ispan2 ? ispan1 : ispan2;
     const int wgpc = (isp - 1) / 2 >= 5 && PSX_INTERP_WGPC_BIG > 0 ? PSX_INTERP_WGPC_BIG : 4;
-    return psx_blur_interp_grid(W1, H1, isp) + psx_blur_interp_grid(W2, H2, isp) <= wgpc * device_cus();
+    // POPSIFT_INTERP_PAIR_ROUNDS (measurement switch): percent of one round the two grids together may take (150 / 200, i.e. octave 0's
+    // levels 4 and 5 sharing a launch with octave 1's levels 1 and 2: pyramid 0.315 -> 0.319 / 0.322 ms, profiles/r06_interp_pair_rounds.txt)
+    static const int pct = [] { const char* e = getenv("POPSIFT_INTERP_PAIR_ROUNDS"); const int v = e ? atoi(e) : 0; return v >= 50 && v <= 1000 ? v : 100; }();
+    return (psx_blur_interp_grid(W1, H1, isp) + psx_blur_interp_grid(W2, H2, isp)) * 100 <= wgpc * device_cus() * pct;
 }
 
 // two independent levels in one launch; the kernel is instantiated for the larger pair count (zero-weight pairs for the other)
