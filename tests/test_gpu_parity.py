@@ -515,6 +515,41 @@ def test_match_mfma_prefilter_equals_exact_scan(oracle, capi):
         assert np.array_equal(do_.view(np.uint32), dg.view(np.uint32)), name
 
 
+def test_match_scratch_state_between_calls(oracle, capi):
+    """psx_match keeps its scratch per calling thread and the last kernel of a call leaves the prefilter's counters zeroed
+    for the next one (match.hip, MatchScratch::tidy).  Sequences that would expose stale state: the same pair three times; a
+    smaller right side after a larger one (buffers not reallocated, the maximum slots must not move with r_len); a call that
+    ends in the full-scan fallback (overflowing candidate lists: the counters are NOT left tidy) followed by an ordinary one; a
+    call below the prefilter's size limits in between.  Every result bit-identical to the oracle's scan."""
+    rng = np.random.default_rng(23)
+
+    def unit(n):
+        v = rng.random((n, 128), dtype=np.float32) ** 4
+        return np.sqrt(v / v.sum(1, keepdims=True)).astype(np.float32)
+
+    def check(l, r, what):
+        mo, do_ = oracle.match(l, r)
+        mg, dg = capi.match(l, r)
+        assert np.array_equal(mo, mg), what
+        assert np.array_equal(do_.view(np.uint32), dg.view(np.uint32)), what
+
+    la, ra = unit(900), unit(9000)
+    for k in range(3):
+        check(la, ra, "same pair, call %d" % k)
+    lb, rb = unit(700), unit(4300)
+    check(lb, rb, "smaller sets after larger ones")
+    check(la, ra, "the larger sets again")
+    lo, ro = unit(300), unit(9000)
+    ro[500:8600] = ro[499]                                   # candidate segments overflow: exact scan of every pair
+    check(lo, ro, "overflow")
+    check(lb, rb, "after the overflow call")
+    check(unit(100), unit(300), "below the prefilter's limits")
+    check(la, ra, "after the small call")
+    lz = unit(400); lz[7] *= np.float32(3e5)                 # norms out of the margin's reach: flag raised by k_match_cvt
+    check(lz, ra, "flag from the conversion kernel")
+    check(lb, rb, "after the flagged call")
+
+
 def test_match_prefilter_on_real_descriptors(oracle, capi):
     """The prefilter path on what it is for: the descriptors of two views of a scene (1280x720, ~8 k descriptors each, the second
     view shifted by 3 pixels: most left descriptors have a near-identical partner, i.e. distances close to zero where the
