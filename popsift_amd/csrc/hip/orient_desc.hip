@@ -627,8 +627,8 @@ __device__ __forceinline__ unsigned bin_slot(unsigned fo)
     return ((((h << 3) | h) >> 1) & 7u) << 3;            // v_and, v_lshl_or, v_bfe; the shift rides on the add
 }
 
-template <bool DENORM>
-__global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
+template <bool DENORM, int WGPC>
+__global__ __launch_bounds__(NT, WGPC) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
 {
     // Histogram layout per copy: tiles (iy, ix), iy, ix in -1..4, at index (iy+1)*5 + (ix+1) (31 slots), 16 words
     // each (two views of 8 bins).  Column 0 and rows 0 / 5 are never read: the trilinear scatter of a pixel near
@@ -640,11 +640,18 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
     // Config (sigma0 <= 2, gauss_filter.cu:131; levels >= 2, popsift.cpp:86) gives SBP <= 20.2, < 5.9e5 in total
     // and < 1.5e5 per copy (each copy takes a quarter of the pixels) against 2^18 = 2.6e5
     // (tests/test_gpu_configs.py::test_descriptor_bins_do_not_overflow_at_large_sigma).
-    constexpr int DCOPIES = 4, DTILES = 31, DSTRIDE = DTILES * 16 + 2;         // even: 8-byte aligned copies
+    // Round 6: the copies OVERLAP.  Slots 25..30 of a copy (row iy = 4, written, never read) lie on slots 0..5 of the next copy
+    // (row iy = -1 and tile (0, -1): written, never read), and the last copy of a wave on the first of the next wave (the last wave
+    // has a tail of its own): a copy advances by 25 slots + 2 words (the bank offset between copies that 31 slots + 2 had) instead of
+    // 31 slots + 2.  31.9 KB -> 26.1 KB per workgroup: six workgroups per CU fit the 160 KB instead of five.
+    constexpr int DCOPIES = 4, DTILES = 31, DSTRIDE = 25 * 16 + 2, WSTRIDE = DCOPIES * DSTRIDE;         // even: 8-byte aligned copies
+    static_assert(DSTRIDE % 2 == 0 && WSTRIDE % 4 == 0, "8-byte aligned copies, 16-byte aligned waves");
+    static_assert(DTILES * 16 - DSTRIDE <= 6 * 16, "a copy's tail must end inside the next copy's dump slots 0..5");
     constexpr float DFIX = 16384.0f;
-    __shared__ __attribute__((aligned(16))) unsigned s_desc[WPB][DCOPIES * DSTRIDE];
+    // (the WGPC = 5 instantiation pads the array to round 5's 31.9 KB: the A/B partner, POPSIFT_DESC_OCC=5)
+    __shared__ __attribute__((aligned(16))) unsigned s_desc[WPB * WSTRIDE + (DTILES * 16 - DSTRIDE) + 2 + (WGPC == 5 ? 1440 : 0)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned* acc = s_desc[wave];
+    unsigned* acc = s_desc + wave * WSTRIDE;
     const int lx = lane & 7, ly = lane >> 3;
     const int copy = (lane & 1) | (((lane >> 3) & 1) << 1);                    // neighbours in x and in y use different copies
     const unsigned myacc = (unsigned)(uintptr_t)(acc + copy * DSTRIDE);
@@ -664,8 +671,8 @@ __global__ __launch_bounds__(NT, 5) void k_descriptors(const PsxParams* __restri
 
         if (ori_num == 0 && lane == 0) write_feature(P, X, ext_idx, ex, ex.idx_ori, total);
 
-        static_assert((DCOPIES * DSTRIDE) % 4 == 0, "the accumulators are cleared 16 bytes at a time");
-        for (int i = lane; i < DCOPIES * DSTRIDE / 4; i += PSX_WAVE) reinterpret_cast<uint4*>(acc)[i] = make_uint4(0u, 0u, 0u, 0u);
+        // (the wave clears ITS words; the tail it shares with the next wave holds dump slots only)
+        for (int i = lane; i < WSTRIDE / 4; i += PSX_WAVE) reinterpret_cast<uint4*>(acc)[i] = make_uint4(0u, 0u, 0u, 0u);
         wave_fence();
 
         const float x = ex.xpos, y = ex.ypos;
@@ -1268,18 +1275,22 @@ hipError_t psx_launch_descriptors_alt(const PsxParams* d_params, const PsxCounte
 hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* d_cnt, const PsxExport& x, int cus, hipStream_t s)
 {
     const bool exporting = x.desc != nullptr;
-    // 5 workgroups (20 waves, 32 KB of LDS each) are resident per CU; 10 per CU = two full rounds measured best for
+    // 6 workgroups (24 waves, 26 KB of LDS each; 5 of 32 KB until round 6) are resident per CU; two full rounds measured best for
     // the descriptors of a 1080p frame (stage time 0.159 ms at 8 per CU, 0.143 at 10, 0.142 at 12, 0.147 at 15, 0.148
     // at 20).  With the zero-copy export attached every wave ends in stores that cross PCIe; fewer resident waves
     // leave room for the other streams' kernels meanwhile (3 per CU measured +11 % on the export leg of bench.py).
     // cus = compute units of the CONTEXT's device (one PopSift per GPU may sit on unequal devices).
     if (cus <= 0) cus = 256;
+    // POPSIFT_DESC_OCC=5: the instantiation padded to round 5's LDS footprint (five workgroups per CU), the A/B partner of the
+    // overlapped histogram copies (six per CU: descriptor stage 0.111-0.114 -> 0.107-0.108 ms with two full rounds = 12 per CU)
+    static const bool occ5 = [] { const char* e = getenv("POPSIFT_DESC_OCC"); return e != nullptr && e[0] == '5'; }();
     // POPSIFT_DESC_WGS=<workgroups per CU>: measurement switch for the grid (the waves loop over the descriptors)
     static const int per_cu = [] { const char* e = getenv("POPSIFT_DESC_WGS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }();
-    const int grid = per_cu ? per_cu * cus : exporting ? 3 * cus : 10 * cus;
+    const int grid = per_cu ? per_cu * cus : exporting ? 3 * cus : (occ5 ? 10 : 12) * cus;
     // POPSIFT_DESC_DENORM=0: round 2's conversion path (v_cvt_u32_f32 of every contribution) instead of the denormal products
     static const bool denorm = [] { const char* e = getenv("POPSIFT_DESC_DENORM"); return !(e != nullptr && e[0] == '0'); }();
-    if (denorm) hipLaunchKernelGGL(k_descriptors<true>, dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
-    else        hipLaunchKernelGGL(k_descriptors<false>, dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
+    if (!denorm)   hipLaunchKernelGGL((k_descriptors<false, 5>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
+    else if (occ5) hipLaunchKernelGGL((k_descriptors<true, 5>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
+    else           hipLaunchKernelGGL((k_descriptors<true, 6>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
     return hipGetLastError();
 }
