@@ -725,37 +725,8 @@ __global__ __launch_bounds__(NT, WGPC) void k_descriptors(const PsxParams* __res
             // of once per lane and 8-row step: ~35 VALU per step-group became one ds_bpermute and ~10); a step-group fetches
             // its rows' entries from the lanes that hold them.  Entry = first column | end column << 16, relative to the box.
             const int xmin0 = xmin & ~1;
-            for (int cy = ymin; cy <= ymax; cy += PSX_WAVE) {
-                int sp;
-                {
-                    const int ii = cy + lane;
-                    const float dyk = ii - y;
-                    const float ub = fmaf(srsbp, dyk, 1.5f);      // u = crsbp*dx + srsbp*dy + 1.5
-                    const float vb = fmaf(crsbp, dyk, 1.5f);      // v = crsbp*dy - srsbp*dx + 1.5
-                    // -1 < u < 4  <=>  crsbp*dx in (-1 - ub, 4 - ub);   -1 < v < 4  <=>  srsbp*dx in (vb - 4, vb + 1)
-                    float lo = fxmin, hi = fxmax;
-                    if (use_c) { const float t1 = (-1.0f - ub) * rcc, t2 = (4.0f - ub) * rcc; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
-                    if (use_s) { const float t1 = (vb - 4.0f) * rcs, t2 = (vb + 1.0f) * rcs; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
-                    // first / last pixel with lo < dx < hi is floor(x + lo) + 1 / ceil(x + hi) - 1: one pixel of slack on each side
-                    // covers the rounding of lo / hi (~1e-5 pixel) many times over
-                    const int xa = max(xmin, (int)floorf(x + lo)) & ~1;               // even: aligned pixel pairs
-                    const int xb = min(xmax, (int)floorf(x + hi) + 1);
-                    sp = (ii <= ymax && lo <= hi && xa <= xb) ? ((xa - xmin0) | ((xb - xmin0) << 16)) : 1;      // 1: first column 1 > end 0
-                }
-            const int cy_end = min(cy + PSX_WAVE - 1, ymax);
-            for (int ty = cy; ty <= cy_end; ty += 8) {
-                const int ii = ty + ly;
-                const int ent = __builtin_amdgcn_ds_bpermute((ty - cy) * 4 + ly * 4, sp);
-                const int xa = xmin0 + (ent & 0xffff), xb = xmin0 + (int)((unsigned)ent >> 16);
-                // an empty row ends before every column: "jj <= xbe" is then the whole row test (one v_cmp feeds the loop
-                // condition and, as a mask, the window test; all window pixels of a row lie in [xa, xb])
-                const int xbe = xa <= xb ? xb : -0x7fffffff;
-                const float dyk = ii - y;
-                const float ub = fmaf(srsbp, dyk, 1.5f);
-                const float vb = fmaf(crsbp, dyk, 1.5f);
-                const unsigned rowoff = (unsigned)ii * pitch4;
-                float fj = (float)(xa + 2 * lx);          // the column as a float beside the integer: + 16 is exact, no conversion per step
-                for (int jj = xa + 2 * lx; __builtin_amdgcn_sicmp(jj, xbe, 41 /* ICMP_SLE */) != 0ull; jj += 16, fj += 16.0f) {
+            // one pixel pair (jj, jj + 1) of row `rowoff`: ok0 / ok1 = the pixel lies in the row's span; accb = the lane's histogram copy
+            auto pixel_pair = [&](int jj, float fj, float ub, float vb, unsigned rowoff, bool ok0, bool ok1, unsigned accb) __attribute__((always_inline)) {
                     const float dx0 = fj - x;
                     const v2f dxk = (v2f){dx0, dx0 + 1.0f};
                     const v2f u = pk_fma(splat(crsbp), dxk, splat(ub));
@@ -763,8 +734,8 @@ __global__ __launch_bounds__(NT, WGPC) void k_descriptors(const PsxParams* __res
                     // the window -1 < u, v < 4 as |u - 1.5|, |v - 1.5| < 2.5: four compares with free abs modifiers instead of
                     // eight (a pixel within an ulp of the border has a weight of that order: it does not matter which side it falls)
                     const v2f un = u - splat(1.5f), vn = v - splat(1.5f);
-                    const bool in0 = (jj <= xbe) && (jj >= xmin) && (fabsf(un.x) < 2.5f) && (fabsf(vn.x) < 2.5f);     // xbe <= xmax
-                    const bool in1 = (jj < xbe) && (fabsf(un.y) < 2.5f) && (fabsf(vn.y) < 2.5f);
+                    const bool in0 = ok0 && (fabsf(un.x) < 2.5f) && (fabsf(vn.x) < 2.5f);     // xbe <= xmax
+                    const bool in1 = ok1 && (fabsf(un.y) < 2.5f) && (fabsf(vn.y) < 2.5f);
                     // (no separate "any lane?" test: the branch around the block below is taken when exec comes out empty)
                     // (a software pipeline that issues the next step's loads before this step's arithmetic was
                     // measured: the compiler's conservative s_waitcnt across the loop edge undoes it, +12 %)
@@ -833,14 +804,14 @@ __global__ __launch_bounds__(NT, WGPC) void k_descriptors(const PsxParams* __res
                                 const v2f pw = pk_fma(splat(wgt2.x), (v2f){-1.0f, 1.0f}, (v2f){1.0f, 0.0f});     // (1 - w, w) = (wgt1.x, wgt2.x) without moving components
                                 // tile (iy0, ix0) at 64-byte granules; pair view: even fo -> word fo, odd fo -> word 8 + fo - 1, i.e. the
                                 // u64 slot (b0 b2 b1) for fo = (b2 b1 b0): the three bits rotated right by one
-                                const unsigned tb = bin_slot((unsigned)(int)ffo.x) + (((unsigned)(int)tidx.x << 6) + myacc);
+                                const unsigned tb = bin_slot((unsigned)(int)ffo.x) + (((unsigned)(int)tidx.x << 6) + accb);
                                 fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                                 lds_add(t, bits(pw * splat(w00.x)));      lds_add(t + 8, bits(pw * splat(w01.x)));       // +1 tile = 16 words = 8 u64
                                 lds_add(t + 40, bits(pw * splat(w10.x))); lds_add(t + 48, bits(pw * splat(w11.x)));      // +5 / +6 tiles
                             }
                             if (in1) {
                                 const v2f pw = pk_fma(splat(wgt2.y), (v2f){-1.0f, 1.0f}, (v2f){1.0f, 0.0f});
-                                const unsigned tb = bin_slot((unsigned)(int)ffo.y) + (((unsigned)(int)tidx.y << 6) + myacc);
+                                const unsigned tb = bin_slot((unsigned)(int)ffo.y) + (((unsigned)(int)tidx.y << 6) + accb);
                                 fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                                 lds_add(t, bits(pw * splat(w00.y)));      lds_add(t + 8, bits(pw * splat(w01.y)));
                                 lds_add(t + 40, bits(pw * splat(w10.y))); lds_add(t + 48, bits(pw * splat(w11.y)));
@@ -855,21 +826,57 @@ __global__ __launch_bounds__(NT, WGPC) void k_descriptors(const PsxParams* __res
                         if (in0) {
                             const unsigned fo = (unsigned)((int)ffo.x & 7);
                             // tile (iy0, ix0) at 64-byte granules; pair view: even fo -> word fo, odd fo -> word 8 + fo - 1
-                            const unsigned tb = myacc + (unsigned)(((int)fv.x + 1) * 5 + ((int)fu.x + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                            const unsigned tb = accb + (unsigned)(((int)fv.x + 1) * 5 + ((int)fu.x + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
                             fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                             lds_add(t, pack(a00.x, b00.x));      lds_add(t + 8, pack(a01.x, b01.x));       // +1 tile = 16 words = 8 u64
                             lds_add(t + 40, pack(a10.x, b10.x)); lds_add(t + 48, pack(a11.x, b11.x));      // +5 / +6 tiles
                         }
                         if (in1) {
                             const unsigned fo = (unsigned)((int)ffo.y & 7);
-                            const unsigned tb = myacc + (unsigned)(((int)fv.y + 1) * 5 + ((int)fu.y + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
+                            const unsigned tb = accb + (unsigned)(((int)fv.y + 1) * 5 + ((int)fu.y + 1)) * 64u + (fo + 7u * (fo & 1u)) * 4u;
                             fix64 LDS_AS* t = (fix64 LDS_AS*)tb;
                             lds_add(t, pack(a00.y, b00.y));      lds_add(t + 8, pack(a01.y, b01.y));
                             lds_add(t + 40, pack(a10.y, b10.y)); lds_add(t + 48, pack(a11.y, b11.y));
                         }
                         }
                     }
+            };
+            // (Round 6 also built the walk as ONE flat list of 4-pair groups per 64-row block, 16 groups per step, each slot's row found
+            // by a binary search over the rows' prefix sums: bit-identical descriptors, 16 % fewer executed step bodies -- and the
+            // same 41.7 M VALU instructions per frame, because scan + search + per-step row terms cost what the saved bodies did; 4 %
+            // slower.  Removed again: profiles/r06_desc_flat_walk.txt.)
+            for (int cy = ymin; cy <= ymax; cy += PSX_WAVE) {
+                int sp;
+                {
+                    const int ii = cy + lane;
+                    const float dyk = ii - y;
+                    const float ub = fmaf(srsbp, dyk, 1.5f);      // u = crsbp*dx + srsbp*dy + 1.5
+                    const float vb = fmaf(crsbp, dyk, 1.5f);      // v = crsbp*dy - srsbp*dx + 1.5
+                    // -1 < u < 4  <=>  crsbp*dx in (-1 - ub, 4 - ub);   -1 < v < 4  <=>  srsbp*dx in (vb - 4, vb + 1)
+                    float lo = fxmin, hi = fxmax;
+                    if (use_c) { const float t1 = (-1.0f - ub) * rcc, t2 = (4.0f - ub) * rcc; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
+                    if (use_s) { const float t1 = (vb - 4.0f) * rcs, t2 = (vb + 1.0f) * rcs; lo = fmaxf(lo, fminf(t1, t2)); hi = fminf(hi, fmaxf(t1, t2)); }
+                    // first / last pixel with lo < dx < hi is floor(x + lo) + 1 / ceil(x + hi) - 1: one pixel of slack on each side
+                    // covers the rounding of lo / hi (~1e-5 pixel) many times over
+                    const int xa = max(xmin, (int)floorf(x + lo)) & ~1;               // even: aligned pixel pairs
+                    const int xb = min(xmax, (int)floorf(x + hi) + 1);
+                    sp = (ii <= ymax && lo <= hi && xa <= xb) ? ((xa - xmin0) | ((xb - xmin0) << 16)) : 1;      // 1: first column 1 > end 0
                 }
+            const int cy_end = min(cy + PSX_WAVE - 1, ymax);
+            for (int ty = cy; ty <= cy_end; ty += 8) {
+                const int ii = ty + ly;
+                const int ent = __builtin_amdgcn_ds_bpermute((ty - cy) * 4 + ly * 4, sp);
+                const int xa = xmin0 + (ent & 0xffff), xb = xmin0 + (int)((unsigned)ent >> 16);
+                // an empty row ends before every column: "jj <= xbe" is then the whole row test (one v_cmp feeds the loop
+                // condition and, as a mask, the window test; all window pixels of a row lie in [xa, xb])
+                const int xbe = xa <= xb ? xb : -0x7fffffff;
+                const float dyk = ii - y;
+                const float ub = fmaf(srsbp, dyk, 1.5f);
+                const float vb = fmaf(crsbp, dyk, 1.5f);
+                const unsigned rowoff = (unsigned)ii * pitch4;
+                float fj = (float)(xa + 2 * lx);          // the column as a float beside the integer: + 16 is exact, no conversion per step
+                for (int jj = xa + 2 * lx; __builtin_amdgcn_sicmp(jj, xbe, 41 /* ICMP_SLE */) != 0ull; jj += 16, fj += 16.0f)
+                    pixel_pair(jj, fj, ub, vb, rowoff, (jj <= xbe) && (jj >= xmin), jj < xbe, myacc);
             }
             }
         }

@@ -515,6 +515,24 @@ def test_match_mfma_prefilter_equals_exact_scan(oracle, capi):
         assert np.array_equal(do_.view(np.uint32), dg.view(np.uint32)), name
 
 
+def test_descriptor_lds_layouts_give_identical_descriptors():
+    """Round 6: k_descriptors keeps its four histogram copies OVERLAPPED (a copy's never-read tail on the next copy's never-read
+    head: 26 KB of LDS per workgroup, six workgroups per CU); POPSIFT_DESC_OCC=5 runs the instantiation with round 5's footprint
+    and register budget.  The histogram adds are integer, so every descriptor must come out BIT-IDENTICAL -- nine configurations
+    (sigma 2 / 2 levels: windows taller than one 64-row block; classic normalisation; a tiny frame)."""
+    import json, os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for tag, env in (("occ6", {}), ("occ5", dict(POPSIFT_DESC_OCC="5"))):
+        p = subprocess.run([sys.executable, os.path.join(here, "desc_walk_worker.py")], capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tag] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(res["occ6"]) >= 9 and sum(r["n"] > 1000 for r in res["occ6"]) >= 7, res["occ6"]
+    for a, b in zip(res["occ6"], res["occ5"]):
+        assert a == b, (a, b)
+
+
 def test_match_scratch_state_between_calls(oracle, capi):
     """psx_match keeps its scratch per calling thread and the last kernel of a call leaves the prefilter's counters zeroed
     for the next one (match.hip, MatchScratch::tidy).  Sequences that would expose stale state: the same pair three times; a
