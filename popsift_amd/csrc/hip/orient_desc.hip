@@ -1285,7 +1285,8 @@ hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* 
     // 6 workgroups (24 waves, 26 KB of LDS each; 5 of 32 KB until round 6) are resident per CU; two full rounds measured best for
     // the descriptors of a 1080p frame (stage time 0.159 ms at 8 per CU, 0.143 at 10, 0.142 at 12, 0.147 at 15, 0.148
     // at 20).  With the zero-copy export attached every wave ends in stores that cross PCIe; fewer resident waves
-    // leave room for the other streams' kernels meanwhile (3 per CU measured +11 % on the export leg of bench.py).
+    // leave room for the other streams' kernels meanwhile (3 per CU measured +11 % on the export leg of bench.py; with six resident
+    // workgroups per CU, round 6: 2 per CU 5534 Mpix/s, 3: 5204, 4 and more: 5050).
     // cus = compute units of the CONTEXT's device (one PopSift per GPU may sit on unequal devices).
     if (cus <= 0) cus = 256;
     // POPSIFT_DESC_OCC=5: the instantiation padded to round 5's LDS footprint (five workgroups per CU), the A/B partner of the
@@ -1293,7 +1294,7 @@ hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* 
     static const bool occ5 = [] { const char* e = getenv("POPSIFT_DESC_OCC"); return e != nullptr && e[0] == '5'; }();
     // POPSIFT_DESC_WGS=<workgroups per CU>: measurement switch for the grid (the waves loop over the descriptors)
     static const int per_cu = [] { const char* e = getenv("POPSIFT_DESC_WGS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }();
-    const int grid = per_cu ? per_cu * cus : exporting ? 3 * cus : (occ5 ? 10 : 12) * cus;
+    const int grid = per_cu ? per_cu * cus : exporting ? (occ5 ? 3 : 2) * cus : (occ5 ? 10 : 12) * cus;
     // POPSIFT_DESC_DENORM=0: round 2's conversion path (v_cvt_u32_f32 of every contribution) instead of the denormal products
     static const bool denorm = [] { const char* e = getenv("POPSIFT_DESC_DENORM"); return !(e != nullptr && e[0] == '0'); }();
     if (!denorm)   hipLaunchKernelGGL((k_descriptors<false, 5>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
