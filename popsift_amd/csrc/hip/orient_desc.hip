@@ -157,13 +157,14 @@ __device__ __forceinline__ int ext_count(const PsxParams* P, const PsxCounters* 
 // ---------------------------------------------------------------------------------------------
 // Orientation
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict__ P, const PsxCounters* cnt)
+template <int WB>
+__global__ __launch_bounds__(PSX_WAVE * WB) void k_orientation(const PsxParams* __restrict__ P, const PsxCounters* cnt)
 {
     // 41.23 fixed-point bins (ds_add_u64): the parabola fit through the histogram peak is ill conditioned
     // for low-contrast keypoints, so the bins keep (almost) the full float precision of every weight
     // (18.14 bins in 32 bits moved 2 of 74 000 orientations by up to 1e-3 rad in tools/fuzz_sweep.py)
     constexpr float OFIX = 8388608.0f;
-    __shared__ fix64 s_hist[WPB][HCOPIES * ORI_NBINS];
+    __shared__ fix64 s_hist[WB][HCOPIES * ORI_NBINS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     fix64* hist = s_hist[wave];
 
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(NT) void k_orientation(const PsxParams* __restrict_
     for (int o = 0; o < P->num_octaves; o++) total += ext_count(P, cnt, o);
     if (total > P->ext_capacity) total = P->ext_capacity;
 
-    const int nwaves = gridDim.x * WPB;
-    for (int ev = blockIdx.x * WPB + wave; ev < total; ev += nwaves) {
+    const int nwaves = gridDim.x * WB;
+    for (int ev = blockIdx.x * WB + wave; ev < total; ev += nwaves) {
         const int e = __builtin_amdgcn_readfirstlane(ev);          // wave uniform: scalar loads below
         int o = 0, base = 0;
         for (;;) {
@@ -627,8 +628,11 @@ __device__ __forceinline__ unsigned bin_slot(unsigned fo)
     return ((((h << 3) | h) >> 1) & 7u) << 3;            // v_and, v_lshl_or, v_bfe; the shift rides on the add
 }
 
-template <bool DENORM, int WGPC>
-__global__ __launch_bounds__(NT, WGPC) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
+// WB = waves per workgroup.  A workgroup's LDS and wave slots are released when its LAST wave ends; descriptors cost 1 : 4 by their
+// sigma, so in a 4-wave workgroup three waves wait for the one that drew the largest window (WGPC counts 4-wave workgroups per CU
+// whatever WB is: the resident waves are the same).
+template <bool DENORM, int WGPC, int WB>
+__global__ __launch_bounds__(PSX_WAVE * WB, WGPC * 4 / WB) void k_descriptors(const PsxParams* __restrict__ P, const PsxCounters* cnt, const PsxExport X)
 {
     // Histogram layout per copy: tiles (iy, ix), iy, ix in -1..4, at index (iy+1)*5 + (ix+1) (31 slots), 16 words
     // each (two views of 8 bins).  Column 0 and rows 0 / 5 are never read: the trilinear scatter of a pixel near
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(NT, WGPC) void k_descriptors(const PsxParams* __res
     static_assert(DTILES * 16 - DSTRIDE <= 6 * 16, "a copy's tail must end inside the next copy's dump slots 0..5");
     constexpr float DFIX = 16384.0f;
     // (the WGPC = 5 instantiation pads the array to round 5's 31.9 KB: the A/B partner, POPSIFT_DESC_OCC=5)
-    __shared__ __attribute__((aligned(16))) unsigned s_desc[WPB * WSTRIDE + (DTILES * 16 - DSTRIDE) + 2 + (WGPC == 5 ? 1440 : 0)];
+    __shared__ __attribute__((aligned(16))) unsigned s_desc[WB * WSTRIDE + (DTILES * 16 - DSTRIDE) + 2 + (WGPC == 5 ? 1440 : 0)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned* acc = s_desc + wave * WSTRIDE;
     const int lx = lane & 7, ly = lane >> 3;
@@ -657,8 +661,8 @@ __global__ __launch_bounds__(NT, WGPC) void k_descriptors(const PsxParams* __res
     const unsigned myacc = (unsigned)(uintptr_t)(acc + copy * DSTRIDE);
 
     const int total = cnt->ori_total;
-    const int nwaves = gridDim.x * WPB;
-    for (int jv = blockIdx.x * WPB + wave; jv < total; jv += nwaves) {
+    const int nwaves = gridDim.x * WB;
+    for (int jv = blockIdx.x * WB + wave; jv < total; jv += nwaves) {
         const int j = __builtin_amdgcn_readfirstlane(jv);
         const int ext_idx = P->feat_to_ext[j];
         const psx_extremum ex = P->extrema[ext_idx];
@@ -1252,7 +1256,11 @@ __global__ __launch_bounds__(NT) void k_descriptors_alt(const PsxParams* __restr
 
 hipError_t psx_launch_orientation(const PsxParams* d_params, PsxCounters* d_cnt, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_orientation, dim3(2048), dim3(NT), 0, s, d_params, d_cnt);
+    // POPSIFT_ORI_WPB=1 / 4: waves per workgroup (as k_descriptors: a keypoint's window grows with sigma^2); measured: no difference
+    // (profiles/r06_desc_waves_per_workgroup.txt), four stays
+    static const int wb = [] { const char* e = getenv("POPSIFT_ORI_WPB"); const int v = e ? atoi(e) : 0; return v == 1 || v == 4 ? v : 4; }();
+    if (wb == 1) hipLaunchKernelGGL(k_orientation<1>, dim3(2048 * 4), dim3(PSX_WAVE), 0, s, d_params, d_cnt);
+    else         hipLaunchKernelGGL(k_orientation<4>, dim3(2048), dim3(NT), 0, s, d_params, d_cnt);
     return hipGetLastError();
 }
 
@@ -1297,8 +1305,15 @@ hipError_t psx_launch_descriptors(const PsxParams* d_params, const PsxCounters* 
     const int grid = per_cu ? per_cu * cus : exporting ? (occ5 ? 3 : 2) * cus : (occ5 ? 10 : 12) * cus;
     // POPSIFT_DESC_DENORM=0: round 2's conversion path (v_cvt_u32_f32 of every contribution) instead of the denormal products
     static const bool denorm = [] { const char* e = getenv("POPSIFT_DESC_DENORM"); return !(e != nullptr && e[0] == '0'); }();
-    if (!denorm)   hipLaunchKernelGGL((k_descriptors<false, 5>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
-    else if (occ5) hipLaunchKernelGGL((k_descriptors<true, 5>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
-    else           hipLaunchKernelGGL((k_descriptors<true, 6>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
+    // POPSIFT_DESC_WPB=1 / 2 / 4: waves per workgroup (the grid keeps its number of waves).  Default: ONE wave per workgroup (a wave's
+    // LDS and slot are free the moment IT is done, not when the slowest of four is: end to end 6806-6847 -> 6872-6879 Mpix/s, device
+    // resident 7005-7011 -> 7047-7058 in three A/B pairs, profiles/r06_desc_waves_per_workgroup.txt); four with the zero-copy export
+    // attached (5451 against 5386 Mpix/s on that leg)
+    static const int wb = [] { const char* e = getenv("POPSIFT_DESC_WPB"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 0; }();
+    if (!denorm)      hipLaunchKernelGGL((k_descriptors<false, 5, 4>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
+    else if (occ5)    hipLaunchKernelGGL((k_descriptors<true, 5, 4>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
+    else if (wb == 1 || (wb == 0 && !exporting)) hipLaunchKernelGGL((k_descriptors<true, 6, 1>), dim3(grid * 4), dim3(PSX_WAVE), 0, s, d_params, d_cnt, x);
+    else if (wb == 2) hipLaunchKernelGGL((k_descriptors<true, 6, 2>), dim3(grid * 2), dim3(2 * PSX_WAVE), 0, s, d_params, d_cnt, x);
+    else              hipLaunchKernelGGL((k_descriptors<true, 6, 4>), dim3(grid), dim3(NT), 0, s, d_params, d_cnt, x);
     return hipGetLastError();
 }
